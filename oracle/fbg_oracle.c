@@ -1,0 +1,1128 @@
+/*
+ * fbg_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement ("oracle-by-reading") of the segmentation hot path of
+ * algbio/founderblockgraphs, file founderblockgraph.cpp (abbreviated fbg.cpp below,
+ * commit mounted 2025-03-21).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product path
+ * (founderblockgraphs_amd/csrc, libfbg_hip.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference cannot be built here (its sdsl-lite submodule is
+ * empty, fbg.cpp:5) and ships no expected outputs, so this
+ * restatement is pinned only by (i) a second, structurally different restatement in
+ * this same file that emulates the reference's suffix-tree walk node by node
+ * (orc_compute_f_literal, orc_segment_v_literal), (ii) brute-force definition
+ * checkers in tests/, and (iii) the hand-derived vectors of SURVEY.md Appendix B
+ * (tests/golden/appendix_b.json).  None of those was produced by the sdsl binary.
+ *
+ * The arithmetic the reference delegates to sdsl-lite v3 (xxsds fork, commit pin
+ * not recoverable: .gitmodules:4-6) is restated with plain arrays:
+ *   cst.csa.isa[p]            -> ISA[p]
+ *   select_leaf(k)            -> the leaf of SA rank k-1 (1-based argument)
+ *   lb(v), rb(v)              -> the lcp-interval [l,r] of node v
+ *   parent(v), depth(v)       -> enclosing lcp-interval, its minimum LCP value
+ *   sl(leaf)                  -> ISA[SA[r]+1]        (suffix link of a leaf)
+ *   sn(leaf)                  -> SA[r]
+ *   backward_search(c)        -> C[c] + Occ(c, .)    (FM step on the BWT)
+ *   rank_support(i)           -> number of ones in [0,i)
+ *   select_support(k)         -> position of the k-th one, k 1-based
+ * Suffixes compare as unsigned bytes; sdsl::construct(..., 1) appends one 0 byte.
+ *
+ * Index width: int32 (text length < 2^31); enough for every test and for the
+ * bounded CPU-baseline samples of bench.py.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <pthread.h>
+
+typedef int32_t idx_t;
+#define ORC_OK 0
+#define ORC_ERR_ALLOC 1
+#define ORC_ERR_TOO_LARGE 2
+#define ORC_ERR_NO_SEGMENTATION 3
+#define ORC_ERR_IO 4
+
+/* ------------------------------------------------------------------------- */
+/* Suffix array: SA-IS (induced sorting), written for this oracle.            */
+/* Text must end with a unique smallest symbol.                               */
+/* ------------------------------------------------------------------------- */
+
+static inline idx_t sym_at(const void *T, int wide, idx_t i)
+{
+    return wide ? ((const idx_t *)T)[i] : (idx_t)((const uint8_t *)T)[i];
+}
+
+static void bucket_heads(const idx_t *cnt, idx_t *bkt, idx_t K)
+{
+    idx_t sum = 0;
+    for (idx_t c = 0; c < K; c++) { bkt[c] = sum; sum += cnt[c]; }
+}
+
+static void bucket_tails(const idx_t *cnt, idx_t *bkt, idx_t K)
+{
+    idx_t sum = 0;
+    for (idx_t c = 0; c < K; c++) { sum += cnt[c]; bkt[c] = sum; }
+}
+
+/* stype[i]=1 : suffix i is S-type */
+static inline int is_lms(const uint8_t *stype, idx_t i)
+{
+    return i > 0 && stype[i] && !stype[i - 1];
+}
+
+static void induce_LS(const void *T, int wide, idx_t *SA, idx_t n, idx_t K,
+                      const uint8_t *stype, const idx_t *cnt, idx_t *bkt)
+{
+    bucket_heads(cnt, bkt, K);
+    for (idx_t i = 0; i < n; i++) {
+        idx_t j = SA[i];
+        if (j > 0 && !stype[j - 1]) SA[bkt[sym_at(T, wide, j - 1)]++] = j - 1;
+    }
+    bucket_tails(cnt, bkt, K);
+    for (idx_t i = n - 1; i >= 0; i--) {
+        idx_t j = SA[i];
+        if (j > 0 && stype[j - 1]) SA[--bkt[sym_at(T, wide, j - 1)]] = j - 1;
+    }
+}
+
+static int sais_rec(const void *T, int wide, idx_t *SA, idx_t n, idx_t K)
+{
+    if (n == 1) { SA[0] = 0; return 0; }
+    uint8_t *stype = (uint8_t *)malloc((size_t)n);
+    idx_t *cnt = (idx_t *)calloc((size_t)K, sizeof(idx_t));
+    idx_t *bkt = (idx_t *)malloc((size_t)K * sizeof(idx_t));
+    if (!stype || !cnt || !bkt) { free(stype); free(cnt); free(bkt); return ORC_ERR_ALLOC; }
+
+    stype[n - 1] = 1;
+    for (idx_t i = n - 2; i >= 0; i--) {
+        idx_t a = sym_at(T, wide, i), b = sym_at(T, wide, i + 1);
+        stype[i] = (a < b) || (a == b && stype[i + 1]);
+    }
+    for (idx_t i = 0; i < n; i++) cnt[sym_at(T, wide, i)]++;
+
+    idx_t n1 = 0;
+    for (idx_t i = 1; i < n; i++) n1 += is_lms(stype, i);
+    idx_t *lmspos = (idx_t *)malloc((size_t)(n1 > 0 ? n1 : 1) * sizeof(idx_t));
+    if (!lmspos) { free(stype); free(cnt); free(bkt); return ORC_ERR_ALLOC; }
+    {
+        idx_t k = 0;
+        for (idx_t i = 1; i < n; i++) if (is_lms(stype, i)) lmspos[k++] = i;
+    }
+
+    /* pass 1: sort LMS substrings */
+    for (idx_t i = 0; i < n; i++) SA[i] = -1;
+    bucket_tails(cnt, bkt, K);
+    for (idx_t k = n1 - 1; k >= 0; k--) SA[--bkt[sym_at(T, wide, lmspos[k])]] = lmspos[k];
+    induce_LS(T, wide, SA, n, K, stype, cnt, bkt);
+
+    /* name LMS substrings in sorted order */
+    idx_t *name_of = (idx_t *)malloc((size_t)(n / 2 + 2) * sizeof(idx_t)); /* by pos/2 */
+    idx_t *s1 = (idx_t *)malloc((size_t)(n1 > 0 ? n1 : 1) * sizeof(idx_t));
+    idx_t *SA1 = (idx_t *)malloc((size_t)(n1 > 0 ? n1 : 1) * sizeof(idx_t));
+    if (!name_of || !s1 || !SA1) {
+        free(stype); free(cnt); free(bkt); free(lmspos); free(name_of); free(s1); free(SA1);
+        return ORC_ERR_ALLOC;
+    }
+    idx_t names = 0, prev = -1;
+    for (idx_t i = 0; i < n; i++) {
+        idx_t p = SA[i];
+        if (p <= 0 || !is_lms(stype, p)) continue;
+        int same = 0;
+        if (prev >= 0) {
+            same = 1;
+            for (idx_t d = 0;; d++) {
+                if (sym_at(T, wide, p + d) != sym_at(T, wide, prev + d) ||
+                    stype[p + d] != stype[prev + d]) { same = 0; break; }
+                if (d > 0) {
+                    int e1 = is_lms(stype, p + d), e2 = is_lms(stype, prev + d);
+                    if (e1 || e2) { same = e1 && e2; break; }
+                }
+            }
+        }
+        if (!same) names++;
+        name_of[p >> 1] = names - 1;
+        prev = p;
+    }
+    for (idx_t k = 0; k < n1; k++) s1[k] = name_of[lmspos[k] >> 1];
+    free(name_of);
+
+    int rc = 0;
+    if (names < n1) {
+        rc = sais_rec(s1, 1, SA1, n1, names);
+    } else {
+        for (idx_t k = 0; k < n1; k++) SA1[s1[k]] = k;
+    }
+    if (rc == 0) {
+        /* pass 2: place LMS suffixes in their final relative order, induce the rest */
+        for (idx_t i = 0; i < n; i++) SA[i] = -1;
+        bucket_tails(cnt, bkt, K);
+        for (idx_t k = n1 - 1; k >= 0; k--) {
+            idx_t p = lmspos[SA1[k]];
+            SA[--bkt[sym_at(T, wide, p)]] = p;
+        }
+        induce_LS(T, wide, SA, n, K, stype, cnt, bkt);
+    }
+    free(stype); free(cnt); free(bkt); free(lmspos); free(s1); free(SA1);
+    return rc;
+}
+
+/* T[0..N): byte text whose last byte is a unique smallest sentinel (0). */
+int orc_suffix_array(const uint8_t *T, int64_t N, int32_t *SA)
+{
+    if (N <= 0 || N >= INT32_MAX) return ORC_ERR_TOO_LARGE;
+    return sais_rec(T, 0, SA, (idx_t)N, 256);
+}
+
+/* LCP[r] = lcp(SA[r-1], SA[r]) for r >= 1, LCP[0] = 0 (Kasai et al.). */
+void orc_lcp_kasai(const uint8_t *T, int64_t N, const int32_t *SA, int32_t *ISA, int32_t *LCP)
+{
+    idx_t n = (idx_t)N;
+    for (idx_t r = 0; r < n; r++) ISA[SA[r]] = r;
+    idx_t h = 0;
+    LCP[0] = 0;
+    for (idx_t p = 0; p < n; p++) {
+        idx_t r = ISA[p];
+        if (r == 0) { h = 0; continue; }
+        idx_t q = SA[r - 1];
+        while (p + h < n && q + h < n && T[p + h] == T[q + h]) h++;
+        LCP[r] = h;
+        if (h > 0) h--;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Index over the MSA: text layout of load_cst (fbg.cpp:372-386) + sentinel  */
+/* appended by sdsl::construct(cst, file, 1) (fbg.cpp:428).                  */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int64_t m, n;
+    idx_t N;          /* text length including the 0 sentinel */
+    uint8_t *T;
+    idx_t *pos;       /* pos[i] = offset of row i in T (fbg.cpp:1596-1600) */
+    idx_t *tot;       /* tot[i] = indexedrows_rs[i].rank(n) */
+    idx_t *SA, *ISA, *LCP; /* LCP has N+1 entries, LCP[N] = 0 */
+} orc_index;
+
+static void orc_index_free(orc_index *ix)
+{
+    free(ix->T); free(ix->pos); free(ix->tot); free(ix->SA); free(ix->ISA); free(ix->LCP);
+    memset(ix, 0, sizeof(*ix));
+}
+
+/* reversed != 0: every gap-stripped row is written back to front (used only by the
+ * mirror-image cross-check of the non-elastic scan, never by the literal paths). */
+static int orc_index_build(orc_index *ix, const uint8_t *msa, int64_t m, int64_t n, int reversed)
+{
+    memset(ix, 0, sizeof(*ix));
+    ix->m = m; ix->n = n;
+    int64_t nongap = 0;
+    for (int64_t c = 0; c < m * n; c++) nongap += msa[c] != '-';
+    int64_t N = nongap + m + 1;
+    if (N >= INT32_MAX) return ORC_ERR_TOO_LARGE;
+    ix->N = (idx_t)N;
+    ix->T = (uint8_t *)malloc((size_t)N);
+    ix->pos = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    ix->tot = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    ix->SA = (idx_t *)malloc((size_t)N * sizeof(idx_t));
+    ix->ISA = (idx_t *)malloc((size_t)N * sizeof(idx_t));
+    ix->LCP = (idx_t *)malloc((size_t)(N + 1) * sizeof(idx_t));
+    if (!ix->T || !ix->pos || !ix->tot || !ix->SA || !ix->ISA || !ix->LCP) {
+        orc_index_free(ix); return ORC_ERR_ALLOC;
+    }
+    idx_t k = 0;
+    for (int64_t i = 0; i < m; i++) {
+        const uint8_t *row = msa + i * n;
+        ix->pos[i] = k;
+        if (!reversed) {
+            for (int64_t j = 0; j < n; j++) if (row[j] != '-') ix->T[k++] = row[j];
+        } else {
+            for (int64_t j = n - 1; j >= 0; j--) if (row[j] != '-') ix->T[k++] = row[j];
+        }
+        ix->tot[i] = k - ix->pos[i];
+        ix->T[k++] = '#';
+    }
+    ix->T[k++] = 0;
+    int rc = orc_suffix_array(ix->T, N, ix->SA);
+    if (rc) { orc_index_free(ix); return rc; }
+    orc_lcp_kasai(ix->T, N, ix->SA, ix->ISA, ix->LCP);
+    ix->LCP[N] = 0;
+    return 0;
+}
+
+/* Exposed for tests: SA / ISA / LCP of the reference's text for an MSA. */
+int orc_msa_index(const uint8_t *msa, int64_t m, int64_t n, int64_t *N_out,
+                  uint8_t *T_out, int32_t *SA_out, int32_t *ISA_out, int32_t *LCP_out)
+{
+    orc_index ix;
+    int rc = orc_index_build(&ix, msa, m, n, 0);
+    if (rc) return rc;
+    *N_out = ix.N;
+    if (T_out) memcpy(T_out, ix.T, (size_t)ix.N);
+    if (SA_out) memcpy(SA_out, ix.SA, (size_t)ix.N * sizeof(idx_t));
+    if (ISA_out) memcpy(ISA_out, ix.ISA, (size_t)ix.N * sizeof(idx_t));
+    if (LCP_out) memcpy(LCP_out, ix.LCP, (size_t)ix.N * sizeof(idx_t));
+    orc_index_free(&ix);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Elastic preprocessing (fbg.cpp:1845-1917) as plain tables.                */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    uint8_t is_ignore[256];
+    int have_ignore;
+    idx_t **colsel;    /* colsel[i][k-1] = indexedrows_ss[i].select(k) */
+    idx_t **nextign;   /* nextign[i][x] = first ignore-char column >= x, or n */
+} orc_rows;
+
+static void orc_rows_free(orc_rows *rw, int64_t m)
+{
+    if (rw->colsel) { for (int64_t i = 0; i < m; i++) free(rw->colsel[i]); free(rw->colsel); }
+    if (rw->nextign) { for (int64_t i = 0; i < m; i++) free(rw->nextign[i]); free(rw->nextign); }
+    memset(rw, 0, sizeof(*rw));
+}
+
+static int orc_rows_build(orc_rows *rw, const orc_index *ix, const uint8_t *msa,
+                          const uint8_t *ignore, int64_t ignore_len)
+{
+    int64_t m = ix->m, n = ix->n;
+    memset(rw, 0, sizeof(*rw));
+    for (int64_t k = 0; k < ignore_len; k++) rw->is_ignore[ignore[k]] = 1; /* fbg.cpp:1868 */
+    rw->have_ignore = ignore_len > 0;                                    /* fbg.cpp:1891 */
+    rw->colsel = (idx_t **)calloc((size_t)m, sizeof(idx_t *));
+    if (!rw->colsel) return ORC_ERR_ALLOC;
+    for (int64_t i = 0; i < m; i++) {
+        rw->colsel[i] = (idx_t *)malloc((size_t)(ix->tot[i] > 0 ? ix->tot[i] : 1) * sizeof(idx_t));
+        if (!rw->colsel[i]) return ORC_ERR_ALLOC;
+        idx_t k = 0;
+        for (int64_t j = 0; j < n; j++) if (msa[i * n + j] != '-') rw->colsel[i][k++] = (idx_t)j;
+    }
+    if (rw->have_ignore) {
+        rw->nextign = (idx_t **)calloc((size_t)m, sizeof(idx_t *));
+        if (!rw->nextign) return ORC_ERR_ALLOC;
+        for (int64_t i = 0; i < m; i++) {
+            rw->nextign[i] = (idx_t *)malloc((size_t)(n + 1) * sizeof(idx_t));
+            if (!rw->nextign[i]) return ORC_ERR_ALLOC;
+            idx_t nx = (idx_t)n;
+            rw->nextign[i][n] = nx;
+            for (int64_t j = n - 1; j >= 0; j--) {
+                if (rw->is_ignore[msa[i * n + j]]) nx = (idx_t)j;
+                rw->nextign[i][j] = nx;
+            }
+        }
+    }
+    return 0;
+}
+
+/* fi of one row for extension g (fbg.cpp:1656-1672). nz = indexedrows_rs[i].rank(x). */
+static inline uint64_t orc_fi(const orc_index *ix, const orc_rows *rw, int64_t i, int64_t x,
+                              idx_t nz, uint64_t g, int disable_tricks)
+{
+    uint64_t gg = (uint64_t)nz + g, fi;
+    if (gg > (uint64_t)ix->tot[i]) {
+        if (!disable_tricks) fi = (uint64_t)rw->colsel[i][ix->tot[i] - 1];
+        else fi = (uint64_t)ix->n;
+    } else {
+        fi = (uint64_t)rw->colsel[i][gg - 1];
+    }
+    if (rw->have_ignore && rw->nextign[i][x] < ix->n) {
+        uint64_t c = (uint64_t)rw->nextign[i][x];
+        if (c < fi) fi = c;
+    }
+    return fi;
+}
+
+/* ------------------------------------------------------------------------- */
+/* compute_f, formulation 1 ("runs"): SURVEY.md Appendix A.1.                */
+/* For column x the coloured SA ranks are sorted; inside each maximal run of */
+/* consecutive ranks [lb..rb], depth(parent(exclusive ancestor)) of member r */
+/* is max(min LCP[lb..r], min LCP[r+1..rb+1]).  fbg.cpp:1610-1694.           */
+/* ------------------------------------------------------------------------- */
+
+static void sort_u64(uint64_t *a, uint64_t *tmp, idx_t cnt)
+{
+    /* LSD radix on the rank half (bits 32..62), 11 bits per pass */
+    if (cnt < 48) {
+        for (idx_t i = 1; i < cnt; i++) {
+            uint64_t v = a[i]; idx_t j = i;
+            while (j > 0 && a[j - 1] > v) { a[j] = a[j - 1]; j--; }
+            a[j] = v;
+        }
+        return;
+    }
+    uint32_t hist[2048];
+    uint64_t *src = a, *dst = tmp;
+    for (int pass = 0; pass < 3; pass++) {
+        int sh = 32 + 11 * pass;
+        memset(hist, 0, sizeof(hist));
+        for (idx_t i = 0; i < cnt; i++) hist[(src[i] >> sh) & 2047]++;
+        uint32_t sum = 0;
+        for (int b = 0; b < 2048; b++) { uint32_t c = hist[b]; hist[b] = sum; sum += c; }
+        for (idx_t i = 0; i < cnt; i++) dst[hist[(src[i] >> sh) & 2047]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, (size_t)cnt * sizeof(uint64_t));
+}
+
+typedef struct {
+    const orc_index *ix; const orc_rows *rw; const uint8_t *msa;
+    int disable_tricks; int64_t x0, x1; uint64_t *f; int rc;
+} f_range_job;
+
+/* Columns [x0, x1] (inclusive), initialised like compute_f_range (fbg.cpp:1494-1501):
+ * row pointers start at rank(x0). Tricks-enabled semantics of compute_f. */
+static void *f_range_runs(void *arg)
+{
+    f_range_job *jb = (f_range_job *)arg;
+    const orc_index *ix = jb->ix; const orc_rows *rw = jb->rw;
+    int64_t m = ix->m, n = ix->n;
+    idx_t *nz = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    uint64_t *keys = (uint64_t *)malloc((size_t)m * sizeof(uint64_t));
+    uint64_t *tmp = (uint64_t *)malloc((size_t)m * sizeof(uint64_t));
+    idx_t *lmin = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    if (!nz || !keys || !tmp || !lmin) { jb->rc = ORC_ERR_ALLOC; goto done; }
+    for (int64_t i = 0; i < m; i++) {
+        idx_t c = 0;
+        for (int64_t j = 0; j < jb->x0; j++) c += jb->msa[i * n + j] != '-';
+        nz[i] = c;
+    }
+    for (int64_t x = jb->x0; x <= jb->x1; x++) {
+        uint64_t fimax = (uint64_t)x;                                 /* fbg.cpp:1618 */
+        idx_t cnt = 0;
+        for (int64_t i = 0; i < m; i++) {
+            if (!jb->disable_tricks && nz[i] == 0) continue;          /* fullrow, 1621/1631 */
+            keys[cnt++] = ((uint64_t)(uint32_t)ix->ISA[ix->pos[i] + nz[i]] << 32) | (uint64_t)i;
+        }
+        sort_u64(keys, tmp, cnt);
+        for (idx_t a = 0; a < cnt;) {
+            idx_t b = a;
+            while (b + 1 < cnt && (keys[b + 1] >> 32) == (keys[b] >> 32) + 1) b++;
+            /* run keys[a..b] = ranks lb..rb */
+            idx_t run = ix->LCP[(idx_t)(keys[a] >> 32)];
+            lmin[a] = run;
+            for (idx_t k = a + 1; k <= b; k++) {
+                idx_t v = ix->LCP[(idx_t)(keys[k] >> 32)];
+                if (v < run) run = v;
+                lmin[k] = run;
+            }
+            idx_t rmin = INT32_MAX;
+            for (idx_t k = b; k >= a; k--) {
+                idx_t r = (idx_t)(keys[k] >> 32);
+                idx_t v = ix->LCP[r + 1];
+                if (v < rmin) rmin = v;
+                uint64_t g = (uint64_t)(lmin[k] > rmin ? lmin[k] : rmin) + 1; /* 1656 */
+                int64_t i = (int64_t)(keys[k] & 0xffffffffu);
+                uint64_t fi = orc_fi(ix, rw, i, x, nz[i], g, jb->disable_tricks);
+                if (fi > fimax) fimax = fi;                                 /* 1671 */
+            }
+            a = b + 1;
+        }
+        if (fimax > jb->f[x]) jb->f[x] = fimax;                       /* 1681: max-merge */
+        for (int64_t i = 0; i < m; i++) nz[i] += jb->msa[i * n + x] != '-'; /* 1687-1691 */
+    }
+done:
+    free(nz); free(keys); free(tmp); free(lmin);
+    return NULL;
+}
+
+/*
+ * f[x] for all columns; f is max-merged into (caller zero-fills, fbg.cpp:3388,1681).
+ * threads <= 1 : compute_f (fbg.cpp:1579-1695).
+ * threads  > 1 : the reference's --threads partition, ranges [x, min(x+n/T, n-1)]
+ *                (fbg.cpp:2278-2289) over compute_f_range (1475-1577).  With tricks
+ *                enabled both produce the same f; the hidden --disable-elastic-tricks
+ *                leavesmap quirk of compute_f_range is NOT restated.
+ */
+int orc_compute_f(const uint8_t *msa, int64_t m, int64_t n, const uint8_t *ignore,
+                  int64_t ignore_len, int disable_tricks, int threads, uint64_t *f,
+                  double *t_index_s, double *t_scan_s);
+
+/* ------------------------------------------------------------------------- */
+/* compute_f, formulation 2 ("literal"): emulates the suffix-tree walk of    */
+/* fbg.cpp:1610-1694 node by node on lcp-intervals.  Slow; cross-check only. */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { idx_t l, r; } node_t;
+
+static node_t st_parent(const orc_index *ix, node_t v, idx_t *depth_out)
+{
+    idx_t N = ix->N;
+    if (v.l == 0 && v.r == N - 1) { if (depth_out) *depth_out = 0; return v; }
+    idx_t hl = v.l > 0 ? ix->LCP[v.l] : -1;
+    idx_t hr = v.r + 1 < N ? ix->LCP[v.r + 1] : -1;
+    idx_t h = hl > hr ? hl : hr;
+    node_t p = v;
+    while (p.l > 0 && ix->LCP[p.l] >= h) p.l--;
+    while (p.r + 1 < N && ix->LCP[p.r + 1] >= h) p.r++;
+    if (depth_out) *depth_out = h;
+    return p;
+}
+
+int orc_compute_f_literal(const uint8_t *msa, int64_t m, int64_t n, const uint8_t *ignore,
+                          int64_t ignore_len, int disable_tricks, uint64_t *f)
+{
+    orc_index ix; orc_rows rw;
+    int rc = orc_index_build(&ix, msa, m, n, 0);
+    if (rc) return rc;
+    rc = orc_rows_build(&rw, &ix, msa, ignore, ignore_len);
+    if (rc) { orc_rows_free(&rw, m); orc_index_free(&ix); return rc; }
+    idx_t N = ix.N;
+    idx_t *leaf = (idx_t *)malloc((size_t)m * sizeof(idx_t));     /* SA rank of leaves[i] */
+    idx_t *nz = (idx_t *)calloc((size_t)m, sizeof(idx_t));
+    idx_t *leavesmap = (idx_t *)malloc((size_t)N * sizeof(idx_t)); /* rank -> row, -1 none */
+    uint8_t *color = (uint8_t *)calloc((size_t)N, 1);
+    uint8_t *fullrow = (uint8_t *)malloc((size_t)m);
+    if (!leaf || !nz || !leavesmap || !color || !fullrow) { rc = ORC_ERR_ALLOC; goto out; }
+    for (idx_t r = 0; r < N; r++) leavesmap[r] = -1;
+    for (int64_t i = 0; i < m; i++) {                               /* 1596-1600 */
+        leaf[i] = ix.ISA[ix.pos[i]];
+        leavesmap[leaf[i]] = (idx_t)i;
+        fullrow[i] = disable_tricks ? 0 : 1;                        /* 1605-1608 */
+    }
+    for (int64_t x = 0; x < n; x++) {
+        uint64_t fimax = (uint64_t)x;
+        for (int64_t i = 0; i < m; i++) if (!fullrow[i]) color[leaf[i]] = 1; /* 1620-1626 */
+        for (int64_t i = 0; i < m; i++) {
+            idx_t l = leaf[i];
+            if (fullrow[i]) continue;
+            if (l == 0 || !color[l - 1]) {                          /* 1633 */
+                /* 1635: row of SA[l] must be i; holds by construction, kept as a check */
+                {
+                    idx_t p = ix.SA[l]; int64_t row = 0;
+                    while (row + 1 < m && ix.pos[row + 1] <= p) row++;
+                    if (row != i) break;
+                }
+                idx_t lb = l, rb = l;
+                while (rb < N - 1 && color[rb + 1]) rb++;           /* 1639-1641 */
+                node_t w = { l, l };
+                while (w.r <= rb) {                                 /* 1645 */
+                    idx_t pdepth;
+                    node_t par = st_parent(&ix, w, &pdepth);
+                    if (lb <= par.l && par.r <= rb) {
+                        w = par;                                    /* 1647-1649 */
+                    } else {
+                        for (idx_t ll = w.l; ll <= w.r; ll++) {     /* 1652 */
+                            idx_t ii = leavesmap[ll];
+                            if (ii < 0) { rc = ORC_ERR_NO_SEGMENTATION; goto out; } /* assert 1655 */
+                            uint64_t g = (uint64_t)pdepth + 1;      /* 1656 */
+                            uint64_t fi = orc_fi(&ix, &rw, ii, x, nz[ii], g, disable_tricks);
+                            if (fi > fimax) fimax = fi;
+                        }
+                        if (w.r == N - 1) break;                    /* 1674 */
+                        w.l = w.r = w.r + 1;                        /* 1676 */
+                    }
+                }
+            }
+        }
+        if (fimax > f[x]) f[x] = fimax;                             /* 1681 */
+        for (int64_t i = 0; i < m; i++) {
+            color[leaf[i]] = 0;                                     /* 1684-1686 */
+            if (msa[i * n + x] != '-') {
+                leavesmap[leaf[i]] = -1;                            /* 1688 */
+                leaf[i] = ix.ISA[ix.SA[leaf[i]] + 1];               /* 1689: sl(leaf) */
+                leavesmap[leaf[i]] = (idx_t)i;
+                nz[i]++;
+                fullrow[i] = 0;
+            }
+        }
+    }
+out:
+    free(leaf); free(nz); free(leavesmap); free(color); free(fullrow);
+    orc_rows_free(&rw, m); orc_index_free(&ix);
+    return rc;
+}
+
+#include <time.h>
+static double now_s(void)
+{
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int orc_compute_f(const uint8_t *msa, int64_t m, int64_t n, const uint8_t *ignore,
+                  int64_t ignore_len, int disable_tricks, int threads, uint64_t *f,
+                  double *t_index_s, double *t_scan_s)
+{
+    orc_index ix; orc_rows rw;
+    double t0 = now_s();
+    int rc = orc_index_build(&ix, msa, m, n, 0);
+    if (rc) return rc;
+    double t1 = now_s();
+    rc = orc_rows_build(&rw, &ix, msa, ignore, ignore_len);
+    if (rc) { orc_rows_free(&rw, m); orc_index_free(&ix); return rc; }
+    if (threads <= 1) {
+        f_range_job jb = { &ix, &rw, msa, disable_tricks, 0, n - 1, f, 0 };
+        f_range_runs(&jb);
+        rc = jb.rc;
+    } else {
+        int64_t step = n / threads;                                  /* fbg.cpp:2282-2283 */
+        f_range_job *jobs = (f_range_job *)calloc((size_t)threads, sizeof(f_range_job));
+        pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+        for (int64_t x = 0; x < n;) {
+            int k = 0;
+            for (; k < threads && x < n; k++) {
+                int64_t e = x + step < n - 1 ? x + step : n - 1;
+                jobs[k] = (f_range_job){ &ix, &rw, msa, disable_tricks, x, e, f, 0 };
+                pthread_create(&th[k], NULL, f_range_runs, &jobs[k]);
+                x = e + 1;
+            }
+            for (int j = 0; j < k; j++) { pthread_join(th[j], NULL); if (jobs[j].rc) rc = jobs[j].rc; }
+        }
+        free(jobs); free(th);
+    }
+    double t2 = now_s();
+    if (t_index_s) *t_index_s = t1 - t0;
+    if (t_scan_s) *t_scan_s = t2 - t1;
+    orc_rows_free(&rw, m); orc_index_free(&ix);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Min-max-length DP + backtrack, literal (fbg.cpp:1940-2039).               */
+/* ------------------------------------------------------------------------- */
+
+static int cmp_pair_second(const void *a, const void *b)
+{
+    const uint64_t *pa = (const uint64_t *)a, *pb = (const uint64_t *)b;
+    return (pa[1] > pb[1]) - (pa[1] < pb[1]);
+}
+
+/*
+ * f[0..n) -> minmaxlength[0..n], backtrack[0..n], boundaries (count written).
+ * mml_out / bt_out may be NULL.  boundaries_out needs room for n+1 entries.
+ * Returns ORC_ERR_NO_SEGMENTATION where the reference would walk backtrack[] out of
+ * bounds (only reachable with --disable-elastic-tricks).
+ */
+int orc_minmax_dp(const uint64_t *f, int64_t n_, uint64_t *mml_out, uint64_t *bt_out,
+                  uint64_t *boundaries_out, int64_t *count_out)
+{
+    uint64_t n = (uint64_t)n_;
+    uint64_t *E = (uint64_t *)malloc((size_t)n * 2 * sizeof(uint64_t)); /* (x, f+1) */
+    uint64_t *count = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint64_t *bcount = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint64_t *mml = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint64_t *bt = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    /* transition_list[0..n+1]: singly linked, append order kept (push_back, 1983) */
+    int64_t *thead = (int64_t *)malloc((size_t)(n + 2) * sizeof(int64_t));
+    int64_t *ttail = (int64_t *)malloc((size_t)(n + 2) * sizeof(int64_t));
+    int64_t *tnext = (int64_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t)); /* per E entry */
+    if (!E || !count || !bcount || !mml || !bt || !thead || !ttail || !tnext) {
+        free(E); free(count); free(bcount); free(mml); free(bt); free(thead); free(ttail); free(tnext);
+        return ORC_ERR_ALLOC;
+    }
+    for (uint64_t x = 0; x < n; x++) { E[2 * x] = x; E[2 * x + 1] = f[x] + 1; }  /* 1943-1946 */
+    qsort(E, (size_t)n, 2 * sizeof(uint64_t), cmp_pair_second);                /* 1953 */
+    for (uint64_t j = 0; j < n + 2; j++) thead[j] = ttail[j] = -1;
+
+    uint64_t y = 0, I = 0, S = n + 1, bS = (uint64_t)-1;                         /* 1967 */
+    for (uint64_t j = 1; j <= n; j++) {
+        while (y < n && j == E[2 * y + 1]) {                                      /* 1969 */
+            uint64_t xy = E[2 * y], rec = mml[xy];
+            if (rec > n) {
+                /* no recursive solution (1973) */
+            } else if (j <= xy + rec) {                                           /* 1975 */
+                count[rec] += 1;
+                if (rec < I) I = rec;
+                uint64_t cx = bcount[rec];
+                if (xy + rec > cx + mml[cx]) bcount[rec] = xy;                    /* 1979 */
+                if (xy + rec + 1 <= n) {                                          /* 1982 */
+                    uint64_t slot = xy + rec + 1;
+                    tnext[y] = -1;
+                    if (ttail[slot] < 0) thead[slot] = (int64_t)y; else tnext[ttail[slot]] = (int64_t)y;
+                    ttail[slot] = (int64_t)y;
+                }
+            } else {
+                if (j - xy < S) bS = xy;                                          /* 1986 */
+                if (j - xy < S) S = j - xy;                                       /* 1989 */
+            }
+            y += 1;
+        }
+        for (int64_t e = thead[j]; e >= 0; e = tnext[e]) {                        /* 1993 */
+            uint64_t x = E[2 * e];
+            count[mml[x]] -= 1;
+            if (j - x < S) { S = j - x; bS = x; }
+            if (count[mml[x]] == 0) bcount[mml[x]] = 0;
+        }
+        if (count[I] > 0 && I < S) { mml[j] = I; bt[j] = bcount[I]; }             /* 2004 */
+        else { mml[j] = S; bt[j] = bS; }
+        S += 1;
+        if (count[I] == 0) I += 1;                                                /* 2012 */
+    }
+    int rc = 0;
+    /* backtrack (2026-2039): boundaries = [..., bt-1, ..., n] */
+    int64_t cnt = 0;
+    {
+        uint64_t j = n;
+        cnt = 1;
+        while (bt[j] != 0) {
+            if (bt[j] > n || cnt > (int64_t)n + 1) { rc = ORC_ERR_NO_SEGMENTATION; break; }
+            cnt++; j = bt[j];
+        }
+        if (!rc && boundaries_out) {
+            int64_t k = cnt - 1;
+            j = n;
+            boundaries_out[k--] = n;
+            while (bt[j] != 0) { boundaries_out[k--] = bt[j] - 1; j = bt[j]; }
+        }
+    }
+    if (count_out) *count_out = rc ? 0 : cnt;
+    if (mml_out) memcpy(mml_out, mml, (size_t)(n + 1) * sizeof(uint64_t));
+    if (bt_out) memcpy(bt_out, bt, (size_t)(n + 1) * sizeof(uint64_t));
+    free(E); free(count); free(bcount); free(mml); free(bt); free(thead); free(ttail); free(tnext);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Non-elastic path: segment() v[j] scan, literal (fbg.cpp:552-611).          */
+/* Two-pointer over BWT intervals: FM backward step + locus contraction.     */
+/* Rows must be gap-free in the reference's --gap-limit=1 mode; gaps are      */
+/* nevertheless honoured the way the code does (range kept on '-').           */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { idx_t C[257]; idx_t *occ; int stride_log; const uint8_t *bwt; idx_t N; } fm_t;
+
+static idx_t fm_occ(const fm_t *fm, uint8_t c, idx_t i) /* # of c in bwt[0..i) */
+{
+    idx_t blk = i >> fm->stride_log;
+    idx_t cnt = fm->occ[(size_t)blk * 256 + c];
+    for (idx_t k = blk << fm->stride_log; k < i; k++) cnt += fm->bwt[k] == c;
+    return cnt;
+}
+
+typedef struct { idx_t sp, ep; } ival_t;
+
+static int cmp_interval(const void *a, const void *b)  /* fbg.cpp:519-524 */
+{
+    const ival_t *x = (const ival_t *)a, *y = (const ival_t *)b;
+    if (x->sp < y->sp) return -1;
+    if (x->sp > y->sp) return 1;
+    if (x->ep > y->ep) return -1;
+    if (x->ep < y->ep) return 1;
+    return 0;
+}
+
+int orc_segment_v_literal(const uint8_t *msa, int64_t m, int64_t n, uint64_t *v)
+{
+    orc_index ix;
+    int rc = orc_index_build(&ix, msa, m, n, 0);
+    if (rc) return rc;
+    idx_t N = ix.N;
+    fm_t fm; memset(&fm, 0, sizeof(fm));
+    fm.stride_log = 6; fm.N = N;
+    uint8_t *bwt = (uint8_t *)malloc((size_t)N);
+    idx_t nblk = (N >> fm.stride_log) + 2;
+    fm.occ = (idx_t *)calloc((size_t)nblk * 256, sizeof(idx_t));
+    idx_t *sp = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    idx_t *ep = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    idx_t *lcp = (idx_t *)calloc((size_t)m, sizeof(idx_t));
+    ival_t *pairs = (ival_t *)malloc((size_t)m * sizeof(ival_t));
+    if (!bwt || !fm.occ || !sp || !ep || !lcp || !pairs) { rc = ORC_ERR_ALLOC; goto out; }
+    {
+        idx_t run[256]; memset(run, 0, sizeof(run));
+        idx_t cnt[256]; memset(cnt, 0, sizeof(cnt));
+        for (idx_t r = 0; r < N; r++) {
+            if ((r & ((1 << fm.stride_log) - 1)) == 0)
+                memcpy(fm.occ + (size_t)(r >> fm.stride_log) * 256, run, sizeof(run));
+            idx_t p = ix.SA[r];
+            bwt[r] = p > 0 ? ix.T[p - 1] : ix.T[N - 1];
+            run[bwt[r]]++;
+            cnt[ix.T[r]]++;
+        }
+        idx_t s = 0;
+        for (int c = 0; c < 256; c++) { fm.C[c] = s; s += cnt[c]; }
+        fm.C[256] = s;
+        fm.bwt = bwt;
+    }
+    for (int64_t i = 0; i < m; i++) { sp[i] = 0; ep[i] = N - 1; }        /* 541-542 */
+    int64_t jp = n;                                                      /* 550 */
+    for (int64_t j = n - 1; j >= 0; j--) {                               /* 552 */
+        v[j] = (uint64_t)(j + 1);
+        if (j < n - 1) {
+            for (int64_t i = 0; i < m; i++) {                            /* 556-572 */
+                if (msa[i * n + j + 1] != '-') {
+                    node_t w = { sp[i], ep[i] };      /* lca(select_leaf(sp+1), select_leaf(ep+1)) */
+                    /* the locus of the current pattern: smallest lcp-interval containing [sp,ep];
+                       [sp,ep] is itself an interval of all suffixes sharing the pattern, and its
+                       lca node is the interval with the same bounds. */
+                    idx_t ud;
+                    node_t u = st_parent(&ix, w, &ud);
+                    if (w.l == w.r) {
+                        /* lca of a single leaf is the leaf; parent(leaf) as above */
+                    }
+                    lcp[i]--;
+                    if (ud == lcp[i]) { sp[i] = u.l; ep[i] = u.r; }
+                }
+            }
+        }
+        for (;;) {                                                       /* 574 */
+            for (int64_t i = 0; i < m; i++) { pairs[i].sp = sp[i]; pairs[i].ep = ep[i]; }
+            qsort(pairs, (size_t)m, sizeof(ival_t), cmp_interval);       /* 583 */
+            uint64_t sum = 0;
+            idx_t spprev = pairs[0].sp, epprev = pairs[0].ep;
+            for (int64_t i = 1; i < m; i++)
+                if (pairs[i].sp > epprev) {
+                    sum += (uint64_t)(epprev - spprev + 1);
+                    spprev = pairs[i].sp; epprev = pairs[i].ep;
+                }
+            sum += (uint64_t)(epprev - spprev + 1);
+            if (sum == (uint64_t)m) { v[j] = (uint64_t)jp; break; }      /* 594-597 */
+            if (jp == 0) break;                                          /* 598 */
+            jp--;
+            for (int64_t i = 0; i < m; i++) {                            /* 602-609 */
+                uint8_t c = msa[i * n + jp];
+                if (c != '-') {
+                    /* sdsl::backward_search(csa, l, r, c, l_res, r_res) */
+                    idx_t nl = fm.C[c] + fm_occ(&fm, c, sp[i]);
+                    idx_t nr = fm.C[c] + fm_occ(&fm, c, ep[i] + 1) - 1;
+                    if (nl <= nr) { sp[i] = nl; ep[i] = nr; }
+                    else { sp[i] = nl; ep[i] = nr; }   /* cannot happen: the pattern occurs */
+                    lcp[i]++;
+                }
+            }
+        }
+    }
+out:
+    free(bwt); free(fm.occ); free(sp); free(ep); free(lcp); free(pairs);
+    orc_index_free(&ix);
+    return rc;
+}
+
+/*
+ * Mirror-image formulation of v[j], gap-free rows only:
+ * on the text of reversed rows, all m rows coloured at column j,
+ * L = max_i (1 + max LCP with any uncoloured suffix); v[j] = j+1-L if L <= j+1 else j+1.
+ * This is the formulation the HIP path uses; checked against the literal one in tests.
+ */
+int orc_segment_v(const uint8_t *msa, int64_t m, int64_t n, uint64_t *v,
+                  double *t_index_s, double *t_scan_s)
+{
+    for (int64_t c = 0; c < m * n; c++) if (msa[c] == '-') return ORC_ERR_NO_SEGMENTATION;
+    orc_index ix;
+    double t0 = now_s();
+    int rc = orc_index_build(&ix, msa, m, n, 1);
+    if (rc) return rc;
+    double t1 = now_s();
+    uint64_t *keys = (uint64_t *)malloc((size_t)m * sizeof(uint64_t));
+    uint64_t *tmp = (uint64_t *)malloc((size_t)m * sizeof(uint64_t));
+    idx_t *lmin = (idx_t *)malloc((size_t)m * sizeof(idx_t));
+    if (!keys || !tmp || !lmin) { free(keys); free(tmp); free(lmin); orc_index_free(&ix); return ORC_ERR_ALLOC; }
+    for (int64_t j = 0; j < n; j++) {
+        /* reversed row i occupies T[pos_i .. pos_i+n); column j sits at pos_i + (n-1-j) */
+        for (int64_t i = 0; i < m; i++)
+            keys[i] = ((uint64_t)(uint32_t)ix.ISA[ix.pos[i] + (idx_t)(n - 1 - j)] << 32) | (uint64_t)i;
+        sort_u64(keys, tmp, (idx_t)m);
+        uint64_t L = 0;
+        for (idx_t a = 0; a < (idx_t)m;) {
+            idx_t b = a;
+            while (b + 1 < (idx_t)m && (keys[b + 1] >> 32) == (keys[b] >> 32) + 1) b++;
+            idx_t run = ix.LCP[(idx_t)(keys[a] >> 32)];
+            lmin[a] = run;
+            for (idx_t k = a + 1; k <= b; k++) {
+                idx_t x = ix.LCP[(idx_t)(keys[k] >> 32)];
+                if (x < run) run = x;
+                lmin[k] = run;
+            }
+            idx_t rmin = INT32_MAX;
+            for (idx_t k = b; k >= a; k--) {
+                idx_t x = ix.LCP[(idx_t)(keys[k] >> 32) + 1];
+                if (x < rmin) rmin = x;
+                uint64_t g = (uint64_t)(lmin[k] > rmin ? lmin[k] : rmin) + 1;
+                if (g > L) L = g;
+            }
+            a = b + 1;
+        }
+        v[j] = L <= (uint64_t)(j + 1) ? (uint64_t)(j + 1) - L : (uint64_t)(j + 1);
+    }
+    double t2 = now_s();
+    if (t_index_s) *t_index_s = t1 - t0;
+    if (t_scan_s) *t_scan_s = t2 - t1;
+    free(keys); free(tmp); free(lmin);
+    orc_index_free(&ix);
+    return 0;
+}
+
+/*
+ * Non-elastic DP + backtrack (fbg.cpp:616-664).  s_out / prev_out: n entries each.
+ * boundaries_out: room for n entries.  Returns ORC_ERR_NO_SEGMENTATION when
+ * s[n-1] == n+1 ("No proper segmentation exists.", fbg.cpp:648-652).
+ */
+int orc_segment_dp(const uint64_t *v, int64_t n_, uint64_t *s_out, uint64_t *prev_out,
+                   uint64_t *boundaries_out, int64_t *count_out)
+{
+    uint64_t n = (uint64_t)n_;
+    uint64_t *s = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    uint64_t *prev = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    if (!s || !prev) { free(s); free(prev); return ORC_ERR_ALLOC; }
+    for (uint64_t j = 0; j < n; j++) {
+        s[j] = j + 2; prev[j] = j + 1;                                  /* 623-624 */
+        if (v[j] > j) continue;
+        uint64_t jp = v[j];
+        for (;;) {
+            if (jp != 0 && s[jp - 1] == jp + 1) { jp--; continue; }      /* 629-632 */
+            uint64_t a = jp == 0 ? 0 : s[jp - 1], b = j - jp + 1;
+            uint64_t cand = a > b ? a : b;
+            if (s[j] > cand) { s[j] = cand; prev[j] = jp; }              /* 633-636 */
+            if (s[j] == j - jp + 1) break;
+            if (jp == 0) break;
+            jp--;
+        }
+    }
+    int rc = 0;
+    int64_t cnt = 0;
+    if (s[n - 1] == n + 1) {
+        rc = ORC_ERR_NO_SEGMENTATION;
+    } else {
+        uint64_t j = n - 1;
+        cnt = 1;
+        while (prev[j] != 0) { cnt++; j = prev[j] - 1; }                 /* 657-660 */
+        if (boundaries_out) {
+            int64_t k = cnt - 1;
+            j = n - 1;
+            boundaries_out[k--] = j;
+            while (prev[j] != 0) { boundaries_out[k--] = prev[j] - 1; j = prev[j] - 1; }
+        }
+    }
+    if (count_out) *count_out = cnt;
+    if (s_out) memcpy(s_out, s, (size_t)n * sizeof(uint64_t));
+    if (prev_out) memcpy(prev_out, prev, (size_t)n * sizeof(uint64_t));
+    free(s); free(prev);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* String set keyed by byte strings (stands in for std::unordered_map /       */
+/* unordered_set<string>; only membership and the stored id are observable).  */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { const uint8_t *s; int64_t len; uint64_t id; int used; } sslot;
+typedef struct { sslot *tab; int64_t cap, cnt; } sset;
+
+static uint64_t fnv1a(const uint8_t *s, int64_t len)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t i = 0; i < len; i++) { h ^= s[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+static int sset_init(sset *ss, int64_t cap_hint)
+{
+    int64_t cap = 16;
+    while (cap < 2 * cap_hint) cap <<= 1;
+    ss->tab = (sslot *)calloc((size_t)cap, sizeof(sslot));
+    ss->cap = cap; ss->cnt = 0;
+    return ss->tab ? 0 : ORC_ERR_ALLOC;
+}
+
+static void sset_clear(sset *ss) { memset(ss->tab, 0, (size_t)ss->cap * sizeof(sslot)); ss->cnt = 0; }
+
+static int sset_grow(sset *ss);
+
+/* returns slot; *found tells whether it existed */
+static sslot *sset_find_or_add(sset *ss, const uint8_t *s, int64_t len, uint64_t id, int *found)
+{
+    if (2 * (ss->cnt + 1) > ss->cap) sset_grow(ss);
+    uint64_t h = fnv1a(s, len) & (uint64_t)(ss->cap - 1);
+    for (;;) {
+        sslot *sl = &ss->tab[h];
+        if (!sl->used) {
+            *found = 0; sl->used = 1; sl->s = s; sl->len = len; sl->id = id; ss->cnt++;
+            return sl;
+        }
+        if (sl->len == len && memcmp(sl->s, s, (size_t)len) == 0) { *found = 1; return sl; }
+        h = (h + 1) & (uint64_t)(ss->cap - 1);
+    }
+}
+
+static int sset_grow(sset *ss)
+{
+    sslot *old = ss->tab; int64_t oc = ss->cap;
+    ss->cap = oc * 2; ss->cnt = 0;
+    ss->tab = (sslot *)calloc((size_t)ss->cap, sizeof(sslot));
+    for (int64_t i = 0; i < oc; i++)
+        if (old[i].used) { int f; sset_find_or_add(ss, old[i].s, old[i].len, old[i].id, &f); }
+    free(old);
+    return 0;
+}
+
+/* gap-stripped MSA[i].substr(prev, b - prev + 1) with std::string::substr clamping */
+static int64_t strip_label(const uint8_t *row, int64_t n, int64_t prev, int64_t b, uint8_t *dst)
+{
+    int64_t end = b + 1 < n ? b + 1 : n, k = 0;
+    for (int64_t j = prev; j < end; j++) if (row[j] != '-') dst[k++] = row[j];
+    return k;
+}
+
+/* ------------------------------------------------------------------------- */
+/* xGFA writer, literal (output_efg, fbg.cpp:1185-1301).                      */
+/* ids: m header strings (text after '>'), concatenated with id_off[m+1].     */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { uint64_t a, b; } edge_t;
+static int cmp_edge(const void *x, const void *y)
+{
+    const edge_t *p = (const edge_t *)x, *q = (const edge_t *)y;
+    if (p->a != q->a) return p->a < q->a ? -1 : 1;
+    if (p->b != q->b) return p->b < q->b ? -1 : 1;
+    return 0;
+}
+
+int orc_write_xgfa(const uint8_t *msa, int64_t m, int64_t n, const uint64_t *boundaries,
+                   int64_t nb, int output_paths, const uint8_t *ids, const int64_t *id_off,
+                   const char *path)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return ORC_ERR_IO;
+    int rc = 0;
+    /* label arena: one block at a time, m labels of at most block-width bytes */
+    uint8_t *arena = NULL; int64_t arena_cap = 0;
+    sset cur; if (sset_init(&cur, m)) { fclose(fp); return ORC_ERR_ALLOC; }
+    int64_t *row_prev = (int64_t *)malloc((size_t)m * sizeof(int64_t)); /* row2id_previous_block */
+    int64_t *row_cur = (int64_t *)malloc((size_t)m * sizeof(int64_t));
+    edge_t *edges = (edge_t *)malloc((size_t)m * sizeof(edge_t));
+    uint64_t **paths = NULL; int64_t *plen = NULL;
+    if (!row_prev || !row_cur || !edges) { rc = ORC_ERR_ALLOC; goto out; }
+
+    fprintf(fp, "M\t%lld\t%lld\n", (long long)m, (long long)n);                    /* 1201 */
+    fputs("X\t1", fp);                                                           /* 1204 */
+    for (int64_t i = 0; i + 1 < nb; i++) fprintf(fp, "\t%llu", (unsigned long long)(boundaries[i] + 2));
+    fputc('\n', fp);
+    fputs("B\t", fp);                                                            /* 1210 */
+    for (int pass = 0; pass < (output_paths ? 3 : 2); pass++) {
+        uint64_t nodecount = 0;
+        int64_t previndex = 0;
+        for (int64_t i = 0; i < m; i++) row_prev[i] = -1;
+        if (pass == 2) {
+            paths = (uint64_t **)calloc((size_t)m, sizeof(uint64_t *));
+            plen = (int64_t *)calloc((size_t)m, sizeof(int64_t));
+            if (!paths || !plen) { rc = ORC_ERR_ALLOC; goto out; }
+            for (int64_t i = 0; i < m; i++) {
+                paths[i] = (uint64_t *)malloc((size_t)(nb > 0 ? nb : 1) * sizeof(uint64_t));
+                if (!paths[i]) { rc = ORC_ERR_ALLOC; goto out; }
+            }
+        }
+        for (int64_t j = 0; j < nb; previndex = (int64_t)boundaries[j] + 1, j++) {
+            int64_t width = (int64_t)boundaries[j] - previndex + 1;
+            if (width < 0) width = 0;
+            if (m * (width + 1) > arena_cap) {
+                arena_cap = m * (width + 1);
+                free(arena); arena = (uint8_t *)malloc((size_t)arena_cap);
+                if (!arena) { rc = ORC_ERR_ALLOC; goto out; }
+            }
+            sset_clear(&cur);
+            int64_t ne = 0;
+            for (int64_t i = 0; i < m; i++) {
+                uint8_t *lab = arena + i * (width + 1);
+                int64_t len = previndex < n ? strip_label(msa + i * n, n, previndex, (int64_t)boundaries[j], lab) : 0;
+                row_cur[i] = -1;
+                if (len == 0) continue;                                           /* 1215,1235 */
+                int found;
+                sslot *sl = sset_find_or_add(&cur, lab, len, nodecount, &found);
+                if (!found) {
+                    nodecount++;
+                    if (pass == 1) {                                              /* 1241 */
+                        fprintf(fp, "S\t%llu\t", (unsigned long long)sl->id);
+                        fwrite(lab, 1, (size_t)len, fp); fputc('\n', fp);
+                    }
+                }
+                row_cur[i] = (int64_t)sl->id;
+                if (pass == 1 && row_prev[i] >= 0) {                              /* 1249-1250 */
+                    edges[ne].a = (uint64_t)row_prev[i]; edges[ne].b = sl->id; ne++;
+                }
+                if (pass == 2) paths[i][plen[i]++] = sl->id;                      /* 1286-1288 */
+            }
+            if (pass == 0) fprintf(fp, "%s%lld", j == 0 ? "" : "\t", (long long)cur.cnt); /* 1218 */
+            if (pass == 1) {
+                qsort(edges, (size_t)ne, sizeof(edge_t), cmp_edge);               /* std::set order */
+                for (int64_t e = 0; e < ne; e++) {
+                    if (e > 0 && edges[e].a == edges[e - 1].a && edges[e].b == edges[e - 1].b) continue;
+                    fprintf(fp, "L\t%llu\t+\t%llu\t+\t0M\n", (unsigned long long)edges[e].a,
+                            (unsigned long long)edges[e].b);                      /* 1254 */
+                }
+                int64_t *t = row_prev; row_prev = row_cur; row_cur = t;           /* 1257 */
+            }
+        }
+        if (pass == 0) fputc('\n', fp);                                           /* 1220 */
+    }
+    if (output_paths) {                                                           /* 1293-1300 */
+        for (int64_t i = 0; i < m; i++) {
+            if (plen[i] == 0) { rc = ORC_ERR_NO_SEGMENTATION; goto out; } /* reference underflows (UB) */
+            fputs("P\t", fp);
+            fwrite(ids + id_off[i], 1, (size_t)(id_off[i + 1] - id_off[i]), fp);
+            fputc('\t', fp);
+            for (int64_t k = 0; k + 1 < plen[i]; k++) fprintf(fp, "%llu+,", (unsigned long long)paths[i][k]);
+            fprintf(fp, "%llu+", (unsigned long long)paths[i][plen[i] - 1]);
+            fputs("\t*\n", fp);
+        }
+    }
+out:
+    if (paths) { for (int64_t i = 0; i < m; i++) free(paths[i]); free(paths); }
+    free(plen); free(arena); free(cur.tab); free(row_prev); free(row_cur); free(edges);
+    if (fclose(fp) != 0 && !rc) rc = ORC_ERR_IO;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Graph statistics printed by segment() (fbg.cpp:667-728): labels are        */
+/* deduplicated GLOBALLY across blocks.  out[0..3] = #nodes, total label      */
+/* length, #founders, #edges.                                                 */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { uint64_t a, b; int used; } eslot;
+
+int orc_segment_stats(const uint8_t *msa, int64_t m, int64_t n, const uint64_t *boundaries,
+                      int64_t nb, uint64_t *out)
+{
+    int rc = 0;
+    sset all; if (sset_init(&all, m * 4)) return ORC_ERR_ALLOC;
+    /* labels must stay alive: arena of all block labels, m*n bytes at most */
+    uint8_t *arena = (uint8_t *)malloc((size_t)(m * n + 1));
+    int64_t *rowid = (int64_t *)malloc((size_t)m * sizeof(int64_t));
+    int64_t *rowid_prev = (int64_t *)malloc((size_t)m * sizeof(int64_t));
+    int64_t ecap = 1024; eslot *etab = (eslot *)calloc((size_t)ecap, sizeof(eslot)); int64_t ecnt = 0;
+    if (!arena || !rowid || !rowid_prev || !etab) { rc = ORC_ERR_ALLOC; goto out; }
+    uint64_t nodecount = 0, totallength = 0, nfounders = 0;
+    int64_t used = 0, previndex = 0;
+    for (int64_t j = 0; j < nb; j++) {
+        uint64_t blocknew = 0;
+        for (int64_t i = 0; i < m; i++) {
+            uint8_t *lab = arena + used;
+            int64_t len = strip_label(msa + i * n, n, previndex, (int64_t)boundaries[j], lab);
+            int found;
+            sslot *sl = sset_find_or_add(&all, lab, len, nodecount, &found);     /* 678-681 */
+            if (!found) { nodecount++; blocknew++; totallength += (uint64_t)len; used += len; }
+            rowid[i] = (int64_t)sl->id;
+        }
+        if (blocknew > nfounders) nfounders = blocknew;                           /* 697-700 */
+        if (j > 0) {
+            for (int64_t i = 0; i < m; i++) {                                     /* 705-721 */
+                uint64_t a = (uint64_t)rowid_prev[i], b = (uint64_t)rowid[i];
+                if (2 * (ecnt + 1) > ecap) {
+                    eslot *old = etab; int64_t oc = ecap; ecap *= 2;
+                    etab = (eslot *)calloc((size_t)ecap, sizeof(eslot));
+                    for (int64_t k = 0; k < oc; k++) if (old[k].used) {
+                        uint64_t h = (old[k].a * 0x9E3779B97F4A7C15ull ^ old[k].b * 0xC2B2AE3D27D4EB4Full) & (uint64_t)(ecap - 1);
+                        while (etab[h].used) h = (h + 1) & (uint64_t)(ecap - 1);
+                        etab[h] = old[k];
+                    }
+                    free(old);
+                }
+                uint64_t h = (a * 0x9E3779B97F4A7C15ull ^ b * 0xC2B2AE3D27D4EB4Full) & (uint64_t)(ecap - 1);
+                for (;;) {
+                    if (!etab[h].used) { etab[h].used = 1; etab[h].a = a; etab[h].b = b; ecnt++; break; }
+                    if (etab[h].a == a && etab[h].b == b) break;
+                    h = (h + 1) & (uint64_t)(ecap - 1);
+                }
+            }
+        }
+        int64_t *t = rowid_prev; rowid_prev = rowid; rowid = t;
+        previndex = (int64_t)boundaries[j] + 1;
+    }
+    out[0] = nodecount; out[1] = totallength; out[2] = nfounders; out[3] = (uint64_t)ecnt;
+out:
+    free(arena); free(rowid); free(rowid_prev); free(etab); free(all.tab);
+    return rc;
+}
