@@ -1,0 +1,221 @@
+"""Host-side mirror of the reference's in-process seam for the segmentation path.
+
+Names and argument meaning follow founderblockgraph.cpp ("fbg.cpp"):
+  segment_elastic_minmaxlength  fbg.cpp:1836-2040   (elastic: f[] scan + min-max-length DP)
+  segment                       fbg.cpp:526-664     (non-elastic: v[] scan + s/prev DP)
+Every call goes through the C ABI of libfbg_hip.so (include/fbg_hip.h); nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FBG_ERR_NO_SEGMENTATION, FBG_OK, STAGES
+
+
+class FbgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfbg_hip error {code}: {msg}")
+        self.code = code
+
+
+class NoSegmentation(FbgError):
+    """'No valid segmentation found!' (fbg.cpp:1934) / 'No proper segmentation exists.' (fbg.cpp:650)."""
+
+
+def _u8(a):
+    return a.ctypes.data_as(_lib.u8p)
+
+
+def _u64(a):
+    return a.ctypes.data_as(_lib.u64p)
+
+
+def _ignore(ignorechars):
+    if isinstance(ignorechars, str):
+        ignorechars = ignorechars.encode()
+    ig = np.frombuffer(bytes(ignorechars or b"") + b"\0", dtype=np.uint8).copy()
+    return ig, len(ig) - 1
+
+
+def as_msa(rows):
+    """(m, n) uint8 array from an array or a list of equal-length str/bytes rows."""
+    if isinstance(rows, np.ndarray):
+        a = np.ascontiguousarray(rows, dtype=np.uint8)
+        if a.ndim != 2:
+            raise ValueError("MSA must be 2-D (rows x columns)")
+        return a
+    rows = [r.encode() if isinstance(r, str) else bytes(r) for r in rows]
+    if not rows or any(len(r) != len(rows[0]) for r in rows):
+        raise ValueError("MSA rows must be non-empty and of equal length")
+    return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0])).copy()
+
+
+class Engine:
+    """One fbg_ctx (one GPU, one stream).  Calls on one engine must be serialised by the caller."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.fbg_ctx_create(int(device), C.byref(h))
+        if rc != FBG_OK:
+            raise FbgError(rc, self._L.fbg_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fbg_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc == FBG_OK:
+            return
+        msg = self._L.fbg_last_error(self._h).decode()
+        raise (NoSegmentation if rc == FBG_ERR_NO_SEGMENTATION else FbgError)(rc, msg)
+
+    # ---- host-buffer entry points --------------------------------------------------------
+    def elastic_f(self, msa, ignorechars="", disable_efg_tricks=False, f=None):
+        """compute_f: f is max-merged into (zeros if omitted), as fbg.cpp:1681 / 3388."""
+        msa = as_msa(msa)
+        m, n = msa.shape
+        ig, il = _ignore(ignorechars)
+        f = np.zeros(n, dtype=np.uint64) if f is None else np.ascontiguousarray(f, dtype=np.uint64).copy()
+        rc = self._L.fbg_elastic_f(self._h, _u8(msa), m, n, _u8(ig), il, int(disable_efg_tricks), _u64(f))
+        if rc == FBG_ERR_NO_SEGMENTATION:
+            raise NoSegmentation(rc, self._L.fbg_last_error(self._h).decode())
+        self._chk(rc)
+        return f
+
+    def minmax_dp(self, f, full=False):
+        f = np.ascontiguousarray(f, dtype=np.uint64)
+        n = len(f)
+        b = np.empty(n + 1, dtype=np.uint64)
+        mml = np.empty(n + 1, dtype=np.uint64)
+        bt = np.empty(n + 1, dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        self._chk(self._L.fbg_minmax_dp(self._h, _u64(f), n, _u64(b), C.byref(cnt), _u64(mml), _u64(bt)))
+        b = b[:cnt.value].copy()
+        return (b, mml, bt) if full else b
+
+    def repeatfree_v(self, msa):
+        msa = as_msa(msa)
+        m, n = msa.shape
+        v = np.empty(n, dtype=np.uint64)
+        self._chk(self._L.fbg_repeatfree_v(self._h, _u8(msa), m, n, _u64(v)))
+        return v
+
+    def repeatfree_dp(self, v):
+        """-> (s, prev, boundaries); boundaries is None when no proper segmentation exists."""
+        v = np.ascontiguousarray(v, dtype=np.uint64)
+        n = len(v)
+        s = np.empty(n, dtype=np.uint64)
+        prev = np.empty(n, dtype=np.uint64)
+        b = np.empty(n, dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        rc = self._L.fbg_repeatfree_dp(self._h, _u64(v), n, _u64(s), _u64(prev), _u64(b), C.byref(cnt))
+        if rc == FBG_ERR_NO_SEGMENTATION:
+            return s, prev, None
+        self._chk(rc)
+        return s, prev, b[:cnt.value].copy()
+
+    # ---- device-resident staged API ------------------------------------------------------
+    def msa_load_host(self, msa):
+        msa = as_msa(msa)
+        self._chk(self._L.fbg_msa_load_host(self._h, _u8(msa), msa.shape[0], msa.shape[1]))
+
+    def msa_set_device(self, ptr, m, n):
+        self._chk(self._L.fbg_msa_set_device(self._h, C.c_void_p(ptr), m, n))
+
+    def msa_synthetic(self, ptr, m, n, seed=0x5EED0001, seed2=0x5EED0002, gap_fraction=0.0, gap_run=0,
+                      seed3=0x5EED0003, n_fraction=0.0):
+        gthr = int((1 << 64) * (gap_fraction / gap_run)) if gap_run else 0
+        nthr = int((1 << 64) * n_fraction)
+        self._chk(self._L.fbg_msa_synthetic(self._h, C.c_void_p(ptr), m, n, seed, seed2, gthr, gap_run, seed3, nthr))
+
+    def index_build(self, reversed=False, ignorechars=""):
+        ig, il = _ignore(ignorechars)
+        self._chk(self._L.fbg_index_build(self._h, int(reversed), _u8(ig), il))
+
+    def scan_f(self, x0, x1, d_f_ptr, disable_efg_tricks=False):
+        self._chk(self._L.fbg_scan_f(self._h, x0, x1, int(disable_efg_tricks), C.c_void_p(d_f_ptr)))
+
+    def scan_v(self, x0, x1, d_v_ptr):
+        self._chk(self._L.fbg_scan_v(self._h, x0, x1, C.c_void_p(d_v_ptr)))
+
+    def minmax_dp_device(self, d_f_ptr, n, d_boundaries_ptr, d_mml_ptr=None, d_bt_ptr=None):
+        cnt = C.c_uint64(0)
+        self._chk(self._L.fbg_minmax_dp_device(self._h, C.c_void_p(d_f_ptr), n, C.c_void_p(d_boundaries_ptr),
+                                               C.byref(cnt), C.c_void_p(d_mml_ptr), C.c_void_p(d_bt_ptr)))
+        return cnt.value
+
+    def repeatfree_dp_device(self, d_v_ptr, n, d_boundaries_ptr, d_s_ptr=None, d_prev_ptr=None):
+        cnt = C.c_uint64(0)
+        self._chk(self._L.fbg_repeatfree_dp_device(self._h, C.c_void_p(d_v_ptr), n, C.c_void_p(d_s_ptr),
+                                                   C.c_void_p(d_prev_ptr), C.c_void_p(d_boundaries_ptr),
+                                                   C.byref(cnt)))
+        return cnt.value
+
+    def set_stream(self, stream_handle):
+        self._chk(self._L.fbg_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def sync(self):
+        self._chk(self._L.fbg_sync(self._h))
+
+    def stage_ms(self):
+        out = {}
+        for k, name in enumerate(STAGES):
+            ms, ln = C.c_float(0), C.c_int(0)
+            self._chk(self._L.fbg_stage_ms(self._h, k, C.byref(ms), C.byref(ln)))
+            out[name] = (ms.value, ln.value)
+        return out
+
+    def device_bytes(self):
+        return int(self._L.fbg_device_bytes(self._h))
+
+    def text_length(self):
+        return int(self._L.fbg_text_length(self._h))
+
+    def index_download(self):
+        N = self.text_length()
+        T = np.empty(N, dtype=np.uint8)
+        arrs = [np.empty(N, dtype=np.uint32) for _ in range(4)]
+        self._chk(self._L.fbg_index_download(self._h, _u8(T), *[a.ctypes.data_as(_lib.u32p) for a in arrs]))
+        return (T, *arrs)
+
+
+# ---- reference-shaped free functions ---------------------------------------------------------
+
+def segment_elastic_minmaxlength(MSA, ignorechars="", disable_efg_tricks=False, f=None, segment=True,
+                                 engine=None):
+    """fbg.cpp:1836-2040.  Returns (out_indices, f); out_indices is None when segment=False."""
+    eng = engine or Engine()
+    try:
+        f = eng.elastic_f(MSA, ignorechars, disable_efg_tricks, f)
+        if not segment:
+            return None, f
+        return eng.minmax_dp(f), f
+    finally:
+        if engine is None:
+            eng.close()
+
+
+def segment(MSA, engine=None):
+    """fbg.cpp:526-664 up to the boundaries.  Returns (status, v, s, prev, boundaries):
+    status 0 = EXIT_SUCCESS, 1 = EXIT_FAILURE ('No proper segmentation exists.')."""
+    eng = engine or Engine()
+    try:
+        v = eng.repeatfree_v(MSA)
+        s, prev, b = eng.repeatfree_dp(v)
+        return (0 if b is not None else 1), v, s, prev, b
+    finally:
+        if engine is None:
+            eng.close()

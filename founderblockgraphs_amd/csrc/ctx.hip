@@ -1,0 +1,350 @@
+// ctx.hip -- context, error plumbing, workspaces and the C-ABI entry points of include/fbg_hip.h.
+#include "fbg_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+static std::string g_global_err;
+
+int fbg_fail(fbg_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_global_err = buf;
+    return code;
+}
+
+int fbg_reserve(fbg_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 256;
+    if (b.cap >= bytes) return FBG_OK;
+    if (b.p) {
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        FBG_HIP_TRY(ctx, hipFree(b.p));
+        ctx->held_bytes -= b.cap;
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fbg_fail(ctx, FBG_ERR_OOM, "hipMalloc(%zu bytes) failed: %s (context already holds %llu bytes)",
+                        want, hipGetErrorString(e), (unsigned long long)ctx->held_bytes);
+    }
+    b.cap = want;
+    ctx->held_bytes += want;
+    return FBG_OK;
+}
+
+void fbg_release(fbg_ctx *ctx, DevBuf &b)
+{
+    if (b.p) {
+        (void)hipFree(b.p);
+        ctx->held_bytes -= b.cap;
+        b.p = nullptr; b.cap = 0;
+    }
+}
+
+int fbg_stage_begin(fbg_ctx *ctx, int stage)
+{
+    StageTimer &t = ctx->timers[stage];
+    if (!t.start) {
+        FBG_HIP_TRY(ctx, hipEventCreate(&t.start));
+        FBG_HIP_TRY(ctx, hipEventCreate(&t.stop));
+    }
+    t.recorded = false;
+    FBG_HIP_TRY(ctx, hipEventRecord(t.start, ctx->stream));
+    return FBG_OK;
+}
+
+int fbg_stage_end(fbg_ctx *ctx, int stage, int launches)
+{
+    StageTimer &t = ctx->timers[stage];
+    FBG_HIP_TRY(ctx, hipEventRecord(t.stop, ctx->stream));
+    t.recorded = true;
+    t.launches = launches;
+    return FBG_OK;
+}
+
+extern "C" {
+
+int fbg_ctx_create(int device, fbg_ctx **out)
+{
+    if (!out) return FBG_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fbg_fail(nullptr, FBG_ERR_NO_DEVICE,
+                        "no HIP device visible (%s); libfbg_hip has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= count)
+        return fbg_fail(nullptr, FBG_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fbg_fail(nullptr, FBG_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    fbg_ctx *ctx = new fbg_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fbg_fail(nullptr, FBG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return FBG_OK;
+}
+
+void fbg_ctx_destroy(fbg_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->sa,
+                      &ctx->isa, &ctx->pl, &ctx->pr, &ctx->RT, &ctx->PLT, &ctx->PRT, &ctx->PT, &ctx->IGT,
+                      &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
+                      &ctx->list, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
+                      &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
+                      &ctx->io_c, &ctx->io_d};
+    for (DevBuf *b : bufs) fbg_release(ctx, *b);
+    for (auto &t : ctx->timers) {
+        if (t.start) (void)hipEventDestroy(t.start);
+        if (t.stop) (void)hipEventDestroy(t.stop);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *fbg_last_error(const fbg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_global_err.c_str(); }
+
+int fbg_set_stream(fbg_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        FBG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return FBG_OK;
+}
+
+int fbg_stage_ms(fbg_ctx *ctx, int stage, float *ms, int *launches)
+{
+    if (!ctx || stage < 0 || stage >= FBG_STAGE_COUNT) return FBG_ERR_INVALID;
+    StageTimer &t = ctx->timers[stage];
+    if (ms) *ms = 0.f;
+    if (launches) *launches = 0;
+    if (!t.recorded) return FBG_OK;
+    FBG_HIP_TRY(ctx, hipEventSynchronize(t.stop));
+    float v = 0.f;
+    FBG_HIP_TRY(ctx, hipEventElapsedTime(&v, t.start, t.stop));
+    if (ms) *ms = v;
+    if (launches) *launches = t.launches;
+    return FBG_OK;
+}
+
+uint64_t fbg_device_bytes(const fbg_ctx *ctx) { return ctx ? ctx->held_bytes : 0; }
+
+int fbg_sync(fbg_ctx *ctx)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FBG_OK;
+}
+
+static int check_dims(fbg_ctx *ctx, uint64_t m, uint64_t n)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (m == 0 || n == 0) return fbg_fail(ctx, FBG_ERR_INVALID, "empty MSA (m=%llu, n=%llu)",
+                                          (unsigned long long)m, (unsigned long long)n);
+    if (m > FBG_MAX_ROWS)
+        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "m=%llu exceeds FBG_MAX_ROWS=%d", (unsigned long long)m, FBG_MAX_ROWS);
+    if (n >= (1ull << 32) || m * (n + 1) + 1 >= (1ull << 32))
+        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length m*(n+1)+1 = %llu needs more than 32-bit ranks",
+                        (unsigned long long)(m * (n + 1) + 1));
+    return FBG_OK;
+}
+
+int fbg_msa_set_device(fbg_ctx *ctx, const uint8_t *d_msa, uint64_t m, uint64_t n)
+{
+    FBG_TRY(check_dims(ctx, m, n));
+    if (!d_msa) return fbg_fail(ctx, FBG_ERR_INVALID, "null MSA pointer");
+    ctx->d_msa = d_msa; ctx->m = m; ctx->n = n; ctx->index_valid = false;
+    return FBG_OK;
+}
+
+int fbg_msa_load_host(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n)
+{
+    FBG_TRY(check_dims(ctx, m, n));
+    if (!msa) return fbg_fail(ctx, FBG_ERR_INVALID, "null MSA pointer");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FBG_TRY(fbg_reserve(ctx, ctx->msa_own, m * n));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msa_own.p, msa, m * n, hipMemcpyHostToDevice, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->d_msa = ctx->msa_own.as<uint8_t>(); ctx->m = m; ctx->n = n; ctx->index_valid = false;
+    return FBG_OK;
+}
+
+int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uint64_t ignore_len)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->d_msa) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_build: no MSA set");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->index_valid = false;
+    ctx->reversed = reversed ? 1 : 0;
+    FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
+    FBG_TRY(fbg_suffix_sort(ctx));
+    FBG_TRY(fbg_neighbour_lcp(ctx));
+    FBG_TRY(fbg_tile_columns(ctx));
+    ctx->index_valid = true;
+    return FBG_OK;
+}
+
+int fbg_scan_f(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_f)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->index_valid || ctx->reversed)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_scan_f needs fbg_index_build(reversed=0) first");
+    if (x0 > x1 || x1 > ctx->n || !d_f) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_scan_f: bad column range");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return fbg_scan_columns(ctx, x0, x1, FBG_SCAN_F, disable_tricks, d_f);
+}
+
+int fbg_scan_v(fbg_ctx *ctx, uint64_t x0, uint64_t x1, uint64_t *d_v)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->index_valid || !ctx->reversed)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_scan_v needs fbg_index_build(reversed=1) first");
+    if (x0 > x1 || x1 > ctx->n || !d_v) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_scan_v: bad column range");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return fbg_scan_columns(ctx, x0, x1, FBG_SCAN_V, 1, d_v);
+}
+
+int fbg_minmax_dp_device(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,
+                         uint64_t *count_out, uint64_t *d_mml, uint64_t *d_bt)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!d_f || !d_boundaries || !count_out || n == 0 || n >= (1ull << 31))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_minmax_dp_device: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return fbg_dp_minmax(ctx, d_f, n, d_boundaries, count_out, d_mml, d_bt);
+}
+
+int fbg_repeatfree_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
+                             uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!d_v || !d_boundaries || !count_out || n == 0 || n >= (1ull << 31))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_repeatfree_dp_device: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return fbg_dp_repeatfree(ctx, d_v, n, d_s, d_prev, d_boundaries, count_out);
+}
+
+// ---- host-buffer entry points ---------------------------------------------------------------
+
+int fbg_elastic_f(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, const uint8_t *ignore_chars,
+                  uint64_t ignore_len, int disable_tricks, uint64_t *f)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!f) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_elastic_f: null f");
+    FBG_TRY(fbg_msa_load_host(ctx, msa, m, n));
+    FBG_TRY(fbg_index_build(ctx, 0, ignore_chars, ignore_len));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_a, n * sizeof(uint64_t)));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, f, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    FBG_TRY(fbg_scan_f(ctx, 0, n, disable_tricks, ctx->io_a.as<uint64_t>()));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(f, ctx->io_a.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (disable_tricks && f[0] == n)
+        return fbg_fail(ctx, FBG_ERR_NO_SEGMENTATION, "No valid segmentation found!");
+    return FBG_OK;
+}
+
+int fbg_minmax_dp(fbg_ctx *ctx, const uint64_t *f, uint64_t n, uint64_t *boundaries_out, uint64_t *count_out,
+                  uint64_t *minmaxlength_out, uint64_t *backtrack_out)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!f || !boundaries_out || !count_out || n == 0 || n >= (1ull << 31))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_minmax_dp: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t w = (n + 1) * sizeof(uint64_t);
+    FBG_TRY(fbg_reserve(ctx, ctx->io_a, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_b, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_c, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_d, w));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, f, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    int rc = fbg_dp_minmax(ctx, ctx->io_a.as<uint64_t>(), n, ctx->io_b.as<uint64_t>(), count_out,
+                           ctx->io_c.as<uint64_t>(), ctx->io_d.as<uint64_t>());
+    if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) return rc;
+    if (minmaxlength_out)
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(minmaxlength_out, ctx->io_c.p, w, hipMemcpyDeviceToHost, ctx->stream));
+    if (backtrack_out)
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(backtrack_out, ctx->io_d.p, w, hipMemcpyDeviceToHost, ctx->stream));
+    if (rc == FBG_OK)
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(boundaries_out, ctx->io_b.p, *count_out * sizeof(uint64_t),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int fbg_repeatfree_v(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, uint64_t *v)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!v) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_repeatfree_v: null v");
+    FBG_TRY(fbg_msa_load_host(ctx, msa, m, n));
+    FBG_TRY(fbg_index_build(ctx, 1, nullptr, 0));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_a, n * sizeof(uint64_t)));
+    FBG_TRY(fbg_scan_v(ctx, 0, n, ctx->io_a.as<uint64_t>()));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(v, ctx->io_a.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FBG_OK;
+}
+
+int fbg_repeatfree_dp(fbg_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *s_out, uint64_t *prev_out,
+                      uint64_t *boundaries_out, uint64_t *count_out)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!v || !boundaries_out || !count_out || n == 0 || n >= (1ull << 31))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_repeatfree_dp: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t w = n * sizeof(uint64_t);
+    FBG_TRY(fbg_reserve(ctx, ctx->io_a, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_b, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_c, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_d, w));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, v, w, hipMemcpyHostToDevice, ctx->stream));
+    int rc = fbg_dp_repeatfree(ctx, ctx->io_a.as<uint64_t>(), n, ctx->io_c.as<uint64_t>(),
+                               ctx->io_d.as<uint64_t>(), ctx->io_b.as<uint64_t>(), count_out);
+    if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) return rc;
+    if (s_out) FBG_HIP_TRY(ctx, hipMemcpyAsync(s_out, ctx->io_c.p, w, hipMemcpyDeviceToHost, ctx->stream));
+    if (prev_out) FBG_HIP_TRY(ctx, hipMemcpyAsync(prev_out, ctx->io_d.p, w, hipMemcpyDeviceToHost, ctx->stream));
+    if (rc == FBG_OK)
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(boundaries_out, ctx->io_b.p, *count_out * sizeof(uint64_t),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+uint64_t fbg_text_length(const fbg_ctx *ctx) { return ctx && ctx->index_valid ? ctx->N : 0; }
+
+int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa, uint32_t *lcp_prev,
+                       uint32_t *lcp_next)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->index_valid) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: no index");
+    size_t N = ctx->N;
+    if (text) FBG_HIP_TRY(ctx, hipMemcpyAsync(text, ctx->text.p, N, hipMemcpyDeviceToHost, ctx->stream));
+    if (sa) FBG_HIP_TRY(ctx, hipMemcpyAsync(sa, ctx->sa.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (isa) FBG_HIP_TRY(ctx, hipMemcpyAsync(isa, ctx->isa.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (lcp_prev) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_prev, ctx->pl.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (lcp_next) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_next, ctx->pr.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FBG_OK;
+}
+
+} // extern "C"

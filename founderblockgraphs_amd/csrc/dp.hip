@@ -1,0 +1,220 @@
+// dp.hip -- the two segmentation recurrences and their backtracks, on the device.
+//
+//  * fbg_dp_minmax:     sort of (x, f[x]+1) by second + min-max-length sweep + backtrack of
+//                       segment_elastic_minmaxlength (fbg.cpp:1940-2039);
+//  * fbg_dp_repeatfree: s[]/prev[] recurrence + backtrack of segment() (fbg.cpp:616-664).
+//
+// The std::sort (fbg.cpp:1953) is a counting sort here: a histogram of f[x]+1, an exclusive scan
+// and a scatter.  Ties may land in any order; the sweep's outcome does not depend on it, because
+// every update inside one step j is a strict min/max over distinct x or a counter.
+// The sweep itself is inherently sequential (step j reads minmaxlength[] of earlier columns); one
+// lane walks it with all state in device memory, exactly the statements of fbg.cpp:1968-2014.
+#include "fbg_internal.h"
+#include <rocprim/rocprim.hpp>
+
+#define DP_NONE 0xffffffffu
+
+// e[x] = f[x] + 1 ; hist[e]++
+__global__ void k_dp_keys(const uint64_t *__restrict__ f, uint64_t n, uint32_t *__restrict__ e,
+                          uint32_t *__restrict__ hist, unsigned long long *__restrict__ bad)
+{
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    uint64_t fx = f[x];
+    if (fx > n || fx < x) { atomicAdd(bad, 1ull); fx = fx > n ? n : x; }   // f[x] in [x, n] by construction
+    e[x] = (uint32_t)(fx + 1);
+    atomicAdd(&hist[fx + 1], 1u);
+}
+
+__global__ void k_dp_scatter(const uint32_t *__restrict__ e, uint64_t n, uint32_t *__restrict__ cursor,
+                             uint32_t *__restrict__ items)
+{
+    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    uint32_t slot = atomicAdd(&cursor[e[x]], 1u);
+    items[slot] = (uint32_t)x;
+}
+
+// fbg.cpp:1960-2014, one lane.  bstart[j]..bstart[j+1] delimit the entries with f[x]+1 == j.
+__global__ void k_dp_minmax(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ items, uint32_t n,
+                            uint32_t *__restrict__ count, uint32_t *__restrict__ bcount,
+                            uint32_t *__restrict__ thead, uint32_t *__restrict__ tnext,
+                            uint32_t *__restrict__ mml, uint32_t *__restrict__ bt)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    // count[], bcount[], mml[0], bt[0] arrive zeroed; thead[] arrives filled with DP_NONE
+    uint32_t I = 0, S = n + 1, bS = DP_NONE;                                    // 1967
+    for (uint32_t j = 1; j <= n; j++) {
+        const uint32_t b0 = bstart[j], b1 = bstart[j + 1];
+        for (uint32_t y = b0; y < b1; y++) {                                     // 1969
+            const uint32_t xy = items[y];
+            const uint32_t rec = mml[xy];
+            if (rec > n) {
+                // no recursive solution (1973)
+            } else if (j <= xy + rec) {                                          // 1975
+                count[rec] += 1;
+                I = min(I, rec);
+                const uint32_t cx = bcount[rec];
+                if (xy + rec > cx + mml[cx]) bcount[rec] = xy;                   // 1979
+                if (xy + rec + 1 <= n) {                                         // 1982
+                    const uint32_t slot = xy + rec + 1;
+                    tnext[xy] = thead[slot];
+                    thead[slot] = xy;
+                }
+            } else {
+                if (j - xy < S) { bS = xy; S = j - xy; }                         // 1986-1989
+            }
+        }
+        for (uint32_t x = thead[j]; x != DP_NONE; x = tnext[x]) {                // 1993
+            const uint32_t v = mml[x];
+            const uint32_t c = count[v] - 1;
+            count[v] = c;
+            if (j - x < S) { S = j - x; bS = x; }
+            if (c == 0) bcount[v] = 0;
+        }
+        const uint32_t cI = count[I];
+        if (cI > 0 && I < S) { mml[j] = I; bt[j] = bcount[I]; }                  // 2004
+        else { mml[j] = S; bt[j] = bS; }
+        S += 1;
+        if (cI == 0) I += 1;                                                     // 2012
+    }
+}
+
+// fbg.cpp:2026-2039.  status: 0 ok, 1 = backtrack left the array (reference: out-of-bounds read)
+__global__ void k_dp_backtrack(const uint32_t *__restrict__ bt, uint32_t n, uint64_t *__restrict__ boundaries,
+                               unsigned long long *__restrict__ result)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t cnt = 1;
+    uint32_t j = n;
+    while (bt[j] != 0) {
+        if (bt[j] > n || cnt > (uint64_t)n + 1) { result[0] = 0; result[1] = 1; return; }
+        cnt++; j = bt[j];
+    }
+    uint64_t k = cnt - 1;
+    j = n;
+    boundaries[k--] = n;
+    while (bt[j] != 0) { boundaries[k--] = (uint64_t)bt[j] - 1; j = bt[j]; }
+    result[0] = cnt; result[1] = 0;
+}
+
+__global__ void k_widen(const uint32_t *__restrict__ src, uint64_t cnt, uint64_t *__restrict__ dst, int none_is_minus1)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    uint32_t v = src[k];
+    dst[k] = (none_is_minus1 && v == DP_NONE) ? ~0ull : (uint64_t)v;
+}
+
+int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries, uint64_t *count_out,
+                  uint64_t *d_mml, uint64_t *d_bt)
+{
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_DP));
+    const size_t w = (n + 2) * 4;
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, w));   // e
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_b, w));   // hist -> bstart
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_c, w));   // cursor / thead
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_d, w));   // items
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_e, w));   // count
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_f, w));   // bcount
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_g, w));   // mml
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_h, w));   // bt
+    FBG_TRY(fbg_reserve(ctx, ctx->list, w));   // tnext
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
+    uint32_t *e = ctx->dp_a.as<uint32_t>(), *bstart = ctx->dp_b.as<uint32_t>(), *cur = ctx->dp_c.as<uint32_t>(),
+             *items = ctx->dp_d.as<uint32_t>(), *count = ctx->dp_e.as<uint32_t>(), *bcount = ctx->dp_f.as<uint32_t>(),
+             *mml = ctx->dp_g.as<uint32_t>(), *bt = ctx->dp_h.as<uint32_t>(), *tnext = ctx->list.as<uint32_t>();
+    unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 4 * sizeof(unsigned long long), st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(bstart, 0, w, st));
+    hipLaunchKernelGGL(k_dp_keys, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, d_f, n, e, bstart, sc + 2);
+    {   // exclusive scan of the histogram over keys 0..n+1 -> bucket starts
+        size_t bytes = 0;
+        hipError_t er = rocprim::exclusive_scan(nullptr, bytes, bstart, bstart, 0u, (size_t)(n + 2), rocprim::plus<uint32_t>(), st);
+        if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim scan size query failed");
+        FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+        size_t have = ctx->tmp.cap;
+        er = rocprim::exclusive_scan(ctx->tmp.p, have, bstart, bstart, 0u, (size_t)(n + 2), rocprim::plus<uint32_t>(), st);
+        if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(er));
+    }
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(cur, bstart, w, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_dp_scatter, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, e, n, cur, items);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(cur, 0xff, w, st));   // thead = DP_NONE
+    hipLaunchKernelGGL(k_dp_minmax, dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, count, bcount, cur, tnext, mml, bt);
+    hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
+    if (d_mml) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, n + 1, d_mml, 0);
+    if (d_bt) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, bt, n + 1, d_bt, 1);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_DP, 6));
+    unsigned long long h[3];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (h[2] != 0) return fbg_fail(ctx, FBG_ERR_INVALID, "f[] has %llu entries outside [x, n]", h[2]);
+    *count_out = h[0];
+    if (h[1] != 0) return fbg_fail(ctx, FBG_ERR_NO_SEGMENTATION, "No valid segmentation found!");
+    return FBG_OK;
+}
+
+// ---- non-elastic recurrence (fbg.cpp:616-664), one lane ----------------------------------------
+
+__global__ void k_dp_repeatfree(const uint64_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ s,
+                                uint32_t *__restrict__ prev, uint64_t *__restrict__ boundaries,
+                                unsigned long long *__restrict__ result)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (uint32_t j = 0; j < n; j++) {
+        uint32_t sj = j + 2, pj = j + 1;                                          // 623-624
+        const uint64_t vj = v[j];
+        if (vj <= j) {
+            uint32_t jp = (uint32_t)vj;
+            for (;;) {
+                if (jp != 0 && s[jp - 1] == jp + 1) { jp--; continue; }          // 629-632
+                const uint32_t a = jp == 0 ? 0u : s[jp - 1], b = j - jp + 1;
+                const uint32_t cand = max(a, b);
+                if (sj > cand) { sj = cand; pj = jp; }                            // 633-636
+                if (sj == j - jp + 1) break;
+                if (jp == 0) break;
+                jp--;
+            }
+        }
+        s[j] = sj; prev[j] = pj;
+    }
+    if (s[n - 1] == n + 1) { result[0] = 0; result[1] = 1; return; }              // 648-652
+    uint64_t cnt = 1;
+    uint32_t j = n - 1;
+    while (prev[j] != 0) { cnt++; j = prev[j] - 1; }                              // 657-660
+    uint64_t k = cnt - 1;
+    j = n - 1;
+    boundaries[k--] = j;
+    while (prev[j] != 0) { boundaries[k--] = (uint64_t)prev[j] - 1; j = prev[j] - 1; }
+    result[0] = cnt; result[1] = 0;
+}
+
+int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s, uint64_t *d_prev,
+                      uint64_t *d_boundaries, uint64_t *count_out)
+{
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_DP));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_g, (n + 2) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_h, (n + 2) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
+    uint32_t *s = ctx->dp_g.as<uint32_t>(), *prev = ctx->dp_h.as<uint32_t>();
+    unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_dp_repeatfree, dim3(1), dim3(64), 0, st, d_v, (uint32_t)n, s, prev, d_boundaries, sc);
+    if (d_s) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, s, n, d_s, 0);
+    if (d_prev) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, prev, n, d_prev, 0);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_DP, 3));
+    unsigned long long h[2];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *count_out = h[0];
+    if (h[1] != 0) return fbg_fail(ctx, FBG_ERR_NO_SEGMENTATION, "No proper segmentation exists.");
+    return FBG_OK;
+}

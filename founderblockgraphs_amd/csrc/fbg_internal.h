@@ -1,0 +1,103 @@
+// fbg_internal.h -- shared declarations of the MI355X segmentation engine (libfbg_hip.so).
+// gfx950 only: 64-wide wavefronts are assumed throughout.
+#pragma once
+#include <cstring>
+#include <cstdlib>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/fbg_hip.h"
+
+#define FBG_WAVE 64
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct StageTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool recorded = false;
+    int launches = 0;
+};
+
+struct fbg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    uint64_t held_bytes = 0;
+
+    // current MSA (row-major m x n bytes, device)
+    const uint8_t *d_msa = nullptr;
+    DevBuf msa_own;
+    uint64_t m = 0, n = 0;
+
+    // index state
+    bool index_valid = false;
+    int reversed = 0;
+    bool gapfree = true;
+    bool have_ignore = false;
+    uint64_t N = 0;            // text length incl. sentinel
+    uint32_t mp = 0;           // rows padded to a multiple of 64 (column-tile pitch)
+    DevBuf text;               // N + 64 bytes, zero padded
+    DevBuf pos, tot;           // u32[m]
+    DevBuf prow;               // u32[m*n]: text pointer of cell (i,x), row-major (gapped MSAs only)
+    DevBuf igrow;              // u32[m*n]: first ignore-char column >= x, row-major (ignore chars only)
+    DevBuf sa, isa;            // u32[N]
+    DevBuf pl, pr;             // u32[N]: lcp with SA predecessor / successor, by text position
+    DevBuf RT, PLT, PRT;       // u32[n*mp] column-tiled: rank, lcp-prev, lcp-next of cell (i,x)
+    DevBuf PT, IGT;            // u32[n*mp] column-tiled text pointer / ignore column (optional)
+    DevBuf colT;               // u32[N]: MSA column of each text position (gapped MSAs only)
+
+    // scratch
+    DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tmp, small, scalars;
+    DevBuf dp_a, dp_b, dp_c, dp_d, dp_e, dp_f, dp_g, dp_h, io_a, io_b, io_c, io_d;
+
+    StageTimer timers[FBG_STAGE_COUNT];
+};
+
+// ---- error plumbing ----------------------------------------------------------------------
+int fbg_fail(fbg_ctx *ctx, int code, const char *fmt, ...);
+#define FBG_HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fbg_fail((ctx), e_ == hipErrorOutOfMemory ? FBG_ERR_OOM : FBG_ERR_HIP,   \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                      \
+    } while (0)
+#define FBG_TRY(expr)                \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != FBG_OK) return rc_; \
+    } while (0)
+
+int fbg_reserve(fbg_ctx *ctx, DevBuf &b, size_t bytes);   // grow-only device allocation
+void fbg_release(fbg_ctx *ctx, DevBuf &b);
+int fbg_stage_begin(fbg_ctx *ctx, int stage);
+int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);
+
+// ---- stages (each in its own translation unit) ----------------------------------------------
+int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len);  // text_build.hip
+int fbg_suffix_sort(fbg_ctx *ctx);                                            // suffix_sort.hip
+int fbg_neighbour_lcp(fbg_ctx *ctx);                                          // lcp.hip
+int fbg_tile_columns(fbg_ctx *ctx);                                           // tile.hip
+int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
+                     uint64_t *d_out);                                        // scan.hip
+int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,
+                  uint64_t *count_out, uint64_t *d_mml, uint64_t *d_bt);      // dp.hip
+int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
+                      uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out);
+
+#define FBG_SCAN_F 0
+#define FBG_SCAN_V 1
+
+static inline unsigned fbg_blocks(uint64_t work, unsigned per_block, unsigned cap = 0x7fffffffu)
+{
+    uint64_t b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}

@@ -1,0 +1,243 @@
+// suffix_sort.hip -- suffix array and inverse of the indexed text, on the device.
+//
+// Stands in for the suffix sorting inside sdsl::construct(cst, file, 1) (fbg.cpp:428): suffixes of
+// T (bytes, unique smallest sentinel 0 at the end) in unsigned-byte lexicographic order.
+//
+// Method: prefix doubling with early discard.
+//   round 0  every suffix gets a 64-bit key holding its first K symbols (alphabet compacted to b
+//            bits, K = 64/b) and all N (key, position) pairs are radix sorted;
+//   round k  only suffixes still sharing their key with a neighbour are re-sorted, by
+//            (rank of their group, rank of the suffix h symbols further on), h = K, 2K, 4K, ...
+// rank[p] is always the SA index of the first member of p's group, so it is final as soon as the
+// group is a singleton.  Device-wide sort / scan / select primitives come from rocPRIM; the key
+// packing, grouping and doubling kernels are this file's.
+#include "fbg_internal.h"
+#include <rocprim/rocprim.hpp>
+
+#define SS_THREADS 256
+
+__global__ void k_byte_hist(const uint8_t *__restrict__ T, uint64_t N, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[T[p]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// key[p] = first K symbol codes of suffix p, most significant first, zero beyond the text
+__global__ __launch_bounds__(SS_THREADS) void k_pack_keys(const uint8_t *__restrict__ T, uint64_t N,
+                                                          const uint8_t *__restrict__ code, int b, int K,
+                                                          uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    __shared__ uint8_t tile[SS_THREADS + 64];
+    __shared__ uint8_t cd[256];
+    cd[threadIdx.x] = code[threadIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * SS_THREADS;
+    for (int k = threadIdx.x; k < SS_THREADS + 64; k += SS_THREADS) {
+        uint64_t p = base + k;
+        tile[k] = p < N ? T[p] : 0;
+    }
+    __syncthreads();
+    const uint64_t p = base + threadIdx.x;
+    if (p >= N) return;
+    uint64_t key = 0;
+    for (int k = 0; k < K; k++) {
+        uint64_t q = p + k;
+        uint8_t c = q < N ? cd[tile[threadIdx.x + k]] : 0;
+        key = (key << b) | c;
+    }
+    keys[p] = key;
+    vals[p] = (uint32_t)p;
+}
+
+// grp[r] = r if key[r] starts a group, else 0  (max-scan turns it into the group head index)
+__global__ void k_mark_heads(const uint64_t *__restrict__ keys, uint64_t cnt, const uint32_t *__restrict__ where,
+                             uint32_t *__restrict__ grp)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    bool head = k == 0 || keys[k] != keys[k - 1];
+    uint32_t r = where ? where[k] : (uint32_t)k;
+    grp[k] = head ? r : 0u;
+}
+
+// after the max-scan: scatter ranks, flag members of groups with more than one element
+__global__ void k_apply_groups(const uint32_t *__restrict__ grp, const uint32_t *__restrict__ vals, uint64_t cnt,
+                               const uint32_t *__restrict__ where, uint32_t *__restrict__ rank,
+                               uint32_t *__restrict__ sa, uint8_t *__restrict__ flags)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    uint32_t r = where ? where[k] : (uint32_t)k;
+    uint32_t g = grp[k];
+    uint32_t p = vals[k];
+    rank[p] = g;
+    if (sa) sa[r] = p;
+    bool head = g == r;
+    bool next_head = (k + 1 == cnt) || (grp[k + 1] == (where ? where[k + 1] : (uint32_t)(k + 1)));
+    flags[k] = !(head && next_head);
+}
+
+struct KeepIdx { uint32_t r, p, g; };
+
+// compact the unresolved members: (SA index, position, group head) triples in SA order
+__global__ void k_gather_unresolved(const uint32_t *__restrict__ sel, uint64_t cnt, const uint32_t *__restrict__ where_old,
+                                    const uint32_t *__restrict__ vals_old, const uint32_t *__restrict__ grp_old,
+                                    uint32_t *__restrict__ where_new, uint32_t *__restrict__ vals_new,
+                                    uint32_t *__restrict__ grp_new)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    uint32_t s = sel[k];
+    where_new[k] = where_old ? where_old[s] : s;
+    vals_new[k] = vals_old[s];
+    grp_new[k] = grp_old[s];
+}
+
+// key = (group head, rank of the suffix h further on)
+__global__ void k_doubling_keys(const uint32_t *__restrict__ vals, const uint32_t *__restrict__ grp, uint64_t cnt,
+                                const uint32_t *__restrict__ rank, uint64_t h, uint64_t N,
+                                uint64_t *__restrict__ keys)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    uint64_t q = (uint64_t)vals[k] + h;
+    uint32_t r2 = q < N ? rank[q] : 0u;   // q < N always holds for unresolved suffixes (unique sentinel)
+    keys[k] = ((uint64_t)grp[k] << 32) | r2;
+}
+
+__global__ void k_iota(uint32_t *__restrict__ a, uint64_t cnt)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) a[k] = (uint32_t)k;
+}
+
+static int ensure_tmp(fbg_ctx *ctx, size_t bytes) { return fbg_reserve(ctx, ctx->tmp, bytes); }
+
+template <class F> static int with_tmp(fbg_ctx *ctx, F &&call)
+{
+    size_t bytes = 0;
+    hipError_t e = call(nullptr, bytes);
+    if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim size query: %s", hipGetErrorString(e));
+    FBG_TRY(ensure_tmp(ctx, bytes));
+    size_t have = ctx->tmp.cap;
+    e = call(ctx->tmp.p, have);
+    if (e != hipSuccess)
+        return fbg_fail(ctx, e == hipErrorOutOfMemory ? FBG_ERR_OOM : FBG_ERR_HIP, "rocprim call: %s", hipGetErrorString(e));
+    return FBG_OK;
+}
+
+int fbg_suffix_sort(fbg_ctx *ctx)
+{
+    const uint64_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SUFFIX_SORT));
+    int launches = 0;
+    const uint8_t *T = ctx->text.as<uint8_t>();
+
+    // ---- alphabet compaction (order preserving) -------------------------------------------
+    unsigned *d_hist = ctx->small.as<unsigned>() + 256;   // small: bytes [0,256) ignore table, [1024,2048) histogram, [2048,2304) code table
+    uint8_t *d_code = ctx->small.as<uint8_t>() + 2048;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
+    hipLaunchKernelGGL(k_byte_hist, dim3(fbg_blocks(N, 256 * 64, 4096)), dim3(256), 0, st, T, N, d_hist);
+    unsigned hist[256];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint8_t code[256];
+    int sigma = 0;
+    for (int c = 0; c < 256; c++) { code[c] = (uint8_t)sigma; if (hist[c]) sigma++; }
+    if (hist[0] != 1)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "the MSA contains a NUL byte; the text needs a unique 0 sentinel");
+    int b = 1;
+    while ((1 << b) < sigma) b++;
+    const int K = 64 / b;            // symbols per 64-bit key
+    const int key_bits = K * b;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // code[] lives on this stack frame
+
+    // ---- round 0: sort all suffixes by their first K symbols -------------------------------
+    FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->valsB, N * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->flags, N));
+    FBG_TRY(fbg_reserve(ctx, ctx->sa, N * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->isa, N * 4));
+    uint64_t *keysA = ctx->keysA.as<uint64_t>(), *keysB = ctx->keysB.as<uint64_t>();
+    uint32_t *valsA = ctx->valsA.as<uint32_t>(), *valsB = ctx->valsB.as<uint32_t>();
+    uint32_t *grp = ctx->grp.as<uint32_t>(), *rank = ctx->isa.as<uint32_t>(), *sa = ctx->sa.as<uint32_t>();
+    uint8_t *flags = ctx->flags.as<uint8_t>();
+    unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
+
+    hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
+                       keysA, valsA);
+    launches += 2;
+    FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::radix_sort_pairs(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, 0u, (unsigned)key_bits, st);
+    }));
+    // groups of equal keys -> rank (= SA index of the group head), SA, unresolved flags
+    hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keysB, N, (const uint32_t *)nullptr, grp);
+    FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::inclusive_scan(tmp, bytes, grp, grp, (size_t)N, rocprim::maximum<uint32_t>(), st);
+    }));
+    hipLaunchKernelGGL(k_apply_groups, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, grp, valsB, N,
+                       (const uint32_t *)nullptr, rank, sa, flags);
+    launches += 4;
+
+    // ---- doubling rounds on the unresolved suffixes ----------------------------------------
+    // state of the compacted list (in SA order): where[k] = SA index, vals[k] = position, grp[k]
+    uint64_t cnt = N;
+    const uint32_t *where_cur = nullptr;      // nullptr = identity (round 0)
+    uint32_t *vals_cur = valsB, *grp_cur = grp;
+    // ping-pong storage for the compacted lists
+    FBG_TRY(fbg_reserve(ctx, ctx->list, N * 4));
+    uint32_t *sel = ctx->list.as<uint32_t>();
+    DevBuf *wbuf[2] = {&ctx->dp_a, &ctx->dp_b}, *vbuf[2] = {&ctx->dp_c, &ctx->dp_d}, *gbuf[2] = {&ctx->dp_e, &ctx->dp_f};
+    int pp = 0;
+    uint64_t h = (uint64_t)K;
+    for (int round = 1;; round++) {
+        // select unresolved members of the current list
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::select(tmp, bytes, rocprim::counting_iterator<uint32_t>(0), flags, sel, d_count, (size_t)cnt, st);
+        }));
+        unsigned long long hc = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&hc, d_count, sizeof(hc), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        launches += 1;
+        if (hc == 0) break;
+        if (round > 64) return fbg_fail(ctx, FBG_ERR_HIP, "suffix sort did not converge");
+        const uint64_t ncnt = hc;
+        FBG_TRY(fbg_reserve(ctx, *wbuf[pp], ncnt * 4));
+        FBG_TRY(fbg_reserve(ctx, *vbuf[pp], ncnt * 4));
+        FBG_TRY(fbg_reserve(ctx, *gbuf[pp], ncnt * 4));
+        uint32_t *where_new = wbuf[pp]->as<uint32_t>(), *vals_new = vbuf[pp]->as<uint32_t>(),
+                 *grp_new = gbuf[pp]->as<uint32_t>();
+        hipLaunchKernelGGL(k_gather_unresolved, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, sel, ncnt, where_cur,
+                           vals_cur, grp_cur, where_new, vals_new, grp_new);
+        hipLaunchKernelGGL(k_doubling_keys, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, vals_new, grp_new, ncnt,
+                           rank, h, N, keysA);
+        // sort by (group, rank at +h); the sorted positions go back to the same SA slots
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::radix_sort_pairs(tmp, bytes, keysA, keysB, vals_new, valsA, (size_t)ncnt, 0u, 64u, st);
+        }));
+        hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, keysB, ncnt, where_new, grp_new);
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::inclusive_scan(tmp, bytes, grp_new, grp_new, (size_t)ncnt, rocprim::maximum<uint32_t>(), st);
+        }));
+        hipLaunchKernelGGL(k_apply_groups, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, grp_new, valsA, ncnt,
+                           where_new, rank, sa, flags);
+        // the sorted positions become the list's values for the next round
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(vals_new, valsA, ncnt * 4, hipMemcpyDeviceToDevice, st));
+        launches += 7;
+        where_cur = where_new; vals_cur = vals_new; grp_cur = grp_new;
+        cnt = ncnt;
+        pp ^= 1;
+        h *= 2;
+    }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
+}

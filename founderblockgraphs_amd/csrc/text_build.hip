@@ -1,0 +1,288 @@
+// text_build.hip -- MSA -> indexed text and per-row tables.
+//
+// Restates on the device what the reference does on the host before its scan:
+//   * load_cst writes every row without '-' followed by '#' (fbg.cpp:372-386) and sdsl::construct
+//     appends one 0 byte (fbg.cpp:428);
+//   * segment_elastic_minmaxlength builds per-row rank/select over non-gap cells and over
+//     ignore characters (fbg.cpp:1845-1917).
+// Here those become plain arrays: pos[i], tot[i], the text pointer of every cell (prow, only for
+// MSAs with gaps), the MSA column of every text position (colT, ditto) and the first ignore
+// column at or after every cell (igrow, only with --ignore-chars).
+// One workgroup sweeps one row in chunks with a running carry, so every load and store is a
+// contiguous stream along the row.
+#include "fbg_internal.h"
+
+#define TB_THREADS 256
+#define TB_ITEMS 8
+#define TB_CHUNK (TB_THREADS * TB_ITEMS)
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds4)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) lds4[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < TB_THREADS / 64; k++) {
+        uint32_t s = lds4[k];
+        if (k < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// tot[i] = number of non-gap cells of row i; scalars[0] += gaps, scalars[1] += ignore cells
+__global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restrict__ msa, uint64_t n,
+                                                          const uint8_t *__restrict__ is_ignore,
+                                                          uint32_t *__restrict__ tot,
+                                                          unsigned long long *__restrict__ scalars)
+{
+    __shared__ uint32_t red[2][TB_THREADS / 64];
+    const uint64_t i = blockIdx.x;
+    const uint8_t *row = msa + i * n;
+    uint32_t nongap = 0, ign = 0;
+    for (uint64_t x = threadIdx.x; x < n; x += TB_THREADS) {
+        uint8_t c = row[x];
+        nongap += c != '-';
+        if (is_ignore) ign += is_ignore[c];
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        nongap += __shfl_down(nongap, d, 64);
+        ign += __shfl_down(ign, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nongap; red[1][threadIdx.x >> 6] = ign; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0;
+        for (int k = 0; k < TB_THREADS / 64; k++) { a += red[0][k]; b += red[1][k]; }
+        tot[i] = a;
+        atomicAdd(&scalars[0], (unsigned long long)(n - a));
+        atomicAdd(&scalars[1], (unsigned long long)b);
+    }
+}
+
+// pos[i] = sum_{k<i} (tot[k] + 1); scalars[2] = N = sum + m + 1
+__global__ void k_row_offsets(const uint32_t *__restrict__ tot, uint64_t m, uint32_t *__restrict__ pos,
+                              unsigned long long *__restrict__ scalars)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (uint64_t i = 0; i < m; i++) { pos[i] = (uint32_t)s; s += (unsigned long long)tot[i] + 1; }
+        scalars[2] = s + 1;
+    }
+}
+
+template <bool GAPPED, bool REVERSED>
+__global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__restrict__ msa, uint64_t n,
+                                                           const uint32_t *__restrict__ pos,
+                                                           const uint32_t *__restrict__ tot,
+                                                           uint8_t *__restrict__ T, uint32_t *__restrict__ prow,
+                                                           uint32_t *__restrict__ colT)
+{
+    __shared__ uint32_t lds4[TB_THREADS / 64];
+    const uint64_t i = blockIdx.x;
+    const uint8_t *row = msa + i * n;
+    const uint32_t p0 = pos[i];
+    uint32_t carry = 0;
+    for (uint64_t base = 0; base < n; base += TB_CHUNK) {
+        const uint64_t x0 = base + (uint64_t)threadIdx.x * TB_ITEMS;
+        uint8_t c[TB_ITEMS];
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < TB_ITEMS; k++) {
+            c[k] = x0 + k < n ? row[x0 + k] : (uint8_t)'-';
+            cnt += c[k] != '-';
+        }
+        if (GAPPED) {
+            uint32_t total;
+            uint32_t off = carry + block_excl_scan(cnt, &total, lds4);
+#pragma unroll
+            for (int k = 0; k < TB_ITEMS; k++) {
+                if (x0 + k < n) {
+                    prow[i * n + x0 + k] = p0 + off;      // pos_i + rank_i(x)
+                    if (c[k] != '-') { T[p0 + off] = c[k]; colT[p0 + off] = (uint32_t)(x0 + k); off++; }
+                }
+            }
+            carry += total;
+        } else {
+#pragma unroll
+            for (int k = 0; k < TB_ITEMS; k++)
+                if (x0 + k < n) T[p0 + (REVERSED ? (n - 1 - (x0 + k)) : (x0 + k))] = c[k];
+        }
+    }
+    if (threadIdx.x == 0) {
+        T[p0 + tot[i]] = '#';
+        if (GAPPED) colT[p0 + tot[i]] = (uint32_t)n;
+    }
+}
+
+// igrow[i*n + x] = smallest column c >= x with is_ignore[msa[i][c]], or n (fbg.cpp:1669-1670)
+__global__ __launch_bounds__(TB_THREADS) void k_ignore_sweep(const uint8_t *__restrict__ msa, uint64_t n,
+                                                             const uint8_t *__restrict__ is_ignore,
+                                                             uint32_t *__restrict__ igrow)
+{
+    __shared__ uint32_t wmin[TB_THREADS / 64];
+    const uint64_t i = blockIdx.x;
+    const uint8_t *row = msa + i * n;
+    uint32_t carry = (uint32_t)n;  // first ignore column to the right of the current chunk
+    const uint64_t nchunks = (n + TB_CHUNK - 1) / TB_CHUNK;
+    for (uint64_t ch = nchunks; ch-- > 0;) {
+        const uint64_t x0 = ch * TB_CHUNK + (uint64_t)threadIdx.x * TB_ITEMS;
+        uint32_t loc[TB_ITEMS];
+        uint32_t first = 0xffffffffu;  // first ignore column among this thread's items
+#pragma unroll
+        for (int k = TB_ITEMS - 1; k >= 0; k--) {
+            if (x0 + k < n && is_ignore[row[x0 + k]]) first = (uint32_t)(x0 + k);
+            loc[k] = first;
+        }
+        // suffix-min across threads: value for thread t = min(first of threads > t)
+        uint32_t v = first;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_down(v, d, 64);
+            if (lane + d < 64) v = min(v, o);
+        }
+        if (lane == 0) wmin[w] = v;
+        __syncthreads();
+        uint32_t after = carry;  // min over later waves
+        for (int k = TB_THREADS / 64 - 1; k > w; k--) after = min(after, wmin[k]);
+        uint32_t chunk_min = carry;
+        for (int k = 0; k < TB_THREADS / 64; k++) chunk_min = min(chunk_min, wmin[k]);
+        // exclusive suffix-min inside the wave
+        uint32_t ex = __shfl_down(v, 1, 64);
+        if (lane == 63) ex = 0xffffffffu;
+        uint32_t right = min(ex, after);
+#pragma unroll
+        for (int k = 0; k < TB_ITEMS; k++)
+            if (x0 + k < n) igrow[i * n + x0 + k] = min(loc[k], right);
+        __syncthreads();
+        carry = chunk_min;
+    }
+}
+
+int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
+{
+    const uint64_t m = ctx->m, n = ctx->n;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_TEXT));
+    int launches = 0;
+    FBG_TRY(fbg_reserve(ctx, ctx->pos, m * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->tot, m * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
+    FBG_TRY(fbg_reserve(ctx, ctx->small, 4096));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->scalars.p, 0, 64 * sizeof(unsigned long long), st));
+
+    ctx->have_ignore = ignore_len > 0;
+    uint8_t *d_is_ignore = nullptr;
+    if (ctx->have_ignore) {
+        uint8_t table[256];
+        memset(table, 0, sizeof(table));
+        for (uint64_t k = 0; k < ignore_len; k++) table[ignore[k]] = 1;   // fbg.cpp:1853,1868
+        d_is_ignore = ctx->small.as<uint8_t>();
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(d_is_ignore, table, 256, hipMemcpyHostToDevice, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // table[] is on this stack frame
+    }
+    unsigned long long *sc = ctx->scalars.as<unsigned long long>();
+    hipLaunchKernelGGL(k_row_count, dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,
+                       ctx->tot.as<uint32_t>(), sc);
+    hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(64), 0, st, ctx->tot.as<uint32_t>(), m,
+                       ctx->pos.as<uint32_t>(), sc);
+    launches += 2;
+    unsigned long long h[3];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->gapfree = h[0] == 0;
+    ctx->N = h[2];
+    if (ctx->N >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit ranks", h[2]);
+    if (ctx->reversed && !ctx->gapfree)
+        return fbg_fail(ctx, FBG_ERR_INVALID,
+                        "the non-elastic scan needs gap-free rows (the reference drops rows with gaps when "
+                        "--gap-limit=1, fbg.cpp:176-177); this MSA has %llu gap cells", h[0]);
+    ctx->mp = (uint32_t)((m + 63) & ~63ull);
+
+    const size_t tbytes = ctx->N + 64;
+    FBG_TRY(fbg_reserve(ctx, ctx->text, tbytes));
+    // sentinel (the 0 byte sdsl::construct appends) + zero padding for 8-byte compares
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->text.as<uint8_t>() + ctx->N - 1, 0, 65, st));
+    uint8_t *T = ctx->text.as<uint8_t>();
+    const uint32_t *pos = ctx->pos.as<uint32_t>(), *tot = ctx->tot.as<uint32_t>();
+    if (!ctx->gapfree) {
+        FBG_TRY(fbg_reserve(ctx, ctx->prow, m * n * 4));
+        FBG_TRY(fbg_reserve(ctx, ctx->colT, ctx->N * 4));
+        hipLaunchKernelGGL((k_write_text<true, false>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
+                           pos, tot, T, ctx->prow.as<uint32_t>(), ctx->colT.as<uint32_t>());
+    } else if (ctx->reversed) {
+        hipLaunchKernelGGL((k_write_text<false, true>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
+                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_write_text<false, false>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
+                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    }
+    launches++;
+    if (ctx->have_ignore) {
+        FBG_TRY(fbg_reserve(ctx, ctx->igrow, m * n * 4));
+        hipLaunchKernelGGL(k_ignore_sweep, dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,
+                           ctx->igrow.as<uint32_t>());
+        launches++;
+    }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return fbg_stage_end(ctx, FBG_STAGE_TEXT, launches);
+}
+
+// ---- synthetic MSA generator of SURVEY.md section 8(d) ---------------------------------------
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void k_synth(uint8_t *__restrict__ out, uint64_t m, uint64_t n, uint64_t seed, uint64_t seed2,
+                        uint64_t gap_thr, uint32_t gap_run, uint64_t seed3, uint64_t n_thr)
+{
+    const uint64_t total = m * n;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+         c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = c % n;
+        uint8_t ch = "ACGT"[splitmix64(seed + c) >> 62];
+        bool gap = false;
+        if (gap_run > 0) {
+            // (i,j) is a gap iff some cell (i,j-d), 0 <= d < gap_run, starts a run
+            for (uint32_t d = 0; d < gap_run && d <= j; d++)
+                if (splitmix64(seed2 + c - d) < gap_thr) { gap = true; break; }
+        }
+        if (gap) ch = '-';
+        else if (n_thr > 0 && splitmix64(seed3 + c) < n_thr) ch = 'N';
+        out[c] = ch;
+    }
+}
+
+extern "C" int fbg_msa_synthetic(fbg_ctx *ctx, uint8_t *d_msa, uint64_t m, uint64_t n, uint64_t seed,
+                                 uint64_t seed2, uint64_t gap_start_threshold, uint32_t gap_run_len,
+                                 uint64_t seed3, uint64_t n_threshold)
+{
+    if (!ctx || !d_msa || m == 0 || n == 0) return FBG_ERR_INVALID;
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_synth, dim3(fbg_blocks(m * n, 256 * 8, 8192)), dim3(256), 0, ctx->stream, d_msa, m, n,
+                       seed, seed2, gap_start_threshold, gap_run_len, seed3, n_threshold);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return FBG_OK;
+}

@@ -1,0 +1,154 @@
+/*
+ * fbg_hip.h -- C ABI of libfbg_hip.so, the MI355X (gfx950) segmentation engine.
+ *
+ * The reference (algbio/founderblockgraphs, founderblockgraph.cpp = "fbg.cpp") has no FFI
+ * or plugin seam; the hot path sits behind two in-process C++ calls made from main():
+ *
+ *   segment_elastic_minmaxlength(MSA, cst, ignorechars, out_indices, disable_efg_tricks, f)
+ *                                             fbg.cpp:1836-1844, called at fbg.cpp:3393
+ *   segment(MSA, cst, out_labels, out_edges)  fbg.cpp:526-531,   called at fbg.cpp:3437
+ *
+ * together with the index they consume (load_cst, fbg.cpp:361-436).  The entry points
+ * below are what a maintainer binds instead of those calls (INTEGRATION.md shows the
+ * patch).  Everything is plain C: pointers + sizes, int status codes, caller-owned
+ * buffers, one opaque context, calls on one context serialised by the caller.  All
+ * column/row/boundary values are uint64_t because the reference's size_type is
+ * (fbg.cpp:47).
+ *
+ * Limits of this build: text length N = (#non-gap cells) + m + 1 must be < 2^32
+ * (32-bit suffix ranks), m <= FBG_MAX_ROWS.  Violations return FBG_ERR_TOO_LARGE.
+ * There is no CPU fallback: without a HIP device every compute call fails with
+ * FBG_ERR_NO_DEVICE / FBG_ERR_HIP.
+ */
+#ifndef FBG_HIP_H
+#define FBG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fbg_ctx fbg_ctx;
+
+enum {
+    FBG_OK = 0,
+    FBG_ERR_INVALID = 1,         /* bad argument / call order */
+    FBG_ERR_NO_SEGMENTATION = 2, /* "No valid segmentation found!" fbg.cpp:1932-1937,
+                                    "No proper segmentation exists." fbg.cpp:648-652 */
+    FBG_ERR_OOM = 3,
+    FBG_ERR_HIP = 4,             /* a HIP runtime call or kernel failed; see fbg_last_error */
+    FBG_ERR_TOO_LARGE = 5,
+    FBG_ERR_NO_DEVICE = 6
+};
+
+#define FBG_MAX_ROWS 16384
+
+/* stage ids for fbg_stage_ms() */
+enum {
+    FBG_STAGE_TEXT = 0,      /* MSA -> gap-stripped text + per-row tables (fbg.cpp:372-386,1845-1917) */
+    FBG_STAGE_SUFFIX_SORT,   /* suffix array + inverse (sdsl::construct, fbg.cpp:428) */
+    FBG_STAGE_LCP,           /* per-position LCP with SA predecessor / successor */
+    FBG_STAGE_TILE,          /* column-tiled rank/LCP tables */
+    FBG_STAGE_SCAN,          /* compute_f / v[] column scan (fbg.cpp:1579-1695, 552-611) */
+    FBG_STAGE_DP,            /* bucket pass + DP sweep + backtrack (fbg.cpp:1940-2039, 616-664) */
+    FBG_STAGE_COUNT
+};
+
+/* ---- context ------------------------------------------------------------------------ */
+int fbg_ctx_create(int device, fbg_ctx **out);
+void fbg_ctx_destroy(fbg_ctx *ctx);
+/* Message of the last failing call on this context ("" if none). ctx may be NULL after a
+ * failed fbg_ctx_create, in which case a process-wide message is returned. */
+const char *fbg_last_error(const fbg_ctx *ctx);
+/* Run all work of this context on an existing hipStream_t (NULL = the context's own). */
+int fbg_set_stream(fbg_ctx *ctx, void *hip_stream);
+/* Device time of a stage during the most recent call that ran it, in ms (HIP events on the
+ * context's stream); launches = number of kernel launches the figure covers. */
+int fbg_stage_ms(fbg_ctx *ctx, int stage, float *ms, int *launches);
+/* Bytes of device memory currently held by the context's workspaces. */
+uint64_t fbg_device_bytes(const fbg_ctx *ctx);
+
+/* ---- host-buffer entry points (what main() of the C++ host calls) -------------------- */
+
+/*
+ * Replaces load_cst + compute_f (fbg.cpp:361-436, 1845-1923).  msa: m rows of n bytes,
+ * row-major, '-' = gap, any other byte is a symbol.  f[0..n) is MAX-MERGED into, exactly as
+ * the reference does (fbg.cpp:1681; main() zero-fills it, fbg.cpp:3388).
+ * Returns FBG_ERR_NO_SEGMENTATION iff disable_tricks && f[0] == n (fbg.cpp:1932-1937); f is
+ * still written in that case.
+ */
+int fbg_elastic_f(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n,
+                  const uint8_t *ignore_chars, uint64_t ignore_len, int disable_tricks,
+                  uint64_t *f);
+
+/*
+ * Replaces the sort + DP + backtrack of segment_elastic_minmaxlength (fbg.cpp:1940-2039).
+ * boundaries_out: room for n+1 values; *count_out receives the number of blocks.  The last
+ * boundary is n (fbg.cpp:2027-2028).  minmaxlength_out / backtrack_out (n+1 values each) may
+ * be NULL.  FBG_ERR_NO_SEGMENTATION where the reference would index backtrack[] out of range
+ * (only reachable with --disable-elastic-tricks).
+ */
+int fbg_minmax_dp(fbg_ctx *ctx, const uint64_t *f, uint64_t n, uint64_t *boundaries_out,
+                  uint64_t *count_out, uint64_t *minmaxlength_out, uint64_t *backtrack_out);
+
+/*
+ * Replaces load_cst + the v[j] scan of segment() (fbg.cpp:552-611).  Rows must be gap-free
+ * (the reference only reaches segment() with --gap-limit=1, which drops rows with gaps,
+ * fbg.cpp:176-177, 3436-3437); a gap returns FBG_ERR_INVALID.  v[0..n) is overwritten.
+ */
+int fbg_repeatfree_v(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, uint64_t *v);
+
+/*
+ * Replaces the s[]/prev[] DP and backtrack of segment() (fbg.cpp:616-664).  s_out, prev_out:
+ * n values each (may be NULL); boundaries_out: room for n values, last one is n-1.
+ * FBG_ERR_NO_SEGMENTATION iff s[n-1] == n+1 (fbg.cpp:648-652); s/prev are still written.
+ */
+int fbg_repeatfree_dp(fbg_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *s_out,
+                      uint64_t *prev_out, uint64_t *boundaries_out, uint64_t *count_out);
+
+/* ---- device-resident staged API (bench, multi-GPU column shards) --------------------- */
+
+/* Borrow an MSA already resident in device memory (row-major m x n bytes). */
+int fbg_msa_set_device(fbg_ctx *ctx, const uint8_t *d_msa, uint64_t m, uint64_t n);
+/* Copy a host MSA into a context-owned device buffer. */
+int fbg_msa_load_host(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n);
+/*
+ * Fill a device buffer with the synthetic MSA of SURVEY.md section 8(d):
+ *   cell(i,j) = "ACGT"[splitmix64(seed + i*n + j) >> 62];
+ *   gap_run_len > 0: cell (i,j) starts a run of gap_run_len '-' iff
+ *                    splitmix64(seed2 + i*n + j) < gap_start_threshold;
+ *   n_threshold > 0: a non-gap cell becomes 'N' iff splitmix64(seed3 + i*n + j) < n_threshold.
+ */
+int fbg_msa_synthetic(fbg_ctx *ctx, uint8_t *d_msa, uint64_t m, uint64_t n, uint64_t seed,
+                      uint64_t seed2, uint64_t gap_start_threshold, uint32_t gap_run_len,
+                      uint64_t seed3, uint64_t n_threshold);
+/*
+ * Build the index of the current MSA: text, suffix array, inverse, neighbour LCPs, and the
+ * column-tiled tables the scan reads.  reversed = 0 for the elastic scan, 1 for the
+ * non-elastic v[] scan (rows written back to front).  ignore_chars only matter for
+ * reversed = 0.  Every rank of a multi-GPU job builds the same index (replicas).
+ */
+int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uint64_t ignore_len);
+/* Columns [x0, x1) of f, max-merged into d_f[x0..x1) (d_f has n entries, device memory). */
+int fbg_scan_f(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_f);
+/* Columns [x0, x1) of v, written to d_v[x0..x1). Requires fbg_index_build(reversed = 1). */
+int fbg_scan_v(fbg_ctx *ctx, uint64_t x0, uint64_t x1, uint64_t *d_v);
+/* DP + backtrack on device arrays; boundaries land in d_boundaries (n+1 values), count on host.
+ * d_mml / d_bt (n+1 values each) may be NULL. */
+int fbg_minmax_dp_device(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,
+                         uint64_t *count_out, uint64_t *d_mml, uint64_t *d_bt);
+int fbg_repeatfree_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
+                             uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out);
+/* Copy out index arrays for tests: any pointer may be NULL. Host buffers of N entries
+ * (N from fbg_text_length). SA / ISA / LCP-with-predecessor / LCP-with-successor by text position. */
+uint64_t fbg_text_length(const fbg_ctx *ctx);
+int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
+                       uint32_t *lcp_prev, uint32_t *lcp_next);
+/* Block until all work queued on the context's stream has finished. */
+int fbg_sync(fbg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBG_HIP_H */

@@ -1,0 +1,131 @@
+"""GPU parity: every result of libfbg_hip.so (through its C ABI) must be bit-identical to the CPU
+oracle (oracle/fbg_oracle.c) on the same inputs.  Integer work: exact equality, no tolerance."""
+import numpy as np
+import pytest
+
+from conftest import random_msa
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = {
+    "msa": ["AGCGA-CTAGATAC", "AGC--ACTAGTT--", "AGCGA-CTCGTTAC", "AGC--ACT-GTTAC"],
+    "test": ["ACCGATGCCGAGCTA", "ACTACTACCGAGCTA"],
+    "test2": ["-CCGATGCCGA-CTA", "A-TACTACCGAGCT-"],
+    "test3": ["ACCGATGCCGA-CTA", "A-TACTACCGAGCTA"],
+}
+
+
+def test_index_arrays_match_oracle(engine):
+    rng = np.random.default_rng(1)
+    for (m, n, kw) in [(4, 40, {}), (7, 300, dict(gap_p=0.03, gap_run=5)), (33, 257, dict(similar=0.95)),
+                       (3, 1000, dict(alphabet="AC", similar=0.99)), (65, 129, dict(alphabet="ACGTN"))]:
+        msa = random_msa(rng, m, n, **kw)
+        T, SA, ISA, LCP = O.msa_index(msa)
+        engine.msa_load_host(msa)
+        engine.index_build()
+        gT, gSA, gISA, gPL, gPR = engine.index_download()
+        assert np.array_equal(gT, T)
+        assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64))
+        assert np.array_equal(gISA.astype(np.int64), ISA.astype(np.int64))
+        N = len(T)
+        lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
+        assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA])
+        assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1])
+        assert N == engine.text_length()
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_reference_fixtures_elastic(engine, name):
+    msa = O.msa_array(FIXTURES[name])
+    for tricks_off in (False, True):
+        f = O.compute_f(msa, disable_tricks=tricks_off)
+        try:
+            g = engine.elastic_f(msa, disable_efg_tricks=tricks_off)
+        except Exception as e:   # NoSegmentation carries no f; compare through the staged path instead
+            assert tricks_off and f[0] == msa.shape[1], e
+            continue
+        assert np.array_equal(g, f)
+        mml, bt, b = O.minmax_dp(f)
+        gb, gmml, gbt = engine.minmax_dp(g, full=True)
+        assert np.array_equal(gb, b) and np.array_equal(gmml, mml) and np.array_equal(gbt, bt)
+
+
+CASES = [
+    (2, 50, {}), (5, 64, {}), (1, 30, {}), (8, 1, {}), (64, 500, {}),
+    (16, 400, dict(gap_p=0.02, gap_run=7)), (30, 300, dict(gap_p=0.05, gap_run=3, n_p=0.02)),
+    (40, 600, dict(similar=0.97)), (100, 350, dict(similar=0.99, gap_p=0.01, gap_run=10)),
+    (257, 200, dict(similar=0.9)), (1000, 120, dict(similar=0.98)), (1025, 70, {}),
+    (12, 2000, dict(alphabet="AC", similar=0.995)), (6, 300, dict(alphabet="ACGTN", n_p=0.05)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_random_elastic_f_and_dp(engine, case):
+    m, n, kw = CASES[case]
+    rng = np.random.default_rng(100 + case)
+    msa = random_msa(rng, m, n, **kw)
+    for ignore in ("", "N"):
+        f = O.compute_f(msa, ignore=ignore)
+        g = engine.elastic_f(msa, ignorechars=ignore)
+        assert np.array_equal(g, f), (case, ignore, np.flatnonzero(g != f)[:10])
+    mml, bt, b = O.minmax_dp(f)
+    gb, gmml, gbt = engine.minmax_dp(g, full=True)
+    assert np.array_equal(gmml, mml)
+    assert np.array_equal(gbt, bt)
+    assert np.array_equal(gb, b)
+
+
+def test_disable_tricks_and_max_merge(engine):
+    rng = np.random.default_rng(7)
+    msa = random_msa(rng, 9, 250, gap_p=0.02, gap_run=4)
+    f0 = rng.integers(0, 250, 250).astype(np.uint64)
+    f = O.compute_f(msa, disable_tricks=True, f_init=f0)
+    import founderblockgraphs_amd as F
+    try:
+        g = engine.elastic_f(msa, disable_efg_tricks=True, f=f0)
+        assert np.array_equal(g, f)
+    except F.NoSegmentation:
+        assert f[0] == 250
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_nonelastic(engine, case):
+    rng = np.random.default_rng(200 + case)
+    m, n, kw = [(2, 15, {}), (4, 200, {}), (64, 700, {}), (10, 500, dict(similar=0.9)),
+                (3, 400, dict(alphabet="AC")), (1, 50, {}), (100, 300, dict(similar=0.97)),
+                (5, 1, {})][case]
+    msa = random_msa(rng, m, n, **kw)
+    v = O.segment_v(msa)
+    gv = engine.repeatfree_v(msa)
+    assert np.array_equal(gv, v)
+    s, prev, b = O.segment_dp(v)
+    gs, gprev, gb = engine.repeatfree_dp(gv)
+    assert np.array_equal(gs, s) and np.array_equal(gprev, prev)
+    assert (b is None) == (gb is None)
+    if b is not None:
+        assert np.array_equal(gb, b)
+
+
+def test_nonelastic_rejects_gaps(engine):
+    import founderblockgraphs_amd as F
+    with pytest.raises(F.FbgError):
+        engine.repeatfree_v(O.msa_array(FIXTURES["msa"]))
+
+
+def test_column_shards_equal_whole(engine):
+    """compute_f_range semantics (fbg.cpp:1475-1577): any column partition gives the same f."""
+    import torch
+    rng = np.random.default_rng(5)
+    msa = random_msa(rng, 50, 1000, similar=0.95, gap_p=0.01, gap_run=6)
+    f = O.compute_f(msa)
+    engine.msa_load_host(msa)
+    engine.index_build()
+    n = msa.shape[1]
+    for shards in (1, 2, 3, 8):
+        d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        edges = [n * k // shards for k in range(shards + 1)]
+        for k in range(shards):
+            engine.scan_f(edges[k], edges[k + 1], d_f.data_ptr())
+        engine.sync()
+        assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), f)
