@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- MSA columns segmented per second on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic MSA already resident in HBM:
+    index build (text, suffix sort, neighbour LCPs, column tiles)  -> load_cst        fbg.cpp:361-436
+    per-column extension scan                                       -> compute_f       fbg.cpp:1579-1695
+    [N>1: one RCCL all-gather of the f slices]
+    bucket pass + min-max-length sweep + backtrack (rank 0)         -> fbg.cpp:1940-2039
+Workload at N=1: BASELINE config C3, synthetic 1000 rows x 1,000,000 columns, iid ACGT
+(SURVEY.md 8d generator), --elastic.  N>1: weak scaling, 1,000,000 columns per GPU, every
+rank builds the (replicated) index and scans its own column range.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the scan kernel (k_scan_columns): algorithmic
+bytes = (13*m + 8) per column over its HIP-event duration.  `cpu_baseline` times
+the CPU restatement (oracle/, kind "port") on a bounded column prefix of the same MSA.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED, SEED2, SEED3 = 0x5EED0001, 0x5EED0002, 0x5EED0003
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def splitmix64(x):
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def synth_msa_host(m, n_total, cols, seed=SEED):
+    """Columns [0, cols) of the synthetic m x n_total MSA, on the host."""
+    i = np.arange(m, dtype=np.uint64)[:, None]
+    j = np.arange(cols, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        h = splitmix64(np.uint64(seed) + i * np.uint64(n_total) + j)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[(h >> np.uint64(62)).astype(np.int64)]
+
+
+def cpu_baseline(m, n_total, sample_cols):
+    """Oracle (CPU restatement, 1 thread = the reference's default --threads=-1) on a column prefix."""
+    from oracle import pyoracle as O
+    lib = None
+    try:   # the reference builds with -march=native (Makefile:3); rebuild the port that way on this host
+        out = os.path.join("/tmp", f"liboracle_native_{os.getpid()}.so")
+        O.build(march="native", out=out)
+        lib = O.lib(out)
+    except Exception:
+        lib = O.lib()
+    msa = synth_msa_host(m, n_total, sample_cols)
+    t = {}
+    t0 = time.perf_counter()
+    f = O.compute_f(msa, threads=1, timings=t, library=lib)
+    O.minmax_dp(f, library=lib)
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample_cols / dt, "unit": "columns/s", "cores": 1, "kind": "port",
+        "sample": f"first {sample_cols} columns of the same {m}-row synthetic MSA, elastic, "
+                  f"index {t.get('index_s', 0):.2f}s + scan {t.get('scan_s', 0):.2f}s + DP, {dt:.2f}s total",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=1000)
+    ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-cols", type=int, default=40_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import founderblockgraphs_amd as F
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    m, n = args.rows, args.cols_per_gpu * world
+    eng = F.Engine(local_rank)
+    # one stream for everything: the engine's kernels, torch's fills and the RCCL exchange
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
+
+    d_msa = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    eng.msa_synthetic(d_msa.data_ptr(), m, n, SEED)
+    d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    x0, x1 = n * rank // world, n * (rank + 1) // world
+    shard = args.cols_per_gpu
+    state = {}
+
+    def step():
+        eng.msa_set_device(d_msa.data_ptr(), m, n)
+        eng.index_build()
+        d_f.zero_()
+        eng.scan_f(x0, x1, d_f.data_ptr())
+        if world > 1:
+            # the one exchange of the path: per-column minimal extensions, n*8 bytes in total
+            dist.all_gather_into_tensor(d_f, d_f[x0:x1].clone())
+        if rank == 0:
+            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        torch.cuda.synchronize()
+        for k, (ms, ln) in eng.stage_ms().items():
+            a = stage_acc.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += ln
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        scan_ms = stage_acc["scan"][0] / max(1, args.steps)            # one launch per step
+        scan_bytes = (13 * m + 8) * (x1 - x0)
+        achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "MSA columns segmented/sec", "value": n * args.steps / dt, "unit": "columns/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {m} rows x {n} cols iid ACGT (seed 0x5EED0001), --elastic"
+                                   f"{'' if world == 1 else f', {shard} columns per GPU, replicated index'}",
+                       "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
+            "roofline": {"bound": "hbm", "kernel": "k_scan_columns", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
+            "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
+            "device_bytes": eng.device_bytes(),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(m, n, min(args.cpu_sample_cols, n))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
