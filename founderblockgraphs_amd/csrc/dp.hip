@@ -24,6 +24,10 @@ __global__ void k_dp_keys(const uint64_t *__restrict__ f, uint64_t n, uint32_t *
     if (fx > n || fx < x) { atomicAdd(bad, 1ull); fx = fx > n ? n : x; }   // f[x] in [x, n] by construction
     e[x] = (uint32_t)(fx + 1);
     atomicAdd(&hist[fx + 1], 1u);
+    // longest minimal extension f[x]+1-x, reduced per wave then one atomic
+    unsigned long long ext = fx + 1 - x;
+    for (int d = 32; d >= 1; d >>= 1) ext = max(ext, (unsigned long long)__shfl_down(ext, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(bad + 1, ext);
 }
 
 __global__ void k_dp_scatter(const uint32_t *__restrict__ e, uint64_t n, uint32_t *__restrict__ cursor,
@@ -80,6 +84,113 @@ __global__ void k_dp_minmax(const uint32_t *__restrict__ bstart, const uint32_t 
     }
 }
 
+
+// ---- wave-parallel sweep ---------------------------------------------------------------------------
+//
+// Equivalent statement of fbg.cpp:1968-2014 used when f[0] == 0 (always true with the elastic
+// "tricks", fbg.cpp:1605-1608: no row is active at column 0).  Then S == 1 after step 1 and the lazy
+// index I of the reference can never hide a live count (whenever count[I] == 0, S <= I+1 holds, so the
+// S branch it takes is the true minimum), hence
+//     minmaxlength[j] = min over x with f[x]+1 <= j of max(minmaxlength[x], j - x),
+// ties resolved towards the "S" candidate exactly as the strict `I < S` test does (fbg.cpp:2004).
+// Lane L of the wave keeps cand[L] = max{ x : f[x]+1 <= j, minmaxlength[x] <= L }; then
+//     minmaxlength[j] = min{ L : cand[L] + L >= j }                       (one ballot + find-first)
+//     backtrack[j]    = j - L*      if cand[L*-1] == j - L*   (the reference's S / backtrack_S branch)
+//                     = cand[L*]    otherwise                 (its count_solutions / backtrack_count branch)
+// R registers per lane cover block lengths up to 64*R-1; minmaxlength never exceeds twice the longest
+// minimal extension + 1, which is how R is chosen.  A step that finds no feasible lane raises `flag`
+// and the host reruns the literal kernel (never observed; it guards the bound).
+#define DPW 1024   // steps / items staged in LDS per refill (multiple of 64)
+
+template <int R>
+__global__ __launch_bounds__(64) void k_dp_wave(const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ items,
+                                                uint32_t n, uint32_t *__restrict__ mml, uint32_t *__restrict__ bt,
+                                                unsigned long long *__restrict__ flag)
+{
+    constexpr int RING = 64 * R;              // covers x in (j - 64R, j): extensions are < 32R
+    __shared__ uint32_t ring[RING];
+    __shared__ uint32_t s_bs[DPW];            // bstart[jb+1 .. jb+DPW]: bucket end of each staged step
+    __shared__ uint32_t s_it[DPW];            // items[itbase .. itbase+DPW)
+    const int lane = threadIdx.x;
+    int cand[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) cand[r] = 0;  // f[0] == 0: column 0 is a candidate for every length from step 1 on
+    if (R > 1) { for (int k = lane; k < RING; k += 64) ring[k] = 0; }
+    int minLs = 1 << 30;
+
+    // items reach the steps through two windows: DPW entries in LDS, 64 of them in one VGPR
+    uint32_t y = 0, itbase = 0, itw = 0;      // itw: items index of lane 0 of the register window
+    for (int k = lane; k < DPW; k += 64) s_it[k] = (uint32_t)k < n ? items[k] : 0;
+    __syncthreads();
+    uint32_t itv = s_it[lane];
+    // steps are walked in 64-aligned groups so that lane (j & 63) of one register holds minmaxlength[j]
+    int ringv = 0, outb = 0;                  // lane 0 of the first group is column 0: both 0
+    for (uint32_t jb = 0; jb <= n; jb += DPW) {
+        for (uint32_t k = lane; k < DPW; k += 64) s_bs[k] = jb + k + 1 <= n + 1 ? bstart[jb + k + 1] : 0;
+        __syncthreads();
+        for (uint32_t g = 0; g < DPW && jb + g <= n; g += 64) {
+            const uint32_t bsv = s_bs[g + lane];
+            const uint32_t k0 = (jb + g == 0) ? 1u : 0u;
+            const uint32_t k1 = min(64u, n - (jb + g) + 1);
+            for (uint32_t k = k0; k < k1; k++) {
+                const uint32_t j = jb + g + k;
+                const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)bsv, (int)k);
+                // ---- entries with f[x]+1 == j (fbg.cpp:1969) ----
+                while (y < b1) {
+                    if (y - itw >= 64) {          // next register window
+                        itw += 64;
+                        if (itw - itbase >= DPW) {   // next LDS window
+                            itbase += DPW;
+                            __syncthreads();
+                            for (int q = lane; q < DPW; q += 64) s_it[q] = itbase + q < n ? items[itbase + q] : 0;
+                            __syncthreads();
+                        }
+                        itv = s_it[itw - itbase + lane];
+                    }
+                    const int x = __builtin_amdgcn_readlane((int)itv, (int)(y - itw));
+                    y++;
+                    int v;
+                    if (R == 1) v = __builtin_amdgcn_readlane(ringv, x & 63);
+                    else v = __builtin_amdgcn_readfirstlane((int)ring[x & (RING - 1)]);
+#pragma unroll
+                    for (int r = 0; r < R; r++) cand[r] = (64 * r + lane >= v) ? max(cand[r], x) : cand[r];
+                }
+                // ---- smallest feasible block length: cand[L] + L is increasing in L ----
+                int Ls = -1;
+#pragma unroll
+                for (int r = R - 1; r >= 0; r--) {
+                    const unsigned long long bal = __builtin_amdgcn_ballot_w64((uint32_t)(cand[r] + 64 * r + lane) >= j);
+                    if (bal) Ls = 64 * r + (int)__builtin_ctzll(bal);
+                }
+                minLs = min(minLs, Ls);
+                int cprev, ccur;
+                if (R == 1) {
+                    cprev = __builtin_amdgcn_readlane(cand[0], (Ls - 1) & 63);
+                    ccur = __builtin_amdgcn_readlane(cand[0], Ls & 63);
+                } else {
+                    cprev = ccur = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int a = __builtin_amdgcn_readlane(cand[r], (Ls - 1) & 63);
+                        const int b = __builtin_amdgcn_readlane(cand[r], Ls & 63);
+                        if (((Ls - 1) >> 6) == r) cprev = a;
+                        if ((Ls >> 6) == r) ccur = b;
+                    }
+                }
+                const int jl = (int)j - Ls;
+                const int back = cprev == jl ? jl : ccur;
+                const bool mine = lane == (int)k;
+                ringv = mine ? Ls : ringv;
+                outb = mine ? back : outb;
+                if (R > 1 && lane == 0) ring[j & (RING - 1)] = (uint32_t)Ls;
+            }
+            if ((uint32_t)lane < k1) { mml[jb + g + lane] = (uint32_t)ringv; bt[jb + g + lane] = (uint32_t)outb; }
+        }
+        __syncthreads();
+    }
+    if (minLs < 1 && lane == 0) flag[4] = 1;
+}
+
 // fbg.cpp:2026-2039.  status: 0 ok, 1 = backtrack left the array (reference: out-of-bounds read)
 __global__ void k_dp_backtrack(const uint32_t *__restrict__ bt, uint32_t n, uint64_t *__restrict__ boundaries,
                                unsigned long long *__restrict__ result)
@@ -126,7 +237,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
              *items = ctx->dp_d.as<uint32_t>(), *count = ctx->dp_e.as<uint32_t>(), *bcount = ctx->dp_f.as<uint32_t>(),
              *mml = ctx->dp_g.as<uint32_t>(), *bt = ctx->dp_h.as<uint32_t>(), *tnext = ctx->list.as<uint32_t>();
     unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
-    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 4 * sizeof(unsigned long long), st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned long long), st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(bstart, 0, w, st));
     hipLaunchKernelGGL(k_dp_keys, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, d_f, n, e, bstart, sc + 2);
     {   // exclusive scan of the histogram over keys 0..n+1 -> bucket starts
@@ -145,7 +256,37 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(cur, 0xff, w, st));   // thead = DP_NONE
-    hipLaunchKernelGGL(k_dp_minmax, dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, count, bcount, cur, tnext, mml, bt);
+    // which sweep: the wave-parallel one needs f[0] == 0 and a bounded block length
+    unsigned long long hk[5];
+    uint64_t f0 = 1;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&f0, d_f, sizeof(f0), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hk[2] != 0) return fbg_fail(ctx, FBG_ERR_INVALID, "f[] has %llu entries outside [x, n]", hk[2]);
+    const unsigned long long max_ext = hk[3];
+    int R = 0;
+    if (f0 == 0 && !getenv("FBG_DP_LITERAL")) {
+        const unsigned long long bound = 2 * max_ext + 2;   // minmaxlength[j] <= 2*max_ext + 1
+        R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 256 ? 4 : bound <= 512 ? 8 : bound <= 1024 ? 16 : 0;
+    }
+    bool literal = R == 0;
+    if (!literal) {
+        switch (R) {
+        case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+        case 2: hipLaunchKernelGGL((k_dp_wave<2>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+        case 4: hipLaunchKernelGGL((k_dp_wave<4>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+        case 8: hipLaunchKernelGGL((k_dp_wave<8>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+        default: hipLaunchKernelGGL((k_dp_wave<16>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+        }
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (hk[4] != 0) literal = true;   // guard tripped: fall through to the literal sweep
+    }
+    if (literal) {
+        FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
+        hipLaunchKernelGGL(k_dp_minmax, dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, count, bcount, cur, tnext, mml, bt);
+    }
     hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
     if (d_mml) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, n + 1, d_mml, 0);
     if (d_bt) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, bt, n + 1, d_bt, 1);
@@ -154,7 +295,6 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     unsigned long long h[3];
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (h[2] != 0) return fbg_fail(ctx, FBG_ERR_INVALID, "f[] has %llu entries outside [x, n]", h[2]);
     *count_out = h[0];
     if (h[1] != 0) return fbg_fail(ctx, FBG_ERR_NO_SEGMENTATION, "No valid segmentation found!");
     return FBG_OK;

@@ -129,3 +129,50 @@ def test_column_shards_equal_whole(engine):
             engine.scan_f(edges[k], edges[k + 1], d_f.data_ptr())
         engine.sync()
         assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), f)
+
+
+def _random_f(rng, n, max_ext, style):
+    x = np.arange(n, dtype=np.int64)
+    if style == "uniform" or n < 4:
+        ext = rng.integers(0, max_ext + 1, n)
+    elif style == "plateau":      # many columns share one right end (long repeats)
+        ends = np.sort(rng.choice(np.arange(1, n), size=max(1, n // max(2, max_ext)), replace=False))
+        nxt = ends[np.minimum(np.searchsorted(ends, x, side="left"), len(ends) - 1)]
+        ext = np.clip(nxt - x, 0, max_ext)
+    else:                         # mostly tiny with rare long extensions
+        ext = np.where(rng.random(n) < 0.03, rng.integers(0, max_ext + 1, n), rng.integers(0, 3, n))
+    f = np.minimum(x + ext, n - 1)
+    f[0] = 0
+    return f.astype(np.uint64)
+
+
+@pytest.mark.parametrize("max_ext", [0, 1, 5, 30, 31, 32, 60, 100, 200, 400, 511, 600])
+@pytest.mark.parametrize("style", ["uniform", "plateau", "spiky"])
+def test_dp_sweep_random_f(engine, max_ext, style):
+    """Both sweeps (wave-parallel for small extensions, literal otherwise) against the literal oracle."""
+    rng = np.random.default_rng(max_ext * 7 + len(style))
+    for n in (1, 2, 63, 64, 65, 1000, 5000):
+        f = _random_f(rng, n, max_ext, style)
+        mml, bt, b = O.minmax_dp(f)
+        gb, gmml, gbt = engine.minmax_dp(f, full=True)
+        assert np.array_equal(gmml, mml), (n, np.flatnonzero(gmml != mml)[:5])
+        assert np.array_equal(gbt, bt), (n, np.flatnonzero(gbt != bt)[:5])
+        assert np.array_equal(gb, b)
+
+
+def test_dp_sweep_f0_nonzero_uses_literal_semantics(engine):
+    """f[0] != 0 (only with --disable-elastic-tricks): lazy-I quirks of fbg.cpp:2004-2013 must survive."""
+    import founderblockgraphs_amd as F
+    rng = np.random.default_rng(11)
+    for n in (10, 200, 3000):
+        for _ in range(5):
+            f = _random_f(rng, n, 12, "uniform")
+            f[0] = rng.integers(1, min(n - 1, 6) + 1)
+            try:
+                mml, bt, b = O.minmax_dp(f)
+            except O.OracleError:
+                with pytest.raises(F.NoSegmentation):
+                    engine.minmax_dp(f)
+                continue
+            gb, gmml, gbt = engine.minmax_dp(f, full=True)
+            assert np.array_equal(gmml, mml) and np.array_equal(gbt, bt) and np.array_equal(gb, b)
