@@ -1,0 +1,14 @@
+// xgfa.hpp -- xGFA writer producing the bytes of output_efg (founderblockgraph.cpp:1185-1301,
+// SURVEY.md Appendix A.3), and the graph statistics segment() prints (fbg.cpp:667-728).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "fasta.hpp"
+
+// boundaries: inclusive block ends, last one == n (fbg.cpp:2027-2039).  Returns false on I/O failure.
+bool write_xgfa(const Msa &msa, const std::vector<uint64_t> &boundaries, bool output_paths,
+                const std::string &path, std::string &error);
+
+struct GraphStats { uint64_t nodes = 0, total_label_length = 0, founders = 0, edges = 0; };
+GraphStats segment_stats(const Msa &msa, const std::vector<uint64_t> &boundaries);
