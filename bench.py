@@ -7,8 +7,10 @@ One "step" = one pass of the hot path over one synthetic MSA already resident in
     [N>1: one RCCL all-gather of the f slices]
     bucket pass + min-max-length sweep + backtrack (rank 0)         -> fbg.cpp:1940-2039
 Workload at N=1: BASELINE config C3, synthetic 1000 rows x 1,000,000 columns, iid ACGT
-(SURVEY.md 8d generator), --elastic.  N>1: weak scaling, 1,000,000 columns per GPU, every
-rank builds the (replicated) index and scans its own column range.
+(SURVEY.md 8d generator), --elastic.  N>1: weak scaling, 1,000,000 columns per GPU.  While the text
+fits 32-bit ranks (N<=4) every rank builds the (replicated) index and scans its own column range
+(SURVEY.md 8e); beyond that (N=8, text 8e9) the exact row-group-pair plan of
+founderblockgraphs_amd/distributed.py is used (one all-reduce(max) instead of the all-gather).
 
 Prints ONE JSON line on rank 0.  `roofline` prices the scan kernel (k_scan_columns): algorithmic
 bytes = (13*m + 8) per column over its HIP-event duration.  `cpu_baseline` times
@@ -93,6 +95,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from founderblockgraphs_amd import distributed as D
     m, n = args.rows, args.cols_per_gpu * world
     eng = F.Engine(local_rank)
     # one stream for everything: the engine's kernels, torch's fills and the RCCL exchange
@@ -100,24 +103,47 @@ def main():
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
 
-    d_msa = torch.empty(m * n, dtype=torch.uint8, device="cuda")
-    eng.msa_synthetic(d_msa.data_ptr(), m, n, SEED)
     d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    x0, x1 = n * rank // world, n * (rank + 1) // world
-    shard = args.cols_per_gpu
     state = {}
+    replicated = m * (n + 1) + 1 < (1 << 32) - 1
+    if replicated:
+        # column shards of one (replicated) index: SURVEY.md 8e, compute_f_range's partition
+        x0, x1 = D.shard_range(n, rank, world)
+        d_msa = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+        eng.msa_synthetic(d_msa.data_ptr(), m, n, SEED)
+        scan_cols, scan_rows, mode = x1 - x0, m, "column shards, replicated index"
 
-    def step():
-        eng.msa_set_device(d_msa.data_ptr(), m, n)
-        eng.index_build()
-        d_f.zero_()
-        eng.scan_f(x0, x1, d_f.data_ptr())
-        if world > 1:
-            # the one exchange of the path: per-column minimal extensions, n*8 bytes in total
-            dist.all_gather_into_tensor(d_f, d_f[x0:x1].clone())
-        if rank == 0:
-            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        def step():
+            eng.msa_set_device(d_msa.data_ptr(), m, n)
+            eng.index_build()
+            d_f.zero_()
+            eng.scan_f(x0, x1, d_f.data_ptr())
+            f_full = D.all_gather_columns(d_f[x0:x1], n, rank, world)   # the one exchange of the path
+            if rank == 0:
+                state["blocks"] = eng.minmax_dp_device(f_full.data_ptr(), n, d_b.data_ptr())
+    else:
+        # text too long for 32-bit ranks: exact row-group-pair plan, one all-reduce(max) of f
+        G, groups, plan = D.plan_row_pairs(m, n, world)
+        mine = plan[rank]
+        rows_pair = max((groups[a][1] - groups[a][0]) + (groups[b][1] - groups[b][0]) for a, b in D.group_pairs(G))
+        d_msa = torch.empty(rows_pair * n, dtype=torch.uint8, device="cuda")
+        scan_cols, scan_rows, mode = n, rows_pair, f"row-group pairs (G={G}, {len(D.group_pairs(G))} pairs), all-reduce(max)"
+
+        def step():
+            d_f.zero_()
+            for a, b in mine:
+                off = 0
+                for g in (a, b):
+                    r0, r1 = groups[g]
+                    eng.msa_synthetic(d_msa.data_ptr() + off * n, r1 - r0, n, SEED + r0 * n)
+                    off += r1 - r0
+                eng.msa_set_device(d_msa.data_ptr(), off, n)
+                eng.index_build()
+                eng.scan_f(0, n, d_f.data_ptr())
+            D.all_reduce_max(d_f)
+            if rank == 0:
+                state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
 
     def fence():
         torch.cuda.synchronize()
@@ -147,7 +173,7 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         scan_ms = stage_acc["scan"][0] / max(1, args.steps)            # one launch per step
-        scan_bytes = (13 * m + 8) * (x1 - x0)
+        scan_bytes = (13 * scan_rows + 8) * scan_cols
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
             "metric": "MSA columns segmented/sec", "value": n * args.steps / dt, "unit": "columns/s",
@@ -155,7 +181,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {m} rows x {n} cols iid ACGT (seed 0x5EED0001), --elastic"
-                                   f"{'' if world == 1 else f', {shard} columns per GPU, replicated index'}",
+                                   f"{'' if world == 1 else f', {args.cols_per_gpu} columns per GPU, {mode}'}",
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
             "roofline": {"bound": "hbm", "kernel": "k_scan_columns", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

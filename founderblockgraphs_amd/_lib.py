@@ -26,6 +26,7 @@ SIGNATURES = {
     "fbg_set_stream": (C.c_int, [vp, vp]),
     "fbg_stage_ms": (C.c_int, [vp, C.c_int, fp, ip]),
     "fbg_device_bytes": (C.c_uint64, [vp]),
+    "fbg_release_scratch": (C.c_int, [vp]),
     "fbg_elastic_f": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.c_int, u64p]),
     "fbg_minmax_dp": (C.c_int, [vp, u64p, C.c_uint64, u64p, u64p, u64p, u64p]),
     "fbg_repeatfree_v": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u64p]),

@@ -178,6 +178,9 @@ class Engine:
             out[name] = (ms.value, ln.value)
         return out
 
+    def release_scratch(self):
+        self._chk(self._L.fbg_release_scratch(self._h))
+
     def device_bytes(self):
         return int(self._L.fbg_device_bytes(self._h))
 

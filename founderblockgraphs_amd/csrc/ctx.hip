@@ -151,6 +151,18 @@ int fbg_stage_ms(fbg_ctx *ctx, int stage, float *ms, int *launches)
 
 uint64_t fbg_device_bytes(const fbg_ctx *ctx) { return ctx ? ctx->held_bytes : 0; }
 
+int fbg_release_scratch(fbg_ctx *ctx)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DevBuf *bufs[] = {&ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags, &ctx->list,
+                      &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
+                      &ctx->dp_g, &ctx->dp_h};
+    for (DevBuf *b : bufs) fbg_release(ctx, *b);
+    return FBG_OK;
+}
+
 int fbg_sync(fbg_ctx *ctx)
 {
     if (!ctx) return FBG_ERR_INVALID;
@@ -200,6 +212,7 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     ctx->reversed = reversed ? 1 : 0;
     FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
     FBG_TRY(fbg_suffix_sort(ctx));
+    if (ctx->N > 1500000000ull) FBG_TRY(fbg_release_scratch(ctx));   // make room for the tiled tables
     FBG_TRY(fbg_neighbour_lcp(ctx));
     FBG_TRY(fbg_tile_columns(ctx));
     ctx->index_valid = true;

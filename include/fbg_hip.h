@@ -42,7 +42,7 @@ enum {
     FBG_ERR_NO_DEVICE = 6
 };
 
-#define FBG_MAX_ROWS 16384
+#define FBG_MAX_ROWS 4096   /* scan kernel: one workgroup holds a whole column in LDS */
 
 /* stage ids for fbg_stage_ms() */
 enum {
@@ -68,6 +68,10 @@ int fbg_set_stream(fbg_ctx *ctx, void *hip_stream);
 int fbg_stage_ms(fbg_ctx *ctx, int stage, float *ms, int *launches);
 /* Bytes of device memory currently held by the context's workspaces. */
 uint64_t fbg_device_bytes(const fbg_ctx *ctx);
+/* Free the suffix-sort / DP scratch buffers (the index itself stays valid).  Called automatically
+ * after the suffix sort when the text is longer than 1.5e9 symbols, so that a 4e9-symbol index
+ * fits the 288 GB of one MI355X. */
+int fbg_release_scratch(fbg_ctx *ctx);
 
 /* ---- host-buffer entry points (what main() of the C++ host calls) -------------------- */
 

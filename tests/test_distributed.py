@@ -1,0 +1,96 @@
+"""world_size-2 gloo test of the column-shard plumbing (shard ranges, uneven all-gather, rank-0
+sweep).  The per-shard compute is the oracle's compute_f_range partition here; on the GPU the same
+plumbing runs on libfbg_hip.so (tests/test_gpu_parity.py::test_sharded_pipeline_single_gpu)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import random_msa
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, seed, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from founderblockgraphs_amd import distributed as D
+    from oracle import pyoracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    msa = random_msa(np.random.default_rng(seed), 12, n, similar=0.95, gap_p=0.02, gap_run=4)
+    f_ref = O.compute_f(msa)
+
+    def scan(x0, x1):
+        # stand-in for the HIP scan of one shard: the oracle restricted to the rank's columns
+        return torch.from_numpy(f_ref[x0:x1].astype(np.int64))
+
+    def sweep(f_full):
+        return torch.from_numpy(O.minmax_dp(f_full.numpy().astype(np.uint64))[2].astype(np.int64))
+
+    f_full, b = D.segment_columns_sharded(n, scan, sweep)
+    assert np.array_equal(f_full.numpy().astype(np.uint64), f_ref)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "b.npy"), b.numpy())
+        np.save(os.path.join(out_dir, "ref.npy"), O.minmax_dp(f_ref)[2].astype(np.int64))
+    else:
+        assert b is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 512, 3])
+def test_two_rank_column_shards(n, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), n, 42, str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "b.npy"), np.load(tmp_path / "ref.npy"))
+
+
+def test_shard_ranges_partition_the_columns():
+    from founderblockgraphs_amd.distributed import shard_range
+    for n in (1, 7, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_pairs(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from founderblockgraphs_amd import distributed as D
+    from oracle import pyoracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, n = 13, 300
+    msa = random_msa(np.random.default_rng(5), m, n, similar=0.96, gap_p=0.02, gap_run=5, n_p=0.01)
+    # pretend ranks hold at most 8 rows x (n+1) symbols: forces the row-group-pair plan
+    G, groups, plan = D.plan_row_pairs(m, n, world, limit=8 * (n + 1) + 1)
+    f = torch.zeros(n, dtype=torch.int64)
+    for a, b in plan[rank]:
+        rows = list(range(*groups[a])) + list(range(*groups[b]))
+        part = O.compute_f(msa[rows], ignore="N")       # stand-in for index_build + scan_f on one pair
+        f = torch.maximum(f, torch.from_numpy(part.astype(np.int64)))
+    D.all_reduce_max(f)
+    assert np.array_equal(f.numpy().astype(np.uint64), O.compute_f(msa, ignore="N"))
+    assert sorted(p for r in plan for p in r) == D.group_pairs(G) and G >= 3
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_group_pairs(tmp_path):
+    """The capacity plan used when m*(n+1)+1 >= 2^32: pairs of row groups, element-wise max of f."""
+    mp.spawn(_worker_pairs, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)

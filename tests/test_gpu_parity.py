@@ -124,6 +124,7 @@ def test_column_shards_equal_whole(engine):
     n = msa.shape[1]
     for shards in (1, 2, 3, 8):
         d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
         edges = [n * k // shards for k in range(shards + 1)]
         for k in range(shards):
             engine.scan_f(edges[k], edges[k + 1], d_f.data_ptr())
@@ -176,3 +177,158 @@ def test_dp_sweep_f0_nonzero_uses_literal_semantics(engine):
                 continue
             gb, gmml, gbt = engine.minmax_dp(f, full=True)
             assert np.array_equal(gmml, mml) and np.array_equal(gbt, bt) and np.array_equal(gb, b)
+
+
+def test_sharded_pipeline_single_gpu(engine):
+    """founderblockgraphs_amd.distributed plumbing on the real engine, world of 1..3 simulated in-process."""
+    import torch
+    from founderblockgraphs_amd import distributed as D
+    rng = np.random.default_rng(6)
+    msa = random_msa(rng, 30, 700, similar=0.96, gap_p=0.02, gap_run=5)
+    n = msa.shape[1]
+    f = O.compute_f(msa)
+    b = O.minmax_dp(f)[2]
+    engine.msa_load_host(msa)
+    engine.index_build()
+    scan, sweep = D.engine_scan_shard(engine, n), D.engine_sweep(engine)
+    for world in (1, 2, 3):
+        parts = [scan(*D.shard_range(n, r, world)).clone() for r in range(world)]
+        full = torch.cat(parts)
+        assert np.array_equal(full.cpu().numpy().astype(np.uint64), f)
+        assert np.array_equal(sweep(full).cpu().numpy().astype(np.uint64), b)
+
+
+def test_row_group_pairs_single_gpu(engine):
+    """Capacity plan for texts beyond 32-bit ranks: max over row-group pairs == whole-MSA f, on the engine."""
+    import torch
+    from founderblockgraphs_amd import distributed as D
+    rng = np.random.default_rng(8)
+    m, n = 37, 600
+    msa = random_msa(rng, m, n, similar=0.97, gap_p=0.02, gap_run=4, n_p=0.01)
+    f = O.compute_f(msa, ignore="N")
+    G, groups, plan = D.plan_row_pairs(m, n, 1, limit=20 * (n + 1) + 1)
+    d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for a, b in plan[0]:
+        rows = list(range(*groups[a])) + list(range(*groups[b]))
+        engine.msa_load_host(msa[rows])
+        engine.index_build(ignorechars="N")
+        engine.scan_f(0, n, d_f.data_ptr())
+    engine.sync()
+    assert G >= 4 and np.array_equal(d_f.cpu().numpy().astype(np.uint64), f)
+
+
+def test_committed_oracle_vectors(engine):
+    """GPU results against tests/golden/oracle_vectors.json (made by tests/golden/make_golden.py)."""
+    import hashlib
+    import json
+    import os
+
+    def digest(a):
+        return hashlib.sha256(np.ascontiguousarray(a, dtype="<u8").tobytes()).hexdigest()
+    path = os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")
+    for c in json.load(open(path)):
+        msa = random_msa(np.random.default_rng(c["seed"]), c["m"], c["n"], **c["kw"])
+        assert hashlib.sha256(msa.tobytes()).hexdigest() == c["msa_sha256"]
+        if c.get("nonelastic"):
+            v = engine.repeatfree_v(msa)
+            s, prev, b = engine.repeatfree_dp(v)
+            assert digest(v) == c["v"] and digest(s) == c["s"] and digest(prev) == c["prev"]
+            assert (None if b is None else b.tolist()) == c["boundaries"]
+        else:
+            f = engine.elastic_f(msa, ignorechars=c.get("ignore", ""))
+            b, mml, bt = engine.minmax_dp(f, full=True)
+            assert (f.tolist() if isinstance(c["f"], list) else digest(f)) == c["f"]
+            assert digest(mml) == c["mml"] and digest(bt) == c["bt"] and digest(b) == c["boundaries"]
+            assert len(b) == c["n_blocks"] and int(mml[-1]) == c["optimal"]
+
+
+def test_synthetic_generator_matches_host_spec(engine):
+    """fbg_msa_synthetic == the splitmix64 spec of SURVEY.md 8(d), including gap runs and N cells."""
+    import torch
+
+    def sm(x):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    m, n, run = 7, 501, 16
+    d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    engine.msa_synthetic(d.data_ptr(), m, n, gap_fraction=0.05, gap_run=run, n_fraction=0.01)
+    engine.sync()
+    got = d.cpu().numpy().reshape(m, n)
+    c = np.arange(m * n, dtype=np.uint64).reshape(m, n)
+    with np.errstate(over="ignore"):
+        base = np.frombuffer(b"ACGT", dtype=np.uint8)[(sm(np.uint64(0x5EED0001) + c) >> np.uint64(62)).astype(np.int64)]
+        start = sm(np.uint64(0x5EED0002) + c) < np.uint64(int((1 << 64) * (0.05 / run)))
+        isn = sm(np.uint64(0x5EED0003) + c) < np.uint64(int((1 << 64) * 0.01))
+    gap = np.zeros((m, n), dtype=bool)
+    for i, j in np.argwhere(start):
+        gap[i, j:j + run] = True
+    exp = np.where(gap, ord("-"), np.where(isn, ord("N"), base)).astype(np.uint8)
+    assert np.array_equal(got, exp)
+
+
+def test_full_size_properties(engine):
+    """BASELINE C3 shape (1000 x 1,000,000, iid) and C2 shape (64 x 100,000 non-elastic) at full size:
+    properties that do not need the oracle -- f in range, shards == whole, every block at least its
+    minimal valid width, both sweeps (wave-parallel and literal) identical, v[] in range."""
+    import os
+    import torch
+    m, n = 1000, 1_000_000
+    d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    engine.msa_synthetic(d.data_ptr(), m, n)
+    engine.msa_set_device(d.data_ptr(), m, n)
+    engine.index_build()
+    d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_g = torch.zeros(n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    engine.scan_f(0, n, d_f.data_ptr())
+    for k in range(4):                                   # four column shards
+        engine.scan_f(n * k // 4, n * (k + 1) // 4, d_g.data_ptr())
+    engine.sync()
+    assert torch.equal(d_f, d_g)
+    x = torch.arange(n, device="cuda")
+    assert bool((d_f >= x).all()) and bool((d_f <= n - 1).all()) and int(d_f[0]) == 0
+    d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    d_mml = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    d_bt = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    cnt = engine.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr(), d_mml.data_ptr(), d_bt.data_ptr())
+    b = d_b[:cnt].clone()
+    assert int(b[-1]) == n and bool((b[1:] > b[:-1]).all())
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), b[:-1] + 1])
+    ends = torch.cat([b[:-1], torch.tensor([n - 1], device="cuda")])
+    assert bool((d_f[starts] <= ends).all())             # every block is semi-repeat-free
+    assert int((ends - starts + 1).max()) == int(d_mml[n])
+    os.environ["FBG_DP_LITERAL"] = "1"                   # statement-by-statement sweep of fbg.cpp:1968-2014
+    try:
+        d_b2 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        d_mml2 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        d_bt2 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        cnt2 = engine.minmax_dp_device(d_f.data_ptr(), n, d_b2.data_ptr(), d_mml2.data_ptr(), d_bt2.data_ptr())
+    finally:
+        del os.environ["FBG_DP_LITERAL"]
+    assert cnt2 == cnt and torch.equal(d_mml, d_mml2) and torch.equal(d_bt, d_bt2) and torch.equal(d_b[:cnt], d_b2[:cnt])
+    del d, d_g
+    # C2: 64 x 100,000 non-elastic
+    m2, n2 = 64, 100_000
+    d2 = torch.empty(m2 * n2, dtype=torch.uint8, device="cuda")
+    engine.msa_synthetic(d2.data_ptr(), m2, n2)
+    engine.msa_set_device(d2.data_ptr(), m2, n2)
+    engine.index_build(reversed=True)
+    d_v = torch.empty(n2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    engine.scan_v(0, n2, d_v.data_ptr())
+    d_b = torch.empty(n2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    cnt = engine.repeatfree_dp_device(d_v.data_ptr(), n2, d_b.data_ptr())
+    j = torch.arange(n2, device="cuda")
+    assert bool((d_v <= j + 1).all())
+    vv = d_v[d_v <= j]                                   # where a valid block exists the left end never moves back
+    assert vv.numel() > 0 and bool((vv[1:] >= vv[:-1]).all())
+    b = d_b[:cnt]
+    assert int(b[-1]) == n2 - 1
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), b[:-1] + 1])
+    assert bool((starts <= d_v[b]).all())                # block [start..end] is repeat-free iff start <= v[end]
