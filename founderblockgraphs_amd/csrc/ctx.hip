@@ -103,9 +103,8 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->sa,
-                      &ctx->isa, &ctx->pl, &ctx->pr, &ctx->RT, &ctx->PLT, &ctx->PRT, &ctx->PT, &ctx->IGT,
-                      &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
+    DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->rec,
+                      &ctx->xlist, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
                       &ctx->list, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d};
@@ -156,7 +155,8 @@ int fbg_release_scratch(fbg_ctx *ctx)
     if (!ctx) return FBG_ERR_INVALID;
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    DevBuf *bufs[] = {&ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags, &ctx->list,
+    // valsB stays: it is the suffix array
+    DevBuf *bufs[] = {&ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
@@ -212,9 +212,8 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     ctx->reversed = reversed ? 1 : 0;
     FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
     FBG_TRY(fbg_suffix_sort(ctx));
-    if (ctx->N > 1500000000ull) FBG_TRY(fbg_release_scratch(ctx));   // make room for the tiled tables
     FBG_TRY(fbg_neighbour_lcp(ctx));
-    FBG_TRY(fbg_tile_columns(ctx));
+    if (ctx->N > 1500000000ull) FBG_TRY(fbg_release_scratch(ctx));   // keep the footprint of huge indexes down
     ctx->index_valid = true;
     return FBG_OK;
 }
@@ -352,10 +351,19 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     if (!ctx->index_valid) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: no index");
     size_t N = ctx->N;
     if (text) FBG_HIP_TRY(ctx, hipMemcpyAsync(text, ctx->text.p, N, hipMemcpyDeviceToHost, ctx->stream));
-    if (sa) FBG_HIP_TRY(ctx, hipMemcpyAsync(sa, ctx->sa.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (isa) FBG_HIP_TRY(ctx, hipMemcpyAsync(isa, ctx->isa.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (lcp_prev) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_prev, ctx->pl.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (lcp_next) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_next, ctx->pr.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (sa) FBG_HIP_TRY(ctx, hipMemcpyAsync(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (isa || lcp_prev || lcp_next) {
+        // records {rank, lcp_prev|hint, lcp_next|hint, -}: pull one word column at a time (strided 2-D copy)
+        uint32_t *dst[3] = {isa, lcp_prev, lcp_next};
+        for (int w = 0; w < 3; w++) {
+            if (!dst[w]) continue;
+            FBG_HIP_TRY(ctx, hipMemcpy2DAsync(dst[w], 4, (const char *)ctx->rec.p + 4 * w, 16, 4, N,
+                                              hipMemcpyDeviceToHost, ctx->stream));
+        }
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (int w = 1; w < 3; w++)
+            if (dst[w]) for (size_t k = 0; k < N; k++) dst[w][k] &= 0x7fffffffu;   // strip the run hints
+    }
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FBG_OK;
 }

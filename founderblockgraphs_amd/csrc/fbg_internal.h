@@ -45,11 +45,11 @@ struct fbg_ctx {
     DevBuf pos, tot;           // u32[m]
     DevBuf prow;               // u32[m*n]: text pointer of cell (i,x), row-major (gapped MSAs only)
     DevBuf igrow;              // u32[m*n]: first ignore-char column >= x, row-major (ignore chars only)
-    DevBuf sa, isa;            // u32[N]
-    DevBuf pl, pr;             // u32[N]: lcp with SA predecessor / successor, by text position
-    DevBuf RT, PLT, PRT;       // u32[n*mp] column-tiled: rank, lcp-prev, lcp-next of cell (i,x)
-    DevBuf PT, IGT;            // u32[n*mp] column-tiled text pointer / ignore column (optional)
+    DevBuf rec;                // uint4[N] by text position: {rank, lcp-prev | hint<<31, lcp-next | hint<<31, 0}
+    uint32_t *sa_ptr = nullptr; // u32[N] suffix array (lives in the sort's value buffer)
+    bool lcp_from_keys = false; // neighbour LCPs came from the sorted keys (few ties) or from text compares
     DevBuf colT;               // u32[N]: MSA column of each text position (gapped MSAs only)
+    DevBuf xlist;              // u32[n+1]: columns whose coloured ranks may contain consecutive integers
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tmp, small, scalars;
@@ -83,7 +83,6 @@ int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);
 int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len);  // text_build.hip
 int fbg_suffix_sort(fbg_ctx *ctx);                                            // suffix_sort.hip
 int fbg_neighbour_lcp(fbg_ctx *ctx);                                          // lcp.hip
-int fbg_tile_columns(fbg_ctx *ctx);                                           // tile.hip
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
                      uint64_t *d_out);                                        // scan.hip
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,

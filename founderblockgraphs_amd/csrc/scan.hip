@@ -8,39 +8,122 @@
 //   * for a member r of the run, depth(parent(exclusive ancestor)) (fbg.cpp:1656) equals
 //         max( min(LCP[lb..r]), min(LCP[r+1..rb+1]) )
 //     and g = that + 1 is how far row i must be extended to the right of x.
-// One workgroup owns one column at a time.  Its m (rank, lcp-prev, lcp-next) triples are one
-// contiguous run of the column-tiled tables (tile.hip).  Runs are found without sorting: the ranks
-// go into an LDS hash set, each member looks up rank-1 / rank+1, and the two running minima are
-// propagated along the run by pointer jumping (log2(run length) rounds, skipped entirely when the
-// column has no two consecutive ranks -- the common case on dissimilar rows).
+//
+// Input is the record array of suffix_sort.hip / lcp.hip: rec[p] = {rank, LCP[rank] | hint, LCP[rank+1] |
+// hint, -} per text position, the hint bit saying "my SA neighbour may be coloured in my column".
+//
+//   k_scan_stream      one THREAD per column, lanes along x: for row i the wave reads 64 consecutive
+//                      records (1 KiB, fully coalesced -- row-major MSA order IS text order), so the whole
+//                      scan is one pass over the records at HBM rate.  A column without any hint has only
+//                      runs of length one, where the two minima are the record's own two LCPs: done.
+//                      Columns with a hint are appended to an exception list instead of being written.
+//   k_scan_exceptions  one WORKGROUP per listed column: the m ranks go into an LDS hash set, every member
+//                      looks up rank-1 / rank+1, and the two running minima are propagated along the runs by
+//                      pointer jumping (log2(run length) rounds).  No sorting.
 #include "fbg_internal.h"
+#include "text_cmp.h"
 
+#define ST_THREADS 256
 #define SC_THREADS 256
 #define SC_MAX_RPT 16            // rows per thread: m <= SC_THREADS * SC_MAX_RPT = 4096
 #define SC_EMPTY 0xffffffffu
 #define SC_NONE 0xffffu
 
 struct ScanArgs {
-    const uint32_t *RT, *PLT, *PRT, *PT, *IGT;  // column-tiled tables (PT, IGT optional)
-    const uint32_t *pos, *tot, *colT;          // per-row / per-text-position tables
+    const uint4 *rec;
+    const uint32_t *prow, *igrow;               // row-major per-cell tables (gapped / ignore chars), optional
+    const uint32_t *pos, *tot, *colT;           // per-row / per-text-position tables
     uint64_t m, n, N;
-    uint32_t mp;
-    uint32_t H, logH;                          // hash slots (power of two >= 2m)
-    int mode, disable_tricks;
+    int mode, disable_tricks, reversed;
     uint64_t x0, x1;
     uint64_t *out;
+    uint32_t *xlist;                            // exception columns
+    unsigned long long *xcount;
+    uint32_t H, logH;                           // hash slots (power of two >= 2m)
 };
+
+// text pointer of cell (i, x): pos_i + rank_i(x)  (fbg.cpp:1596-1600,1687-1691)
+__device__ __forceinline__ uint32_t cell_ptr(const ScanArgs &a, uint64_t i, uint64_t x)
+{
+    if (a.prow) return a.prow[i * a.n + x];
+    return (uint32_t)(i * (a.n + 1) + (a.reversed ? a.n - 1 - x : x));
+}
+
+// fi of one active row for extension g (fbg.cpp:1656-1672)
+__device__ __forceinline__ unsigned long long row_extent(const ScanArgs &a, uint64_t i, uint64_t x, uint32_t p,
+                                                         unsigned long long g)
+{
+    unsigned long long fi;
+    if (a.prow) {
+        const uint32_t p0 = a.pos[i], tt = a.tot[i];
+        const unsigned long long gg = (unsigned long long)(p - p0) + g;              // 1657
+        if (gg > tt) fi = a.disable_tricks ? a.n : a.colT[p0 + tt - 1];              // 1659-1664
+        else fi = a.colT[p0 + gg - 1];                                               // 1666
+    } else {
+        const unsigned long long gg = x + g;
+        if (gg > a.n) fi = a.disable_tricks ? a.n : a.n - 1;
+        else fi = gg - 1;
+    }
+    if (a.igrow) {                                                                   // 1669-1670
+        const uint32_t ig = a.igrow[i * a.n + x];
+        if (ig < a.n) fi = min(fi, (unsigned long long)ig);
+    }
+    return fi;
+}
+
+__device__ __forceinline__ bool row_active(const ScanArgs &a, uint64_t i, uint64_t x, uint32_t p)
+{
+    if (a.mode != FBG_SCAN_F || a.disable_tricks) return true;
+    // fullrow[i] (fbg.cpp:1605-1608,1621): row i has not emitted a character yet
+    return a.prow ? p != a.pos[i] : x != 0;
+}
+
+__device__ __forceinline__ void write_column(const ScanArgs &a, uint64_t x, unsigned long long best)
+{
+    if (a.mode == FBG_SCAN_V) {
+        // v[j] = j+1-L when the block [v..j] fits in the row, else j+1
+        a.out[x] = best <= x + 1 ? x + 1 - best : x + 1;
+    } else {
+        const unsigned long long fx = max((unsigned long long)x, best);              // fbg.cpp:1618
+        a.out[x] = max((unsigned long long)a.out[x], fx);                            // fbg.cpp:1681
+    }
+}
+
+__global__ __launch_bounds__(ST_THREADS) void k_scan_stream(ScanArgs a)
+{
+    const uint64_t x = a.x0 + (uint64_t)blockIdx.x * ST_THREADS + threadIdx.x;
+    if (x >= a.x1) return;
+    unsigned long long best = 0;
+    uint32_t hint = 0;
+    const uint64_t m = a.m;
+#pragma unroll 4
+    for (uint64_t i = 0; i < m; i++) {
+        const uint32_t p = cell_ptr(a, i, x);
+        const uint4 r = a.rec[p];
+        if (!row_active(a, i, x, p)) continue;
+        hint |= r.y | r.z;
+        const unsigned long long g = (unsigned long long)max(r.y & FBG_LCP_MASK, r.z & FBG_LCP_MASK) + 1;   // 1656
+        best = max(best, a.mode == FBG_SCAN_V ? g : row_extent(a, i, x, p, g));
+    }
+    if (hint & 0x80000000u) {
+        const unsigned long long slot = atomicAdd(a.xcount, 1ull);
+        a.xlist[slot] = (uint32_t)x;
+    } else {
+        write_column(a, x, best);
+    }
+}
 
 __device__ __forceinline__ uint32_t sc_hash(uint32_t r, uint32_t logH) { return (r * 2654435761u) >> (32 - logH); }
 
-__global__ __launch_bounds__(SC_THREADS) void k_scan_columns(ScanArgs a)
+__global__ __launch_bounds__(SC_THREADS) void k_scan_exceptions(ScanArgs a, uint64_t ncols)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *hkey = reinterpret_cast<uint32_t *>(smem);          // H
     uint32_t *rk = hkey + a.H;                                    // m   rank (SC_EMPTY = inactive row)
     uint32_t *vL = rk + a.m;                                      // m   running min towards the run head
     uint32_t *vR = vL + a.m;                                      // m   running min towards the run tail
-    uint16_t *hrow = reinterpret_cast<uint16_t *>(vR + a.m);      // H
+    uint32_t *pp = vR + a.m;                                      // m   text pointer of the row
+    uint16_t *hrow = reinterpret_cast<uint16_t *>(pp + a.m);      // H
     uint16_t *ptrL = hrow + a.H;                                  // m
     uint16_t *ptrR = ptrL + a.m;                                  // m
     __shared__ unsigned long long red[SC_THREADS / 64];
@@ -48,23 +131,20 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_columns(ScanArgs a)
     const uint32_t tid = threadIdx.x, Hm = a.H - 1;
     const uint32_t m = (uint32_t)a.m;
 
-    for (uint64_t x = a.x0 + blockIdx.x; x < a.x1; x += gridDim.x) {
-        const uint64_t colbase = x * a.mp;
+    for (uint64_t c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const uint64_t x = a.xlist[c];
         for (uint32_t s = tid; s < a.H; s += SC_THREADS) hkey[s] = SC_EMPTY;
         __syncthreads();
 
         // ---- load the column, colour the active rows, insert their ranks -------------------
         for (uint32_t i = tid; i < m; i += SC_THREADS) {
-            uint32_t r = a.RT[colbase + i];
-            bool active = true;
-            if (a.mode == FBG_SCAN_F && !a.disable_tricks) {
-                // fullrow[i] (fbg.cpp:1605-1608,1621): row i has not emitted a character yet
-                uint32_t nz = a.PT ? a.PT[colbase + i] - a.pos[i] : (uint32_t)x;
-                active = nz != 0;
-            }
-            vL[i] = a.PLT[colbase + i];
-            vR[i] = a.PRT[colbase + i];
-            if (active) {
+            const uint32_t p = cell_ptr(a, i, x);
+            const uint4 r4 = a.rec[p];
+            uint32_t r = r4.x;
+            vL[i] = r4.y & FBG_LCP_MASK;
+            vR[i] = r4.z & FBG_LCP_MASK;
+            pp[i] = p;
+            if (row_active(a, i, x, p)) {
                 uint32_t s = sc_hash(r, a.logH);
                 for (;;) {
                     uint32_t prev = atomicCAS(&hkey[s], SC_EMPTY, r);
@@ -142,39 +222,14 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_columns(ScanArgs a)
         for (uint32_t i = tid; i < m; i += SC_THREADS) {
             if (rk[i] == SC_EMPTY) continue;
             const unsigned long long g = (unsigned long long)max(vL[i], vR[i]) + 1;   // fbg.cpp:1656
-            if (a.mode == FBG_SCAN_V) {
-                best = max(best, g);
-            } else {
-                unsigned long long fi;
-                if (a.PT) {
-                    const uint32_t p = a.PT[colbase + i], p0 = a.pos[i], tt = a.tot[i];
-                    const unsigned long long gg = (unsigned long long)(p - p0) + g;   // fbg.cpp:1657
-                    if (gg > tt) fi = a.disable_tricks ? a.n : a.colT[p0 + tt - 1];   // 1659-1664
-                    else fi = a.colT[p0 + gg - 1];                                    // 1666
-                } else {
-                    const unsigned long long gg = x + g;
-                    if (gg > a.n) fi = a.disable_tricks ? a.n : a.n - 1;
-                    else fi = gg - 1;
-                }
-                if (a.IGT) {                                                          // 1669-1670
-                    const uint32_t ig = a.IGT[colbase + i];
-                    if (ig < a.n) fi = min(fi, (unsigned long long)ig);
-                }
-                best = max(best, fi);
-            }
+            best = max(best, a.mode == FBG_SCAN_V ? g : row_extent(a, i, x, pp[i], g));
         }
         for (int d = 32; d >= 1; d >>= 1) best = max(best, (unsigned long long)__shfl_down(best, d, 64));
         if ((tid & 63) == 0) red[tid >> 6] = best;
         __syncthreads();
         if (tid == 0) {
             for (int k = 1; k < SC_THREADS / 64; k++) best = max(best, red[k]);
-            if (a.mode == FBG_SCAN_V) {
-                // v[j] = j+1-L when the block [v..j] fits in the row, else j+1
-                a.out[x] = best <= x + 1 ? x + 1 - best : x + 1;
-            } else {
-                unsigned long long fx = max((unsigned long long)x, best);             // fbg.cpp:1618
-                a.out[x] = max((unsigned long long)a.out[x], fx);                     // fbg.cpp:1681
-            }
+            write_column(a, x, best);
         }
         __syncthreads();
     }
@@ -186,27 +241,39 @@ int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disab
         return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel supports m <= %d rows (got %llu)", SC_THREADS * SC_MAX_RPT,
                         (unsigned long long)ctx->m);
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SCAN));
+    int launches = 0;
     if (x1 > x0) {
+        hipStream_t st = ctx->stream;
+        FBG_TRY(fbg_reserve(ctx, ctx->xlist, (ctx->n + 1) * 4));
+        unsigned long long *xcount = ctx->scalars.as<unsigned long long>() + 24;
+        FBG_HIP_TRY(ctx, hipMemsetAsync(xcount, 0, sizeof(unsigned long long), st));
         ScanArgs a;
-        a.RT = ctx->RT.as<uint32_t>(); a.PLT = ctx->PLT.as<uint32_t>(); a.PRT = ctx->PRT.as<uint32_t>();
-        a.PT = ctx->gapfree ? nullptr : ctx->PT.as<uint32_t>();
-        a.IGT = (mode == FBG_SCAN_F && ctx->have_ignore) ? ctx->IGT.as<uint32_t>() : nullptr;
+        a.rec = ctx->rec.as<uint4>();
+        a.prow = ctx->gapfree ? nullptr : ctx->prow.as<uint32_t>();
+        a.igrow = (mode == FBG_SCAN_F && ctx->have_ignore) ? ctx->igrow.as<uint32_t>() : nullptr;
         a.pos = ctx->pos.as<uint32_t>(); a.tot = ctx->tot.as<uint32_t>();
         a.colT = ctx->gapfree ? nullptr : ctx->colT.as<uint32_t>();
-        a.m = ctx->m; a.n = ctx->n; a.N = ctx->N; a.mp = ctx->mp;
+        a.m = ctx->m; a.n = ctx->n; a.N = ctx->N;
+        a.mode = mode; a.disable_tricks = disable_tricks; a.reversed = ctx->reversed;
+        a.x0 = x0; a.x1 = x1; a.out = d_out;
+        a.xlist = ctx->xlist.as<uint32_t>(); a.xcount = xcount;
         uint32_t logH = 7;
         while ((1u << logH) < 2 * ctx->m) logH++;
         a.H = 1u << logH; a.logH = logH;
-        a.mode = mode; a.disable_tricks = disable_tricks;
-        a.x0 = x0; a.x1 = x1; a.out = d_out;
-        const size_t lds = (size_t)a.H * 6 + (size_t)a.m * 16;
-        if (lds > 150 * 1024) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel LDS budget exceeded (%zu bytes)", lds);
-        if (lds > 64 * 1024)
-            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_scan_columns, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // enough workgroups to fill 256 CUs several times over; each strides over columns
-        unsigned blocks = fbg_blocks(x1 - x0, 1, 256 * 8);
-        hipLaunchKernelGGL(k_scan_columns, dim3(blocks), dim3(SC_THREADS), lds, ctx->stream, a);
+        hipLaunchKernelGGL(k_scan_stream, dim3(fbg_blocks(x1 - x0, ST_THREADS)), dim3(ST_THREADS), 0, st, a);
+        launches++;
+        unsigned long long nx = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&nx, xcount, sizeof(nx), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (nx > 0) {
+            const size_t lds = (size_t)a.H * 6 + (size_t)a.m * 20;
+            if (lds > 150 * 1024) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel LDS budget exceeded (%zu bytes)", lds);
+            if (lds > 64 * 1024)
+                FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_scan_exceptions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_scan_exceptions, dim3(fbg_blocks(nx, 1, 256 * 8)), dim3(SC_THREADS), lds, st, a, (uint64_t)nx);
+            launches++;
+        }
         FBG_HIP_TRY(ctx, hipGetLastError());
     }
-    return fbg_stage_end(ctx, FBG_STAGE_SCAN, x1 > x0 ? 1 : 0);
+    return fbg_stage_end(ctx, FBG_STAGE_SCAN, launches);
 }

@@ -11,7 +11,17 @@
 // rank[p] is always the SA index of the first member of p's group, so it is final as soon as the
 // group is a singleton.  Device-wide sort / scan / select primitives come from rocPRIM; the key
 // packing, grouping and doubling kernels are this file's.
+//
+// Ranks live in a 16-byte record per text position, rec[p] = {rank, lcp_prev, lcp_next, 0}, so that the
+// one unavoidable random scatter of the sort (SA order -> text order) also delivers the two neighbour
+// LCPs the scan needs: for suffixes whose round-0 keys differ the LCP is the number of equal leading
+// symbols of the two keys -- no text access.  Bit 31 of an LCP word is the run hint: the SA neighbour
+// sits in the same MSA column, i.e. the two ranks can be coloured together (fbg.cpp:1633-1641).
+// Suffixes that tie on their whole key (round-0 groups) are patched after the last doubling round
+// (k_fix_dirty: text comparison from symbol K on).  When ties are common (similar rows) or the MSA has
+// gaps, lcp.hip recomputes both LCP words for every position instead.
 #include "fbg_internal.h"
+#include "text_cmp.h"
 #include <rocprim/rocprim.hpp>
 
 #define SS_THREADS 256
@@ -64,21 +74,99 @@ __global__ void k_mark_heads(const uint64_t *__restrict__ keys, uint64_t cnt, co
     grp[k] = head ? r : 0u;
 }
 
-// after the max-scan: scatter ranks, flag members of groups with more than one element
+// number of equal leading symbols of two K-symbol keys (b bits per symbol, right aligned in key_bits)
+__device__ __forceinline__ uint32_t key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
+{
+    const uint64_t d = a ^ c;
+    return (uint32_t)((__clzll((long long)d) - (64 - key_bits)) / b);
+}
+
+struct ColTest {          // "same MSA column" for gap-free MSAs: positions p, q with equal p mod (n+1)
+    uint64_t row_len;     // n + 1 ; 0 = test disabled (MSA with gaps: lcp.hip computes the hints)
+    uint64_t last;        // N - 1, the sentinel, never a row pointer
+    __device__ __forceinline__ uint32_t same(uint32_t p, uint32_t q) const
+    {
+        if (row_len == 0 || p == last || q == last) return 0;
+        const uint32_t d = (uint32_t)row_len;
+        return (p % d) == (q % d) ? 0x80000000u : 0u;
+    }
+};
+
+// round 0, after the max-scan: one 16-byte record per text position (rank, key-derived neighbour LCPs
+// with run hints), unresolved flags.  vals[] doubles as the suffix array.
+__global__ void k_apply_groups0(const uint32_t *__restrict__ grp, const uint32_t *__restrict__ vals,
+                                const uint64_t *__restrict__ keys, uint64_t N, int b, int key_bits, ColTest ct,
+                                uint4 *__restrict__ rec, uint8_t *__restrict__ flags)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t g = grp[k], p = vals[k];
+    const uint64_t key = keys[k];
+    uint32_t lp = 0, ln = 0;
+    bool head = g == (uint32_t)k, next_head = true;
+    if (k > 0) {
+        const uint64_t kp = keys[k - 1];
+        if (kp != key) lp = key_lcp(kp, key, b, key_bits) | ct.same(vals[k - 1], p);
+    }
+    if (k + 1 < N) {
+        const uint64_t kn = keys[k + 1];
+        next_head = kn != key;
+        if (next_head) ln = key_lcp(key, kn, b, key_bits) | ct.same(p, vals[k + 1]);
+    }
+    rec[p] = make_uint4(g, lp, ln, 0u);
+    flags[k] = !(head && next_head);
+}
+
+// doubling rounds: new group heads -> rank word of the records, suffix array slots, unresolved flags
 __global__ void k_apply_groups(const uint32_t *__restrict__ grp, const uint32_t *__restrict__ vals, uint64_t cnt,
-                               const uint32_t *__restrict__ where, uint32_t *__restrict__ rank,
+                               const uint32_t *__restrict__ where, uint4 *__restrict__ rec,
                                uint32_t *__restrict__ sa, uint8_t *__restrict__ flags)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= cnt) return;
-    uint32_t r = where ? where[k] : (uint32_t)k;
-    uint32_t g = grp[k];
-    uint32_t p = vals[k];
-    rank[p] = g;
-    if (sa) sa[r] = p;
-    bool head = g == r;
-    bool next_head = (k + 1 == cnt) || (grp[k + 1] == (where ? where[k + 1] : (uint32_t)(k + 1)));
+    const uint32_t r = where[k], g = grp[k], p = vals[k];
+    rec[p].x = g;
+    sa[r] = p;
+    const bool head = g == r;
+    const bool next_head = (k + 1 == cnt) || (grp[k + 1] == where[k + 1]);
     flags[k] = !(head && next_head);
+}
+
+// After the last round: members of round-0 tie groups get their final neighbour LCPs and hints.
+// dirty[] = SA indices of those members.  A neighbour with a different round-0 key keeps its key-derived
+// LCP, but its hint depends on who finally sits next to it, so that word is rewritten from here too
+// (both sides compute the identical word).
+__global__ void k_fix_dirty(const uint32_t *__restrict__ dirty, uint64_t cnt, const uint32_t *__restrict__ sa,
+                            const uint64_t *__restrict__ key0, const uint8_t *__restrict__ T, uint64_t N, int b,
+                            int key_bits, int K, ColTest ct, uint4 *__restrict__ rec)
+{
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t r = dirty[k], p = sa[r];
+    const uint64_t key = key0[r];
+    uint32_t lp = 0, ln = 0;
+    if (r > 0) {
+        const uint32_t q = sa[r - 1];
+        const uint64_t kq = key0[r - 1];
+        if (kq == key) {
+            lp = fbg_clamp_lcp(fbg_extend_match(T, (uint64_t)q + K, (uint64_t)p + K, 0) + (uint32_t)K) | ct.same(q, p);
+        } else {
+            lp = key_lcp(kq, key, b, key_bits) | ct.same(q, p);
+            rec[q].z = lp;
+        }
+    }
+    if ((uint64_t)r + 1 < N) {
+        const uint32_t q = sa[r + 1];
+        const uint64_t kq = key0[r + 1];
+        if (kq == key) {
+            ln = fbg_clamp_lcp(fbg_extend_match(T, (uint64_t)p + K, (uint64_t)q + K, 0) + (uint32_t)K) | ct.same(p, q);
+        } else {
+            ln = key_lcp(key, kq, b, key_bits) | ct.same(p, q);
+            rec[q].y = ln;
+        }
+    }
+    rec[p].y = lp;
+    rec[p].z = ln;
 }
 
 struct KeepIdx { uint32_t r, p, g; };
@@ -99,13 +187,13 @@ __global__ void k_gather_unresolved(const uint32_t *__restrict__ sel, uint64_t c
 
 // key = (group head, rank of the suffix h further on)
 __global__ void k_doubling_keys(const uint32_t *__restrict__ vals, const uint32_t *__restrict__ grp, uint64_t cnt,
-                                const uint32_t *__restrict__ rank, uint64_t h, uint64_t N,
+                                const uint4 *__restrict__ rec, uint64_t h, uint64_t N,
                                 uint64_t *__restrict__ keys)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= cnt) return;
     uint64_t q = (uint64_t)vals[k] + h;
-    uint32_t r2 = q < N ? rank[q] : 0u;   // q < N always holds for unresolved suffixes (unique sentinel)
+    uint32_t r2 = q < N ? rec[q].x : 0u;   // q < N always holds for unresolved suffixes (unique sentinel)
     keys[k] = ((uint64_t)grp[k] << 32) | r2;
 }
 
@@ -165,13 +253,18 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     FBG_TRY(fbg_reserve(ctx, ctx->valsB, N * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->flags, N));
-    FBG_TRY(fbg_reserve(ctx, ctx->sa, N * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->isa, N * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->rec, N * 16));
     uint64_t *keysA = ctx->keysA.as<uint64_t>(), *keysB = ctx->keysB.as<uint64_t>();
     uint32_t *valsA = ctx->valsA.as<uint32_t>(), *valsB = ctx->valsB.as<uint32_t>();
-    uint32_t *grp = ctx->grp.as<uint32_t>(), *rank = ctx->isa.as<uint32_t>(), *sa = ctx->sa.as<uint32_t>();
+    uint32_t *grp = ctx->grp.as<uint32_t>();
+    uint4 *rec = ctx->rec.as<uint4>();
     uint8_t *flags = ctx->flags.as<uint8_t>();
     unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
+    uint32_t *sa = valsB;                     // the sorted positions ARE the suffix array
+    ctx->sa_ptr = sa;
+    ColTest ct;
+    ct.row_len = ctx->gapfree ? ctx->n + 1 : 0;
+    ct.last = N - 1;
 
     hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
                        keysA, valsA);
@@ -179,13 +272,13 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
         return rocprim::radix_sort_pairs(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, 0u, (unsigned)key_bits, st);
     }));
-    // groups of equal keys -> rank (= SA index of the group head), SA, unresolved flags
+    // groups of equal keys -> records (rank = SA index of the group head, key-derived LCPs), unresolved flags
     hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keysB, N, (const uint32_t *)nullptr, grp);
     FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
         return rocprim::inclusive_scan(tmp, bytes, grp, grp, (size_t)N, rocprim::maximum<uint32_t>(), st);
     }));
-    hipLaunchKernelGGL(k_apply_groups, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, grp, valsB, N,
-                       (const uint32_t *)nullptr, rank, sa, flags);
+    hipLaunchKernelGGL(k_apply_groups0, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, grp, valsB, keysB, N, b, key_bits,
+                       ct, rec, flags);
     launches += 4;
 
     // ---- doubling rounds on the unresolved suffixes ----------------------------------------
@@ -193,12 +286,14 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     uint64_t cnt = N;
     const uint32_t *where_cur = nullptr;      // nullptr = identity (round 0)
     uint32_t *vals_cur = valsB, *grp_cur = grp;
-    // ping-pong storage for the compacted lists
     FBG_TRY(fbg_reserve(ctx, ctx->list, N * 4));
     uint32_t *sel = ctx->list.as<uint32_t>();
     DevBuf *wbuf[2] = {&ctx->dp_a, &ctx->dp_b}, *vbuf[2] = {&ctx->dp_c, &ctx->dp_d}, *gbuf[2] = {&ctx->dp_e, &ctx->dp_f};
     int pp = 0;
     uint64_t h = (uint64_t)K;
+    uint64_t dirty_cnt = 0;
+    ctx->lcp_from_keys = false;
+    uint64_t *dkeys_in = keysA, *dkeys_out = nullptr;
     for (int round = 1;; round++) {
         // select unresolved members of the current list
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
@@ -208,8 +303,23 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         FBG_HIP_TRY(ctx, hipMemcpyAsync(&hc, d_count, sizeof(hc), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         launches += 1;
+        if (round == 1) {
+            // few ties and no gaps: the key-derived LCPs stand, only the tie groups are patched afterwards;
+            // the round-0 keys (keysB) must then survive the doubling rounds
+            ctx->lcp_from_keys = ctx->gapfree && hc <= N / 32 && !getenv("FBG_LCP_TEXT");
+            if (ctx->lcp_from_keys && hc > 0) {
+                dirty_cnt = hc;
+                FBG_TRY(fbg_reserve(ctx, ctx->io_d, hc * 4));
+                FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_d.p, sel, hc * 4, hipMemcpyDeviceToDevice, st));
+                FBG_TRY(fbg_reserve(ctx, ctx->dp_g, hc * 8));
+                FBG_TRY(fbg_reserve(ctx, ctx->dp_h, hc * 8));
+                dkeys_in = ctx->dp_g.as<uint64_t>();
+                dkeys_out = ctx->dp_h.as<uint64_t>();
+            }
+        }
         if (hc == 0) break;
         if (round > 64) return fbg_fail(ctx, FBG_ERR_HIP, "suffix sort did not converge");
+        if (!dkeys_out) dkeys_out = keysB;
         const uint64_t ncnt = hc;
         FBG_TRY(fbg_reserve(ctx, *wbuf[pp], ncnt * 4));
         FBG_TRY(fbg_reserve(ctx, *vbuf[pp], ncnt * 4));
@@ -219,17 +329,17 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         hipLaunchKernelGGL(k_gather_unresolved, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, sel, ncnt, where_cur,
                            vals_cur, grp_cur, where_new, vals_new, grp_new);
         hipLaunchKernelGGL(k_doubling_keys, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, vals_new, grp_new, ncnt,
-                           rank, h, N, keysA);
+                           rec, h, N, dkeys_in);
         // sort by (group, rank at +h); the sorted positions go back to the same SA slots
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_pairs(tmp, bytes, keysA, keysB, vals_new, valsA, (size_t)ncnt, 0u, 64u, st);
+            return rocprim::radix_sort_pairs(tmp, bytes, dkeys_in, dkeys_out, vals_new, valsA, (size_t)ncnt, 0u, 64u, st);
         }));
-        hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, keysB, ncnt, where_new, grp_new);
+        hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, dkeys_out, ncnt, where_new, grp_new);
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
             return rocprim::inclusive_scan(tmp, bytes, grp_new, grp_new, (size_t)ncnt, rocprim::maximum<uint32_t>(), st);
         }));
         hipLaunchKernelGGL(k_apply_groups, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, grp_new, valsA, ncnt,
-                           where_new, rank, sa, flags);
+                           where_new, rec, sa, flags);
         // the sorted positions become the list's values for the next round
         FBG_HIP_TRY(ctx, hipMemcpyAsync(vals_new, valsA, ncnt * 4, hipMemcpyDeviceToDevice, st));
         launches += 7;
@@ -237,6 +347,11 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         cnt = ncnt;
         pp ^= 1;
         h *= 2;
+    }
+    if (ctx->lcp_from_keys && dirty_cnt > 0) {
+        hipLaunchKernelGGL(k_fix_dirty, dim3(fbg_blocks(dirty_cnt, 256)), dim3(256), 0, st, ctx->io_d.as<uint32_t>(),
+                           dirty_cnt, sa, keysB, T, N, b, key_bits, K, ct, rec);
+        launches += 1;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
     return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);

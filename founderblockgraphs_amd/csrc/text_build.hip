@@ -235,6 +235,11 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
                            pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr);
     }
     launches++;
+    if (!ctx->gapfree) {   // the sentinel has no column: same marker as '#'
+        const uint32_t nn = (uint32_t)n;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->colT.as<uint32_t>() + (ctx->N - 1), &nn, 4, hipMemcpyHostToDevice, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
     if (ctx->have_ignore) {
         FBG_TRY(fbg_reserve(ctx, ctx->igrow, m * n * 4));
         hipLaunchKernelGGL(k_ignore_sweep, dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,

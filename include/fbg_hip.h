@@ -49,7 +49,7 @@ enum {
     FBG_STAGE_TEXT = 0,      /* MSA -> gap-stripped text + per-row tables (fbg.cpp:372-386,1845-1917) */
     FBG_STAGE_SUFFIX_SORT,   /* suffix array + inverse (sdsl::construct, fbg.cpp:428) */
     FBG_STAGE_LCP,           /* per-position LCP with SA predecessor / successor */
-    FBG_STAGE_TILE,          /* column-tiled rank/LCP tables */
+    FBG_STAGE_TILE,          /* (unused since the record layout: always 0) */
     FBG_STAGE_SCAN,          /* compute_f / v[] column scan (fbg.cpp:1579-1695, 552-611) */
     FBG_STAGE_DP,            /* bucket pass + DP sweep + backtrack (fbg.cpp:1940-2039, 616-664) */
     FBG_STAGE_COUNT
