@@ -191,6 +191,145 @@ __global__ __launch_bounds__(64) void k_dp_wave(const uint32_t *__restrict__ bst
     if (minLs < 1 && lane == 0) flag[4] = 1;
 }
 
+// ---- tiled sweep: 8 steps per iteration (block lengths < 64) ---------------------------------------
+//
+// Same recurrence as k_dp_wave, arranged so that one wave instruction works on 8 steps x 8 candidates:
+//     minmaxlength[j] = min over candidates x < j with f[x]+1 <= j of max(minmaxlength[x], j - x).
+// A chunk of c <= 8 consecutive steps j..j+c-1 can be evaluated together when no column inside the chunk
+// is itself a usable candidate inside it, i.e. f[x]+1 >= j+c for every x >= j (clen[], precomputed).
+// Lane (t, c8) scores candidates of age 8*c8+1 .. 8*c8+8 (relative to j) for step j+t; the eight partial
+// minima of a step are combined with three DPP row operations.  The reference's tie-breaking is folded
+// into the key: cost*128 + 0 for a candidate of its "S" kind (age > minmaxlength[x], fbg.cpp:1985-1989,
+// 1996-1999), cost*128 + 1 + age for its count_solutions kind (youngest first = backtrack_count's
+// largest x, fbg.cpp:1976-1981); S wins ties like the strict `I < S` (fbg.cpp:2004).
+// The last 64 columns' (extension, minmaxlength) pairs live in an LDS ring; ages beyond 64 cannot win
+// because minmaxlength <= 63 here (checked: a step without a feasible candidate raises the flag).
+#define DPT_BIG 0xffffu
+
+__global__ void k_dp_prep(const uint32_t *__restrict__ e, uint32_t n, uint8_t *__restrict__ ext7,
+                          uint8_t *__restrict__ clen)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    ext7[j] = j < n ? (uint8_t)min(e[j] - j, 127u) : (uint8_t)127;
+    uint32_t c = 8;
+    for (uint32_t s = 0; s < 8 && j + s < n; s++) c = min(c, e[j + s] - j);   // e[j+s] - j >= s + 1 >= 1
+    clen[j] = (uint8_t)c;
+}
+
+__device__ __forceinline__ uint32_t dpp_min8(uint32_t v)
+{
+    // minimum over each group of 8 consecutive lanes (half a DPP row)
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_dp_tile(const uint8_t *__restrict__ ext7, const uint8_t *__restrict__ clen,
+                                                uint32_t n, uint32_t *__restrict__ mml, uint32_t *__restrict__ bt,
+                                                unsigned long long *__restrict__ flag)
+{
+    __shared__ uint16_t ring[64];            // (extension << 7) | minmaxlength of column (x & 63)
+    __shared__ uint8_t s_ext[DPW + 16], s_len[DPW + 16];
+    const uint32_t lane = threadIdx.x, t = lane >> 3, c8 = lane & 7;
+    ring[lane] = (uint16_t)(127u << 7);      // columns < 0 do not exist: never valid
+    if (lane == 0) { mml[0] = 0; bt[0] = 0; }
+    uint32_t wbase = 0xffffffffu, j = 1;
+    uint32_t bad = 0;
+    while (j <= n) {
+        if (wbase == 0xffffffffu || j + 8 > wbase + DPW) {           // stage the next window of inputs
+            __syncthreads();
+            wbase = j;
+            for (uint32_t k = lane; k < DPW + 8; k += 64) {
+                const uint32_t x = wbase + k;
+                s_ext[k] = x <= n ? ext7[x] : (uint8_t)127;
+                s_len[k] = x <= n ? clen[x] : (uint8_t)1;
+            }
+            if (j == 1 && lane == 0) ring[0] = (uint16_t)(((uint32_t)ext7[0] << 7) | 0u);   // column 0, minmaxlength 0
+            __syncthreads();
+        }
+        uint32_t cl = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_len[j - wbase]);
+        cl = min(cl, n - j + 1);
+        uint32_t best = DPT_BIG;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t a0 = 1 + 8 * c8 + u;                      // age of the candidate at step j
+            const uint32_t pk = ring[(j - a0) & 63];
+            const uint32_t v = pk & 127u, ext = pk >> 7;
+            const uint32_t age = a0 + t;                             // its age at this lane's step j + t
+            const uint32_t key = (max(v, age) << 7) | (age > v ? 0u : age + 1);
+            best = min(best, ext <= age ? key : DPT_BIG);
+        }
+        best = dpp_min8(best);
+        const uint32_t jt = j + t;
+        const uint32_t cost = best >> 7, tb = best & 127u;
+        const uint32_t back = tb == 0 ? jt - cost : jt - (tb - 1);
+        const bool live = t < cl;
+        bad |= (live && best == DPT_BIG) ? 1u : 0u;
+        if (live && c8 == 0) {
+            mml[jt] = cost;
+            bt[jt] = back;
+            if (jt < n) ring[jt & 63] = (uint16_t)(((uint32_t)s_ext[jt - wbase] << 7) | (cost & 127u));
+        }
+        j += cl;
+    }
+    if (__ballot(bad != 0) && lane == 0) flag[4] = 1;
+}
+
+// backtrack (fbg.cpp:2026-2039) for block lengths < 64: walks backtrack[] backwards through two
+// register-resident 64-column windows (current and the prefetched previous one); the boundaries are
+// collected in reverse in LDS and flushed 1024 at a time.  rev[] receives them, result[0] the count.
+__global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__restrict__ bt, uint32_t n,
+                                                          uint32_t *__restrict__ rev,
+                                                          unsigned long long *__restrict__ result)
+{
+    __shared__ uint32_t obuf[1024];
+    const uint32_t lane = threadIdx.x;
+    uint32_t j = n, cnt = 0, flushed = 0;
+    uint32_t blk = j >> 6;
+    uint32_t cur = blk * 64 + lane <= n ? bt[blk * 64 + lane] : 0;
+    uint32_t prv = blk > 0 ? bt[(blk - 1) * 64 + lane] : 0;
+    if (lane == 0) obuf[0] = n;
+    cnt = 1;
+    bool err = false;
+    for (;;) {
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(j & 63));
+        if (b == 0) break;
+        if (b > n || cnt > n + 1) { err = true; break; }
+        if (cnt - flushed == 1024) {
+            __syncthreads();
+            for (uint32_t k = lane; k < 1024; k += 64) rev[flushed + k] = obuf[k];
+            flushed += 1024;
+            __syncthreads();
+        }
+        if (lane == 0) obuf[cnt - flushed] = b - 1;
+        cnt++;
+        j = b;
+        const uint32_t nb = j >> 6;
+        if (nb != blk) {
+            if (nb + 1 == blk) {
+                cur = prv;
+            } else {
+                cur = bt[nb * 64 + lane];
+            }
+            blk = nb;
+            prv = blk > 0 ? bt[(blk - 1) * 64 + lane] : 0;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = lane; k < cnt - flushed; k += 64) rev[flushed + k] = obuf[k];
+    if (lane == 0) { result[0] = err ? 0 : cnt; result[1] = err ? 1 : 0; }
+}
+
+__global__ void k_reverse_widen(const uint32_t *__restrict__ rev, const unsigned long long *__restrict__ result,
+                                uint64_t *__restrict__ boundaries)
+{
+    const unsigned long long cnt = result[0];
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) boundaries[k] = rev[cnt - 1 - k];
+}
+
 // fbg.cpp:2026-2039.  status: 0 ok, 1 = backtrack left the array (reference: out-of-bounds read)
 __global__ void k_dp_backtrack(const uint32_t *__restrict__ bt, uint32_t n, uint64_t *__restrict__ boundaries,
                                unsigned long long *__restrict__ result)
@@ -270,24 +409,40 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 256 ? 4 : bound <= 512 ? 8 : bound <= 1024 ? 16 : 0;
     }
     bool literal = R == 0;
+    bool tiled = false;
     if (!literal) {
-        switch (R) {
-        case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
-        case 2: hipLaunchKernelGGL((k_dp_wave<2>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
-        case 4: hipLaunchKernelGGL((k_dp_wave<4>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
-        case 8: hipLaunchKernelGGL((k_dp_wave<8>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
-        default: hipLaunchKernelGGL((k_dp_wave<16>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+        if (R == 1 && !getenv("FBG_DP_WAVE")) {
+            // block lengths < 64: 8-steps-per-iteration sweep straight from f (no bucket order needed)
+            uint8_t *ext7 = ctx->dp_e.as<uint8_t>(), *clen = ctx->dp_f.as<uint8_t>();
+            hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext7, clen);
+            hipLaunchKernelGGL(k_dp_tile, dim3(1), dim3(64), 0, st, ext7, clen, (uint32_t)n, mml, bt, sc);
+            tiled = true;
+        } else {
+            switch (R) {
+            case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+            case 2: hipLaunchKernelGGL((k_dp_wave<2>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+            case 4: hipLaunchKernelGGL((k_dp_wave<4>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+            case 8: hipLaunchKernelGGL((k_dp_wave<8>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+            default: hipLaunchKernelGGL((k_dp_wave<16>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
+            }
         }
         FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         if (hk[4] != 0) literal = true;   // guard tripped: fall through to the literal sweep
     }
     if (literal) {
+        FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
         FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
         FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
         hipLaunchKernelGGL(k_dp_minmax, dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, count, bcount, cur, tnext, mml, bt);
+        hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
+    } else if (tiled) {
+        hipLaunchKernelGGL(k_dp_backtrack_wave, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, tnext, sc);
+        hipLaunchKernelGGL(k_reverse_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, tnext, sc, d_boundaries);
+    } else {
+        hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
     }
-    hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
     if (d_mml) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, n + 1, d_mml, 0);
     if (d_bt) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, bt, n + 1, d_bt, 1);
     FBG_HIP_TRY(ctx, hipGetLastError());
