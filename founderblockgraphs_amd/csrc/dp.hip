@@ -277,6 +277,106 @@ __global__ __launch_bounds__(64) void k_dp_tile(const uint8_t *__restrict__ ext7
     if (__ballot(bad != 0) && lane == 0) flag[4] = 1;
 }
 
+// ---- block-matrix sweep: the recurrence as a (min,max) matrix chain ----------------------------------
+//
+// minmaxlength[j] = min_x max(minmaxlength[x], j-x) is a product in the (min,max) semiring, so a block of 64
+// steps acts on the 64 values before it through a 64x64 matrix W_b:
+//     minmaxlength[64b+1+t] = min_k max( minmaxlength[64b-63+k], W_b[k][t] ),
+// W_b[k][t] = the smallest achievable longest block over all ways of cutting [64b-63+k, 64b+1+t) into valid
+// blocks (first block starting at the old column, the rest inside the new 64 columns).  Only candidates of
+// age <= 64 are considered, which is exact while minmaxlength <= 63 (flagged otherwise).
+//   k_dp_blockW  builds every W_b independently: one wave per block, lane = old column k, 64 sequential
+//                steps of the same recurrence started from a one-hot state.  Embarrassingly parallel.
+//   k_dp_chain   the only sequential part left: one (min,max) matrix-vector product per block.
+//   k_dp_bt      backtrack[j] from minmaxlength[] alone, one thread per column, with the reference's
+//                tie-breaking (S kind first, else the youngest count_solutions kind; fbg.cpp:1976-2009).
+#define DPB_INF 255u
+
+__global__ __launch_bounds__(64) void k_dp_blockW(const uint8_t *__restrict__ ext7, uint32_t n, uint32_t nblocks,
+                                                  uint8_t *__restrict__ Wt)
+{
+    __shared__ uint8_t wl[64][64];           // wl[t][lane]: W of inside column 64b+1+t for source `lane`
+    __shared__ uint8_t s_ext[64];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const uint32_t jb = 64 * b;
+        const int64_t xs = (int64_t)jb - 63 + lane;                   // this lane's old column
+        const uint32_t ext_src = xs >= 0 ? ext7[xs] : 127u;
+        __syncthreads();
+        s_ext[lane] = jb + 1 + lane < n ? ext7[jb + 1 + lane] : (uint8_t)127;
+        __syncthreads();
+        uint8_t *out = Wt + (size_t)b * 4096;
+        for (uint32_t t = 0; t < 64; t++) {
+            const uint32_t age_src = t + 64 - lane;                   // (64b+1+t) - xs
+            uint32_t w = (ext_src <= age_src && age_src <= 64) ? age_src : DPB_INF;
+            for (uint32_t tp = 0; tp < t; tp++) {
+                const uint32_t age = t - tp;
+                if (s_ext[tp] <= age) w = min(w, max((uint32_t)wl[tp][lane], age));   // uniform test
+            }
+            wl[t][lane] = (uint8_t)w;
+            out[t * 64 + lane] = (uint8_t)w;                          // Wt[b][t][k]
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt, uint32_t n, uint32_t nblocks,
+                                                 uint32_t *__restrict__ mml, unsigned long long *__restrict__ flag)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t S = lane == 63 ? 0u : DPB_INF;                           // state before block 0: only column 0
+    if (lane == 0) mml[0] = 0;
+    uint32_t bad = 0;
+    const uint4 *W4 = reinterpret_cast<const uint4 *>(Wt);
+    uint4 nx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nx[q] = W4[(size_t)lane * 4 + q];     // block 0, row t = lane: 64 bytes
+    for (uint32_t b = 0; b < nblocks; b++) {
+        uint32_t wv[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { wv[4 * q] = nx[q].x; wv[4 * q + 1] = nx[q].y; wv[4 * q + 2] = nx[q].z; wv[4 * q + 3] = nx[q].w; }
+        if (b + 1 < nblocks) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) nx[q] = W4[((size_t)(b + 1) * 64 + lane) * 4 + q];
+        }
+        uint32_t best = DPB_INF;
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)S, k);
+            const uint32_t w = (wv[k >> 2] >> (8 * (k & 3))) & 255u;
+            best = min(best, max(sk, w));
+        }
+        const uint32_t j = 64 * b + 1 + lane;
+        if (j <= n) {
+            mml[j] = best;
+            bad |= best >= 64 ? 1u : 0u;
+        }
+        S = best;
+    }
+    if (__ballot(bad != 0) && lane == 0) flag[4] = 1;
+}
+
+__global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restrict__ ext7, uint32_t n,
+                        uint32_t *__restrict__ bt, unsigned long long *__restrict__ flag)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    if (j == 0) { bt[0] = 0; return; }
+    const uint32_t L = mml[j];
+    uint32_t best_age = 0;                    // youngest count_solutions-kind candidate (age <= its value == L)
+    bool s_kind = false;                      // candidate of age L with a smaller value: the S / backtrack_S branch
+    const uint32_t amax = min(64u, j);
+    for (uint32_t a = 1; a <= amax; a++) {
+        const uint32_t x = j - a;
+        if (ext7[x] > a) continue;            // block [x, j) not valid yet: f[x]+1 > j
+        const uint32_t v = mml[x];
+        if (a > v) { if (a == L) s_kind = true; }
+        else if (v == L && best_age == 0) best_age = a;
+    }
+    if (s_kind) bt[j] = j - L;
+    else if (best_age) bt[j] = j - best_age;
+    else { bt[j] = 0; flag[4] = 1; }
+}
+
 // backtrack (fbg.cpp:2026-2039) for block lengths < 64: walks backtrack[] backwards through two
 // register-resident 64-column windows (current and the prefetched previous one); the boundaries are
 // collected in reverse in LDS and flushed 1024 at a time.  rev[] receives them, result[0] the count.
@@ -412,10 +512,20 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     bool tiled = false;
     if (!literal) {
         if (R == 1 && !getenv("FBG_DP_WAVE")) {
-            // block lengths < 64: 8-steps-per-iteration sweep straight from f (no bucket order needed)
+            // block lengths < 64: sweeps that work straight from f (no bucket order needed)
             uint8_t *ext7 = ctx->dp_e.as<uint8_t>(), *clen = ctx->dp_f.as<uint8_t>();
             hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext7, clen);
-            hipLaunchKernelGGL(k_dp_tile, dim3(1), dim3(64), 0, st, ext7, clen, (uint32_t)n, mml, bt, sc);
+            if (getenv("FBG_DP_TILE")) {
+                hipLaunchKernelGGL(k_dp_tile, dim3(1), dim3(64), 0, st, ext7, clen, (uint32_t)n, mml, bt, sc);
+            } else {
+                const uint32_t nblocks = (uint32_t)((n + 63) / 64);
+                FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * 4096));
+                uint8_t *Wt = ctx->tmp.as<uint8_t>();
+                hipLaunchKernelGGL(k_dp_blockW, dim3(fbg_blocks(nblocks, 1, 256 * 16)), dim3(64), 0, st, ext7, (uint32_t)n,
+                                   nblocks, Wt);
+                hipLaunchKernelGGL(k_dp_chain, dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
+                hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, bt, sc);
+            }
             tiled = true;
         } else {
             switch (R) {
