@@ -12,7 +12,7 @@ fits 32-bit ranks (N<=4) every rank builds the (replicated) index and scans its 
 (SURVEY.md 8e); beyond that (N=8, text 8e9) the exact row-group-pair plan of
 founderblockgraphs_amd/distributed.py is used (one all-reduce(max) instead of the all-gather).
 
-Prints ONE JSON line on rank 0.  `roofline` prices the scan kernel (k_scan_columns): algorithmic
+Prints ONE JSON line on rank 0.  `roofline` prices the scan kernel (k_scan_stream): algorithmic
 bytes = (13*m + 8) per column over its HIP-event duration.  `cpu_baseline` times
 the CPU restatement (oracle/, kind "port") on a bounded column prefix of the same MSA.
 """
@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-cols", type=int, default=40_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-row-pairs", type=int, default=0, help="debug: use the row-group-pair plan with this many rows per pair text")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -90,14 +92,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(1, ndev) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     from founderblockgraphs_amd import distributed as D
     m, n = args.rows, args.cols_per_gpu * world
-    eng = F.Engine(local_rank)
+    eng = F.Engine(dev)
     # one stream for everything: the engine's kernels, torch's fills and the RCCL exchange
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -106,7 +113,7 @@ def main():
     d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     state = {}
-    replicated = m * (n + 1) + 1 < (1 << 32) - 1
+    replicated = m * (n + 1) + 1 < (1 << 32) - 1 and not args.force_row_pairs
     if replicated:
         # column shards of one (replicated) index: SURVEY.md 8e, compute_f_range's partition
         x0, x1 = D.shard_range(n, rank, world)
@@ -124,7 +131,8 @@ def main():
                 state["blocks"] = eng.minmax_dp_device(f_full.data_ptr(), n, d_b.data_ptr())
     else:
         # text too long for 32-bit ranks: exact row-group-pair plan, one all-reduce(max) of f
-        G, groups, plan = D.plan_row_pairs(m, n, world)
+        G, groups, plan = (D.plan_row_pairs(m, n, world, limit=args.force_row_pairs * (n + 1) + 1)
+                           if args.force_row_pairs else D.plan_row_pairs(m, n, world))
         mine = plan[rank]
         rows_pair = max((groups[a][1] - groups[a][0]) + (groups[b][1] - groups[b][0]) for a, b in D.group_pairs(G))
         d_msa = torch.empty(rows_pair * n, dtype=torch.uint8, device="cuda")
@@ -183,7 +191,7 @@ def main():
             "config": {"workload": f"synthetic {m} rows x {n} cols iid ACGT (seed 0x5EED0001), --elastic"
                                    f"{'' if world == 1 else f', {args.cols_per_gpu} columns per GPU, {mode}'}",
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
-            "roofline": {"bound": "hbm", "kernel": "k_scan_columns", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},

@@ -1,0 +1,5 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 1 --warmup 1 --backend gloo --cols-per-gpu 100000 --no-cpu-baseline --force-row-pairs 500 > gpurun_out/mr2p.log 2>&1 || { tail -30 gpurun_out/mr2p.log; exit 1; }
+tail -1 gpurun_out/mr2p.log | cut -c1-700
