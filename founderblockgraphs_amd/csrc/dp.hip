@@ -206,12 +206,12 @@ __global__ __launch_bounds__(64) void k_dp_wave(const uint32_t *__restrict__ bst
 // because minmaxlength <= 63 here (checked: a step without a feasible candidate raises the flag).
 #define DPT_BIG 0xffffu
 
-__global__ void k_dp_prep(const uint32_t *__restrict__ e, uint32_t n, uint8_t *__restrict__ ext7,
+__global__ void k_dp_prep(const uint32_t *__restrict__ e, uint32_t n, uint32_t ext_cap, uint8_t *__restrict__ ext7,
                           uint8_t *__restrict__ clen)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n) return;
-    ext7[j] = j < n ? (uint8_t)min(e[j] - j, 127u) : (uint8_t)127;
+    ext7[j] = j < n ? (uint8_t)min(e[j] - j, ext_cap) : (uint8_t)ext_cap;
     uint32_t c = 8;
     for (uint32_t s = 0; s < 8 && j + s < n; s++) c = min(c, e[j + s] - j);   // e[j+s] - j >= s + 1 >= 1
     clen[j] = (uint8_t)c;
@@ -292,70 +292,122 @@ __global__ __launch_bounds__(64) void k_dp_tile(const uint8_t *__restrict__ ext7
 //                tie-breaking (S kind first, else the youngest count_solutions kind; fbg.cpp:1976-2009).
 #define DPB_INF 255u
 
+// R = window / 64: candidates up to 64R columns back, blocks of 64R steps, matrices of (64R)^2 bytes.
+template <int R>
 __global__ __launch_bounds__(64) void k_dp_blockW(const uint8_t *__restrict__ ext7, uint32_t n, uint32_t nblocks,
                                                   uint8_t *__restrict__ Wt)
 {
-    __shared__ uint8_t wl[64][64];           // wl[t][lane]: W of inside column 64b+1+t for source `lane`
-    __shared__ uint8_t s_ext[64];
+    constexpr uint32_t WN = 64 * R;
+    extern __shared__ uint8_t dyn_lds[];
+    uint8_t *wl = dyn_lds;                   // wl[t * WN + k]: W of inside column (block start + 1 + t) for source k
+    uint8_t *s_ext = dyn_lds + WN * WN;      // extensions of the inside columns
     const uint32_t lane = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        const uint32_t jb = 64 * b;
-        const int64_t xs = (int64_t)jb - 63 + lane;                   // this lane's old column
-        const uint32_t ext_src = xs >= 0 ? ext7[xs] : 127u;
+        const uint32_t jb = WN * b;
+        uint32_t ext_src[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t xs = (int64_t)jb - (WN - 1) + 64 * r + lane;    // old column of source k = 64r + lane
+            ext_src[r] = xs >= 0 ? ext7[xs] : 255u;
+        }
         __syncthreads();
-        s_ext[lane] = jb + 1 + lane < n ? ext7[jb + 1 + lane] : (uint8_t)127;
+        for (uint32_t q = lane; q < WN; q += 64) s_ext[q] = jb + 1 + q < n ? ext7[jb + 1 + q] : (uint8_t)255;
         __syncthreads();
-        uint8_t *out = Wt + (size_t)b * 4096;
-        for (uint32_t t = 0; t < 64; t++) {
-            const uint32_t age_src = t + 64 - lane;                   // (64b+1+t) - xs
-            uint32_t w = (ext_src <= age_src && age_src <= 64) ? age_src : DPB_INF;
+        uint8_t *out = Wt + (size_t)b * WN * WN;
+        for (uint32_t t = 0; t < WN; t++) {
+            uint32_t w[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t age_src = t + WN - (64 * r + lane);       // (jb+1+t) - xs
+                w[r] = (ext_src[r] <= age_src && age_src <= WN) ? age_src : DPB_INF;
+            }
             for (uint32_t tp = 0; tp < t; tp++) {
                 const uint32_t age = t - tp;
-                if (s_ext[tp] <= age) w = min(w, max((uint32_t)wl[tp][lane], age));   // uniform test
+                if (s_ext[tp] <= age) {                                   // uniform test
+#pragma unroll
+                    for (int r = 0; r < R; r++) w[r] = min(w[r], max((uint32_t)wl[tp * WN + 64 * r + lane], age));
+                }
             }
-            wl[t][lane] = (uint8_t)w;
-            out[t * 64 + lane] = (uint8_t)w;                          // Wt[b][t][k]
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t v = min(w[r], DPB_INF);
+                wl[t * WN + 64 * r + lane] = (uint8_t)v;
+                out[(size_t)t * WN + 64 * r + lane] = (uint8_t)v;         // Wt[b][t][k]
+            }
         }
     }
 }
 
+template <int R>
 __global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt, uint32_t n, uint32_t nblocks,
                                                  uint32_t *__restrict__ mml, unsigned long long *__restrict__ flag)
 {
+    constexpr uint32_t WN = 64 * R;
+    constexpr bool PREFETCH = R <= 2;        // next block's rows held in registers (16 R^2 VGPRs)
+    constexpr int NQ = R * R * 4;             // uint4 loads per lane per block
     const uint32_t lane = threadIdx.x;
-    uint32_t S = lane == 63 ? 0u : DPB_INF;                           // state before block 0: only column 0
+    uint32_t S[R];                                                        // S[r]: state of source k = 64r + lane
+#pragma unroll
+    for (int r = 0; r < R; r++) S[r] = (r == R - 1 && lane == 63) ? 0u : DPB_INF;   // before block 0: only column 0
     if (lane == 0) mml[0] = 0;
     uint32_t bad = 0;
-    const uint4 *W4 = reinterpret_cast<const uint4 *>(Wt);
-    uint4 nx[4];
+    uint4 nx[PREFETCH ? NQ : 1];
+    auto row_ptr = [&](uint32_t b, int rt) {
+        return reinterpret_cast<const uint4 *>(Wt + (size_t)b * WN * WN + (size_t)(64 * rt + lane) * WN);
+    };
+    if (PREFETCH) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) nx[q] = W4[(size_t)lane * 4 + q];     // block 0, row t = lane: 64 bytes
+        for (int rt = 0; rt < R; rt++)
+#pragma unroll
+            for (int i = 0; i < 4 * R; i++) nx[rt * 4 * R + i] = row_ptr(0, rt)[i];
+    }
     for (uint32_t b = 0; b < nblocks; b++) {
-        uint32_t wv[16];
+        uint4 cur[NQ];
+        if (PREFETCH) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) { wv[4 * q] = nx[q].x; wv[4 * q + 1] = nx[q].y; wv[4 * q + 2] = nx[q].z; wv[4 * q + 3] = nx[q].w; }
-        if (b + 1 < nblocks) {
+            for (int i = 0; i < NQ; i++) cur[i] = nx[i];
+            if (b + 1 < nblocks) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) nx[q] = W4[((size_t)(b + 1) * 64 + lane) * 4 + q];
-        }
-        uint32_t best = DPB_INF;
+                for (int rt = 0; rt < R; rt++)
 #pragma unroll
-        for (int k = 0; k < 64; k++) {
-            const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)S, k);
-            const uint32_t w = (wv[k >> 2] >> (8 * (k & 3))) & 255u;
-            best = min(best, max(sk, w));
+                    for (int i = 0; i < 4 * R; i++) nx[rt * 4 * R + i] = row_ptr(b + 1, rt)[i];
+            }
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < R; rt++)
+#pragma unroll
+                for (int i = 0; i < 4 * R; i++) cur[rt * 4 * R + i] = row_ptr(b, rt)[i];
         }
-        const uint32_t j = 64 * b + 1 + lane;
-        if (j <= n) {
-            mml[j] = best;
-            bad |= best >= 64 ? 1u : 0u;
+        uint32_t best[R];
+#pragma unroll
+        for (int rt = 0; rt < R; rt++) {                                   // target t = 64*rt + lane
+            uint32_t acc = DPB_INF;
+#pragma unroll
+            for (int rs = 0; rs < R; rs++) {                               // sources 64*rs .. 64*rs+63
+#pragma unroll
+                for (int k = 0; k < 64; k++) {
+                    const uint4 q = cur[rt * 4 * R + rs * 4 + (k >> 4)];
+                    const uint32_t word = ((k >> 2) & 3) == 0 ? q.x : ((k >> 2) & 3) == 1 ? q.y : ((k >> 2) & 3) == 2 ? q.z : q.w;
+                    const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)S[rs], k);
+                    acc = min(acc, max(sk, (word >> (8 * (k & 3))) & 255u));
+                }
+            }
+            best[rt] = acc;
         }
-        S = best;
+#pragma unroll
+        for (int rt = 0; rt < R; rt++) {
+            const uint32_t j = WN * b + 1 + 64 * rt + lane;
+            if (j <= n) {
+                mml[j] = best[rt];
+                bad |= best[rt] >= (R == 1 ? 64u : 255u) ? 1u : 0u;
+            }
+            S[rt] = best[rt];
+        }
     }
     if (__ballot(bad != 0) && lane == 0) flag[4] = 1;
 }
 
-__global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restrict__ ext7, uint32_t n,
+__global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restrict__ ext7, uint32_t n, uint32_t window,
                         uint32_t *__restrict__ bt, unsigned long long *__restrict__ flag)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -364,7 +416,7 @@ __global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restr
     const uint32_t L = mml[j];
     uint32_t best_age = 0;                    // youngest count_solutions-kind candidate (age <= its value == L)
     bool s_kind = false;                      // candidate of age L with a smaller value: the S / backtrack_S branch
-    const uint32_t amax = min(64u, j);
+    const uint32_t amax = min(window, j);
     for (uint32_t a = 1; a <= amax; a++) {
         const uint32_t x = j - a;
         if (ext7[x] > a) continue;            // block [x, j) not valid yet: f[x]+1 > j
@@ -506,25 +558,38 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     int R = 0;
     if (f0 == 0 && !getenv("FBG_DP_LITERAL")) {
         const unsigned long long bound = 2 * max_ext + 2;   // minmaxlength[j] <= 2*max_ext + 1
-        R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 256 ? 4 : bound <= 512 ? 8 : bound <= 1024 ? 16 : 0;
+        R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 254 ? 4 : bound <= 512 ? 8 : bound <= 1024 ? 16 : 0;
     }
     bool literal = R == 0;
     bool tiled = false;
     if (!literal) {
-        if (R == 1 && !getenv("FBG_DP_WAVE")) {
-            // block lengths < 64: sweeps that work straight from f (no bucket order needed)
+        if (R <= 4 && !getenv("FBG_DP_WAVE")) {
+            // sweeps that work straight from f (no bucket order needed)
             uint8_t *ext7 = ctx->dp_e.as<uint8_t>(), *clen = ctx->dp_f.as<uint8_t>();
-            hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext7, clen);
-            if (getenv("FBG_DP_TILE")) {
+            const bool tile = R == 1 && getenv("FBG_DP_TILE");
+            hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n,
+                               tile ? 127u : 255u, ext7, clen);
+            if (tile) {
                 hipLaunchKernelGGL(k_dp_tile, dim3(1), dim3(64), 0, st, ext7, clen, (uint32_t)n, mml, bt, sc);
             } else {
-                const uint32_t nblocks = (uint32_t)((n + 63) / 64);
-                FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * 4096));
+                const uint32_t WN = 64u * R;
+                const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN);
+                FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
                 uint8_t *Wt = ctx->tmp.as<uint8_t>();
-                hipLaunchKernelGGL(k_dp_blockW, dim3(fbg_blocks(nblocks, 1, 256 * 16)), dim3(64), 0, st, ext7, (uint32_t)n,
-                                   nblocks, Wt);
-                hipLaunchKernelGGL(k_dp_chain, dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
-                hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, bt, sc);
+                const size_t lds = (size_t)WN * WN + WN;
+                const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
+                if (R == 1) {
+                    hipLaunchKernelGGL((k_dp_blockW<1>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);
+                    hipLaunchKernelGGL((k_dp_chain<1>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
+                } else if (R == 2) {
+                    hipLaunchKernelGGL((k_dp_blockW<2>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);
+                    hipLaunchKernelGGL((k_dp_chain<2>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
+                } else {
+                    FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_blockW<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_dp_blockW<4>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);
+                    hipLaunchKernelGGL((k_dp_chain<4>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
+                }
+                hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, WN, bt, sc);
             }
             tiled = true;
         } else {

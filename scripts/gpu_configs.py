@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Runs the BASELINE configs other than the headline (and the harder 'star phylogeny' distribution of
+SURVEY.md 8d) through the staged device API and prints per-stage times.  Not part of bench.py's contract;
+used to fill the tables of DESIGN.md / BASELINE.md."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import founderblockgraphs_amd as F  # noqa: E402
+
+
+def star_msa(m, n, p=0.01, seed=7):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    anc = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.uint8)
+    out = torch.empty((m, n), dtype=torch.uint8, device="cuda")
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    for i0 in range(0, m, 50):
+        i1 = min(m, i0 + 50)
+        mut = torch.rand((i1 - i0, n), device="cuda", generator=g) < p
+        sub = torch.randint(0, 4, (i1 - i0, n), device="cuda", generator=g, dtype=torch.uint8)
+        out[i0:i1] = lut[torch.where(mut, sub, anc.expand(i1 - i0, n)).long()]
+    return out.reshape(-1)
+
+
+def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_fraction=0.0, star=False, reps=2):
+    eng = F.Engine(0)
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    eng.set_stream(st.cuda_stream)
+    if star:
+        d = star_msa(m, n)
+    else:
+        d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+        eng.msa_synthetic(d.data_ptr(), m, n, gap_fraction=gap_fraction, gap_run=gap_run, n_fraction=n_fraction)
+    d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.msa_set_device(d.data_ptr(), m, n)
+        eng.index_build(reversed=not elastic, ignorechars=ignore)
+        d_f.zero_()
+        if elastic:
+            eng.scan_f(0, n, d_f.data_ptr())
+            blocks = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        else:
+            eng.scan_v(0, n, d_f.data_ptr())
+            blocks = eng.repeatfree_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stages = {k: round(v[0], 3) for k, v in eng.stage_ms().items()}
+        if best is None or dt < best[0]:
+            best = (dt, stages, blocks)
+    dt, stages, blocks = best
+    ext = int((d_f - torch.arange(n, device="cuda")).max()) if elastic else None
+    print(json.dumps({"config": name, "rows": m, "cols": n, "ms": round(dt * 1e3, 2), "columns_per_s": round(n / dt),
+                      "blocks": blocks, "max_extension": ext, "stages_ms": stages,
+                      "device_GB": round(eng.device_bytes() / 1e9, 1)}), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c5", "star"]
+    if "c2" in which:
+        run("C2 64x100k non-elastic", 64, 100_000, elastic=False)
+    if "c5" in which:
+        run("C5 256x2M gaps+N elastic ignore=N", 256, 2_000_000, ignore="N", gap_fraction=0.05, gap_run=16, n_fraction=0.001)
+    if "star" in which:
+        run("star phylogeny 1000x200k p=0.01", 1000, 200_000, star=True)
+    if "star1m" in which:
+        run("star phylogeny 1000x1M p=0.01", 1000, 1_000_000, star=True, reps=1)
+    if "c3" in which:
+        run("C3 1000x1M elastic", 1000, 1_000_000)
