@@ -81,15 +81,28 @@ __device__ __forceinline__ uint32_t key_lcp(uint64_t a, uint64_t c, int b, int k
     return (uint32_t)((__clzll((long long)d) - (64 - key_bits)) / b);
 }
 
-struct ColTest {          // "same MSA column" for gap-free MSAs: positions p, q with equal p mod (n+1)
-    uint64_t row_len;     // n + 1 ; 0 = test disabled (MSA with gaps: lcp.hip computes the hints)
-    uint64_t last;        // N - 1, the sentinel, never a row pointer
-    __device__ __forceinline__ uint32_t same(uint32_t p, uint32_t q) const
+// Run hint of two SA-adjacent positions: can both be the pointer of an active row in one column?
+// Row pointer p is current for the columns (column of the previous symbol of its row, column of p]
+// (fbg.cpp:1687-1691); gap-free MSAs: exactly one column, p mod (n+1).
+struct ColTest {
+    const uint32_t *colT;  // MSAs with gaps: column of every text position ('#', sentinel: n); else nullptr
+    uint32_t row_len;      // gap-free: n + 1
+    uint32_t n;
+    uint32_t last;         // N - 1, the sentinel, never a row pointer
+    __device__ __forceinline__ uint2 span(uint32_t p) const
     {
-        if (row_len == 0 || p == last || q == last) return 0;
-        const uint32_t d = (uint32_t)row_len;
-        return (p % d) == (q % d) ? 0x80000000u : 0u;
+        if (p == last) return make_uint2(1u, 0u);                        // empty
+        if (!colT) { const uint32_t c = p % row_len; return make_uint2(c, c); }
+        const uint32_t c = colT[p];
+        uint32_t lo = 0;
+        if (p > 0) { const uint32_t cp = colT[p - 1]; lo = cp >= n ? 0u : cp + 1; }
+        return make_uint2(lo, c < n ? c : n - 1);
     }
+    static __device__ __forceinline__ uint32_t meet(uint2 a, uint2 c)
+    {
+        return max(a.x, c.x) <= min(a.y, c.y) ? 0x80000000u : 0u;
+    }
+    __device__ __forceinline__ uint32_t same(uint32_t p, uint32_t q) const { return meet(span(p), span(q)); }
 };
 
 // round 0, after the max-scan: one 16-byte record per text position (rank, key-derived neighbour LCPs
@@ -98,20 +111,32 @@ __global__ void k_apply_groups0(const uint32_t *__restrict__ grp, const uint32_t
                                 const uint64_t *__restrict__ keys, uint64_t N, int b, int key_bits, ColTest ct,
                                 uint4 *__restrict__ rec, uint8_t *__restrict__ flags)
 {
-    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const uint32_t g = grp[k], p = vals[k];
-    const uint64_t key = keys[k];
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = k < N;
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = in ? grp[k] : 0u, p = in ? vals[k] : ct.last;
+    const uint64_t key = in ? keys[k] : 0ull;
+    // column span of this suffix's position; the neighbours' spans come from the adjacent lanes
+    const uint2 sp = ct.span(p);
+    uint2 sprev = make_uint2(__shfl_up(sp.x, 1, 64), __shfl_up(sp.y, 1, 64));
+    uint2 snext = make_uint2(__shfl_down(sp.x, 1, 64), __shfl_down(sp.y, 1, 64));
+    if (!in) return;
     uint32_t lp = 0, ln = 0;
     bool head = g == (uint32_t)k, next_head = true;
     if (k > 0) {
         const uint64_t kp = keys[k - 1];
-        if (kp != key) lp = key_lcp(kp, key, b, key_bits) | ct.same(vals[k - 1], p);
+        if (kp != key) {
+            if (lane == 0) sprev = ct.span(vals[k - 1]);
+            lp = key_lcp(kp, key, b, key_bits) | ColTest::meet(sprev, sp);
+        }
     }
     if (k + 1 < N) {
         const uint64_t kn = keys[k + 1];
         next_head = kn != key;
-        if (next_head) ln = key_lcp(key, kn, b, key_bits) | ct.same(p, vals[k + 1]);
+        if (next_head) {
+            if (lane == 63) snext = ct.span(vals[k + 1]);
+            ln = key_lcp(key, kn, b, key_bits) | ColTest::meet(sp, snext);
+        }
     }
     rec[p] = make_uint4(g, lp, ln, 0u);
     flags[k] = !(head && next_head);
@@ -263,8 +288,10 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     uint32_t *sa = valsB;                     // the sorted positions ARE the suffix array
     ctx->sa_ptr = sa;
     ColTest ct;
-    ct.row_len = ctx->gapfree ? ctx->n + 1 : 0;
-    ct.last = N - 1;
+    ct.colT = ctx->gapfree ? nullptr : ctx->colT.as<uint32_t>();
+    ct.row_len = (uint32_t)(ctx->n + 1);
+    ct.n = (uint32_t)ctx->n;
+    ct.last = (uint32_t)(N - 1);
 
     hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
                        keysA, valsA);
@@ -304,9 +331,9 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         launches += 1;
         if (round == 1) {
-            // few ties and no gaps: the key-derived LCPs stand, only the tie groups are patched afterwards;
+            // few ties: the key-derived LCPs stand, only the tie groups are patched afterwards;
             // the round-0 keys (keysB) must then survive the doubling rounds
-            ctx->lcp_from_keys = ctx->gapfree && hc <= N / 32 && !getenv("FBG_LCP_TEXT");
+            ctx->lcp_from_keys = hc <= N / 32 && !getenv("FBG_LCP_TEXT");
             if (ctx->lcp_from_keys && hc > 0) {
                 dirty_cnt = hc;
                 FBG_TRY(fbg_reserve(ctx, ctx->io_d, hc * 4));
