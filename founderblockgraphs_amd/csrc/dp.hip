@@ -340,8 +340,11 @@ __global__ __launch_bounds__(64) void k_dp_blockW(const uint8_t *__restrict__ ex
 
 template <int R>
 __global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt, uint32_t n, uint32_t nblocks,
+                                                 uint32_t F, uint8_t *__restrict__ Sg,
                                                  uint32_t *__restrict__ mml, unsigned long long *__restrict__ flag)
 {
+    // steps from group to group: block index of step g is the last block of group g (its matrix holds the
+    // product of the whole group after k_dp_compose); Sg[g] receives the state entering group g
     constexpr uint32_t WN = 64 * R;
     constexpr bool PREFETCH = R <= 2;        // next block's rows held in registers (16 R^2 VGPRs)
     constexpr int NQ = R * R * 4;             // uint4 loads per lane per block
@@ -352,7 +355,9 @@ __global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt,
     if (lane == 0) mml[0] = 0;
     uint32_t bad = 0;
     uint4 nx[PREFETCH ? NQ : 1];
-    auto row_ptr = [&](uint32_t b, int rt) {
+    const uint32_t ngroups = (nblocks + F - 1) / F;
+    auto row_ptr = [&](uint32_t g, int rt) {
+        const uint32_t b = min(g * F + F - 1, nblocks - 1);
         return reinterpret_cast<const uint4 *>(Wt + (size_t)b * WN * WN + (size_t)(64 * rt + lane) * WN);
     };
     if (PREFETCH) {
@@ -361,12 +366,14 @@ __global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt,
 #pragma unroll
             for (int i = 0; i < 4 * R; i++) nx[rt * 4 * R + i] = row_ptr(0, rt)[i];
     }
-    for (uint32_t b = 0; b < nblocks; b++) {
+    for (uint32_t b = 0; b < ngroups; b++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) Sg[(size_t)b * WN + 64 * r + lane] = (uint8_t)min(S[r], DPB_INF);
         uint4 cur[NQ];
         if (PREFETCH) {
 #pragma unroll
             for (int i = 0; i < NQ; i++) cur[i] = nx[i];
-            if (b + 1 < nblocks) {
+            if (b + 1 < ngroups) {
 #pragma unroll
                 for (int rt = 0; rt < R; rt++)
 #pragma unroll
@@ -395,16 +402,89 @@ __global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt,
             best[rt] = acc;
         }
 #pragma unroll
-        for (int rt = 0; rt < R; rt++) {
-            const uint32_t j = WN * b + 1 + 64 * rt + lane;
-            if (j <= n) {
-                mml[j] = best[rt];
-                bad |= best[rt] >= (R == 1 ? 64u : 255u) ? 1u : 0u;
-            }
-            S[rt] = best[rt];
-        }
+        for (int rt = 0; rt < R; rt++) S[rt] = best[rt];   // minmaxlength values are written by k_dp_expand
     }
     if (__ballot(bad != 0) && lane == 0) flag[4] = 1;
+}
+
+// Shorten the sequential chain: inside every group of F consecutive blocks the matrices are replaced by
+// their running (min,max) products P_i = W_first (x) ... (x) W_i (in place, all groups in parallel), so the
+// chain only has to step from group to group (through the last product) and every block's values follow
+// from its group's entry state with one independent matrix-vector product (k_dp_expand).
+//     (P (x) W)[t][k] = min_u max( P[u][k], W[t][u] )      t: target of W, k: source of P
+template <int R>
+__global__ __launch_bounds__(256) void k_dp_compose(uint8_t *__restrict__ Wt, uint32_t nblocks, uint32_t F)
+{
+    constexpr uint32_t WN = 64 * R;
+    extern __shared__ uint8_t dyn_lds[];
+    uint8_t *P = dyn_lds, *W = dyn_lds + WN * WN;       // [row][col] = [target][source]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * F;
+    if (b0 >= nblocks) return;
+    const uint32_t b1 = min(b0 + F, nblocks);
+    for (uint32_t q = tid * 16; q < WN * WN; q += 256 * 16)
+        *reinterpret_cast<uint4 *>(P + q) = *reinterpret_cast<const uint4 *>(Wt + (size_t)b0 * WN * WN + q);
+    for (uint32_t b = b0 + 1; b < b1; b++) {
+        uint8_t *G = Wt + (size_t)b * WN * WN;
+        __syncthreads();
+        for (uint32_t q = tid * 16; q < WN * WN; q += 256 * 16)
+            *reinterpret_cast<uint4 *>(W + q) = *reinterpret_cast<const uint4 *>(G + q);
+        __syncthreads();
+        // thread -> (row t, 4 consecutive sources k): WN*WN/4 work items
+        for (uint32_t item = tid; item < WN * WN / 4; item += 256) {
+            const uint32_t t = item / (WN / 4), k4 = (item % (WN / 4)) * 4;
+            uint32_t a0 = DPB_INF, a1 = DPB_INF, a2 = DPB_INF, a3 = DPB_INF;
+            for (uint32_t u = 0; u < WN; u++) {
+                const uint32_t w = W[t * WN + u];
+                if (w == DPB_INF) continue;
+                const uint32_t p4 = *reinterpret_cast<const uint32_t *>(P + u * WN + k4);
+                a0 = min(a0, max(w, p4 & 255u));
+                a1 = min(a1, max(w, (p4 >> 8) & 255u));
+                a2 = min(a2, max(w, (p4 >> 16) & 255u));
+                a3 = min(a3, max(w, p4 >> 24));
+            }
+            *reinterpret_cast<uint32_t *>(G + t * WN + k4) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        }
+        __syncthreads();
+        // the product becomes P for the next block of the group
+        for (uint32_t q = tid * 16; q < WN * WN; q += 256 * 16)
+            *reinterpret_cast<uint4 *>(P + q) = *reinterpret_cast<const uint4 *>(G + q);
+    }
+}
+
+// state entering block b (64R values) (x) matrix of block b -> minmaxlength of the block's columns
+template <int R>
+__global__ __launch_bounds__(64) void k_dp_expand(const uint8_t *__restrict__ Wt, const uint8_t *__restrict__ Sg,
+                                                  uint32_t n, uint32_t nblocks, uint32_t F, uint32_t *__restrict__ mml,
+                                                  unsigned long long *__restrict__ flag)
+{
+    constexpr uint32_t WN = 64 * R;
+    __shared__ uint8_t s_state[WN];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        __syncthreads();
+        for (uint32_t q = lane; q < WN; q += 64) s_state[q] = Sg[(size_t)(b / F) * WN + q];
+        __syncthreads();
+        const uint8_t *Wb = Wt + (size_t)b * WN * WN;
+#pragma unroll
+        for (int rt = 0; rt < R; rt++) {
+            const uint32_t t = 64 * rt + lane;
+            const uint4 *row = reinterpret_cast<const uint4 *>(Wb + (size_t)t * WN);
+            uint32_t acc = DPB_INF;
+            for (uint32_t q = 0; q < WN / 16; q++) {
+                const uint4 w4 = row[q];
+                const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    acc = min(acc, max((uint32_t)s_state[16 * q + i], (ws[i >> 2] >> (8 * (i & 3))) & 255u));
+            }
+            const uint32_t j = WN * b + 1 + t;
+            if (j <= n) {
+                mml[j] = acc;
+                if (acc >= (R == 1 ? 64u : 255u)) flag[4] = 1;
+            }
+        }
+    }
 }
 
 __global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restrict__ ext7, uint32_t n, uint32_t window,
@@ -429,24 +509,30 @@ __global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restr
     else { bt[j] = 0; flag[4] = 1; }
 }
 
-// backtrack (fbg.cpp:2026-2039) for block lengths < 64: walks backtrack[] backwards through two
-// register-resident 64-column windows (current and the prefetched previous one); the boundaries are
-// collected in reverse in LDS and flushed 1024 at a time.  rev[] receives them, result[0] the count.
+// backtrack (fbg.cpp:2026-2039): walks backtrack[] backwards through an 8192-column LDS window (one bulk
+// load per window instead of one global round trip per hop); the boundaries are collected in reverse in
+// LDS and flushed 1024 at a time.  rev[] receives them, result[0] the count.
 __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__restrict__ bt, uint32_t n,
                                                           uint32_t *__restrict__ rev,
                                                           unsigned long long *__restrict__ result)
 {
+    constexpr uint32_t WIN = 8192;           // backtrack[] window held in LDS, reloaded when walked out of
+    __shared__ uint32_t s_bt[WIN];
     __shared__ uint32_t obuf[1024];
     const uint32_t lane = threadIdx.x;
-    uint32_t j = n, cnt = 0, flushed = 0;
-    uint32_t blk = j >> 6;
-    uint32_t cur = blk * 64 + lane <= n ? bt[blk * 64 + lane] : 0;
-    uint32_t prv = blk > 0 ? bt[(blk - 1) * 64 + lane] : 0;
+    uint32_t j = n, cnt = 1, flushed = 0;
+    uint32_t wlo = 0xffffffffu, whi = 0;      // window covers columns [wlo, whi]
     if (lane == 0) obuf[0] = n;
-    cnt = 1;
     bool err = false;
     for (;;) {
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(j & 63));
+        if (j < wlo || j > whi) {             // (re)load the window ending at j
+            __syncthreads();
+            whi = j;
+            wlo = j >= WIN - 1 ? j - (WIN - 1) : 0;
+            for (uint32_t k = lane; k <= whi - wlo; k += 64) s_bt[k] = bt[wlo + k];
+            __syncthreads();
+        }
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_bt[j - wlo]);
         if (b == 0) break;
         if (b > n || cnt > n + 1) { err = true; break; }
         if (cnt - flushed == 1024) {
@@ -458,16 +544,6 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
         if (lane == 0) obuf[cnt - flushed] = b - 1;
         cnt++;
         j = b;
-        const uint32_t nb = j >> 6;
-        if (nb != blk) {
-            if (nb + 1 == blk) {
-                cur = prv;
-            } else {
-                cur = bt[nb * 64 + lane];
-            }
-            blk = nb;
-            prv = blk > 0 ? bt[(blk - 1) * 64 + lane] : 0;
-        }
     }
     __syncthreads();
     for (uint32_t k = lane; k < cnt - flushed; k += 64) rev[flushed + k] = obuf[k];
@@ -576,19 +652,26 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                 const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN);
                 FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
                 uint8_t *Wt = ctx->tmp.as<uint8_t>();
-                const size_t lds = (size_t)WN * WN + WN;
+                const size_t lds = (size_t)WN * WN + WN, lds2 = 2 * (size_t)WN * WN;
                 const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
-                if (R == 1) {
-                    hipLaunchKernelGGL((k_dp_blockW<1>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);
-                    hipLaunchKernelGGL((k_dp_chain<1>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
-                } else if (R == 2) {
-                    hipLaunchKernelGGL((k_dp_blockW<2>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);
-                    hipLaunchKernelGGL((k_dp_chain<2>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
-                } else {
-                    FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_blockW<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_dp_blockW<4>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);
-                    hipLaunchKernelGGL((k_dp_chain<4>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, mml, sc);
-                }
+                const uint32_t Fg = 4;                                   // blocks per group of the chain
+                const uint32_t ngroups = (nblocks + Fg - 1) / Fg;
+                uint8_t *Sg = reinterpret_cast<uint8_t *>(cur);          // (n+2)*4 bytes >= ngroups * WN: free on this path
+#define FBG_DP_PIPE(RR)                                                                                                   \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_blockW<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (lds2 > 64 * 1024)                                                                                            \
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_compose<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);             \
+        hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
+        hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);        \
+        hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc);    \
+    } while (0)
+                if (R == 1) FBG_DP_PIPE(1);
+                else if (R == 2) FBG_DP_PIPE(2);
+                else FBG_DP_PIPE(4);
+#undef FBG_DP_PIPE
                 hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, WN, bt, sc);
             }
             tiled = true;

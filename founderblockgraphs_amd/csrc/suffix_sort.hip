@@ -37,30 +37,35 @@ __global__ void k_byte_hist(const uint8_t *__restrict__ T, uint64_t N, unsigned 
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
-// key[p] = first K symbol codes of suffix p, most significant first, zero beyond the text
+// key[p] = first K symbol codes of suffix p, most significant first, zero beyond the text.
+// Each thread owns PK_ITEMS consecutive positions: the first key is packed symbol by symbol, the following
+// ones roll (drop the leading symbol, append one), so the cost per position is one LDS byte read.
+#define PK_ITEMS 8
 __global__ __launch_bounds__(SS_THREADS) void k_pack_keys(const uint8_t *__restrict__ T, uint64_t N,
                                                           const uint8_t *__restrict__ code, int b, int K,
                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
-    __shared__ uint8_t tile[SS_THREADS + 64];
+    constexpr int TILE = SS_THREADS * PK_ITEMS;
+    __shared__ uint8_t tile[TILE + 64];      // symbol codes of the block's positions (+K lookahead)
     __shared__ uint8_t cd[256];
     cd[threadIdx.x] = code[threadIdx.x];
-    const uint64_t base = (uint64_t)blockIdx.x * SS_THREADS;
-    for (int k = threadIdx.x; k < SS_THREADS + 64; k += SS_THREADS) {
-        uint64_t p = base + k;
-        tile[k] = p < N ? T[p] : 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    for (int k = threadIdx.x; k < TILE + 64; k += SS_THREADS) {
+        const uint64_t p = base + k;
+        tile[k] = p < N ? cd[T[p]] : 0;
     }
     __syncthreads();
-    const uint64_t p = base + threadIdx.x;
-    if (p >= N) return;
+    const int t0 = threadIdx.x * PK_ITEMS;
+    const uint64_t mask = (K * b) >= 64 ? ~0ull : ((1ull << (K * b)) - 1);
     uint64_t key = 0;
-    for (int k = 0; k < K; k++) {
-        uint64_t q = p + k;
-        uint8_t c = q < N ? cd[tile[threadIdx.x + k]] : 0;
-        key = (key << b) | c;
+    for (int k = 0; k < K; k++) key = (key << b) | tile[t0 + k];
+#pragma unroll
+    for (int i = 0; i < PK_ITEMS; i++) {
+        const uint64_t p = base + t0 + i;
+        if (p < N) { keys[p] = key; vals[p] = (uint32_t)p; }
+        key = ((key << b) | tile[t0 + K + i]) & mask;
     }
-    keys[p] = key;
-    vals[p] = (uint32_t)p;
 }
 
 // grp[r] = r if key[r] starts a group, else 0  (max-scan turns it into the group head index)
@@ -293,7 +298,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     ct.n = (uint32_t)ctx->n;
     ct.last = (uint32_t)(N - 1);
 
-    hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
+    hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
                        keysA, valsA);
     launches += 2;
     FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
