@@ -294,46 +294,37 @@ __global__ __launch_bounds__(64) void k_dp_tile(const uint8_t *__restrict__ ext7
 
 // R = window / 64: candidates up to 64R columns back, blocks of 64R steps, matrices of (64R)^2 bytes.
 template <int R>
-__global__ __launch_bounds__(64) void k_dp_blockW(const uint8_t *__restrict__ ext7, uint32_t n, uint32_t nblocks,
-                                                  uint8_t *__restrict__ Wt)
+__global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict__ ext7, uint32_t n, uint32_t nblocks,
+                                                      uint8_t *__restrict__ Wt)
 {
+    // one thread per source column k; the R waves of a block never need each other's values
     constexpr uint32_t WN = 64 * R;
     extern __shared__ uint8_t dyn_lds[];
     uint8_t *wl = dyn_lds;                   // wl[t * WN + k]: W of inside column (block start + 1 + t) for source k
     uint8_t *s_ext = dyn_lds + WN * WN;      // extensions of the inside columns
-    const uint32_t lane = threadIdx.x;
+    const uint32_t k = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const uint32_t jb = WN * b;
-        uint32_t ext_src[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int64_t xs = (int64_t)jb - (WN - 1) + 64 * r + lane;    // old column of source k = 64r + lane
-            ext_src[r] = xs >= 0 ? ext7[xs] : 255u;
-        }
+        const int64_t xs = (int64_t)jb - (WN - 1) + k;                    // old column of source k
+        const uint32_t ext_src = xs >= 0 ? ext7[xs] : 255u;
         __syncthreads();
-        for (uint32_t q = lane; q < WN; q += 64) s_ext[q] = jb + 1 + q < n ? ext7[jb + 1 + q] : (uint8_t)255;
+        s_ext[k] = jb + 1 + k < n ? ext7[jb + 1 + k] : (uint8_t)255;
         __syncthreads();
+        uint32_t minext = 255;
+        for (uint32_t q = 0; q < WN; q++) minext = min(minext, (uint32_t)s_ext[q]);
         uint8_t *out = Wt + (size_t)b * WN * WN;
         for (uint32_t t = 0; t < WN; t++) {
-            uint32_t w[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint32_t age_src = t + WN - (64 * r + lane);       // (jb+1+t) - xs
-                w[r] = (ext_src[r] <= age_src && age_src <= WN) ? age_src : DPB_INF;
-            }
-            for (uint32_t tp = 0; tp < t; tp++) {
+            const uint32_t age_src = t + WN - k;                          // (jb+1+t) - xs
+            uint32_t w = (ext_src <= age_src && age_src <= WN) ? age_src : DPB_INF;
+            // inside candidates need age >= their extension >= minext
+            const uint32_t tp_end = t >= minext ? t - minext + 1 : 0;
+            for (uint32_t tp = 0; tp < tp_end; tp++) {
                 const uint32_t age = t - tp;
-                if (s_ext[tp] <= age) {                                   // uniform test
-#pragma unroll
-                    for (int r = 0; r < R; r++) w[r] = min(w[r], max((uint32_t)wl[tp * WN + 64 * r + lane], age));
-                }
+                if (s_ext[tp] <= age) w = min(w, max((uint32_t)wl[tp * WN + k], age));   // wave-uniform test
             }
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const uint32_t v = min(w[r], DPB_INF);
-                wl[t * WN + 64 * r + lane] = (uint8_t)v;
-                out[(size_t)t * WN + 64 * r + lane] = (uint8_t)v;         // Wt[b][t][k]
-            }
+            w = min(w, DPB_INF);
+            wl[t * WN + k] = (uint8_t)w;
+            out[(size_t)t * WN + k] = (uint8_t)w;                         // Wt[b][t][k]
         }
     }
 }
@@ -663,7 +654,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_blockW<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         if (lds2 > 64 * 1024)                                                                                            \
             FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_compose<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64), lds, st, ext7, (uint32_t)n, nblocks, Wt);             \
+        hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext7, (uint32_t)n, nblocks, Wt);             \
         hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
         hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);        \
         hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc);    \
