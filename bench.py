@@ -70,6 +70,19 @@ def cpu_baseline(m, n_total, sample_cols):
     }
 
 
+def measured_traffic(m, n):
+    """HBM bytes per k_scan_stream launch from the committed rocprofv3 PMC pass (profiles/, collected and
+    corrected as MI355X_MICROARCH.md prescribes); None when no pass exists for this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_stream.json")) as fh:
+            d = json.load(fh)
+        if d["workload"] == {"rows": m, "cols": n}:
+            return d["kernels"]["k_scan_stream"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,7 +205,9 @@ def main():
                                    f"{'' if world == 1 else f', {args.cols_per_gpu} columns per GPU, {mode}'}",
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
             "roofline": {"bound": "hbm", "kernel": "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": measured_traffic(scan_rows, scan_cols) if world == 1 else None,
+                         "traffic_source": "profiles/r01_pmc_scan_stream.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "device_bytes": eng.device_bytes(),
