@@ -294,14 +294,17 @@ __global__ __launch_bounds__(64) void k_dp_tile(const uint8_t *__restrict__ ext7
 
 // R = window / 64: candidates up to 64R columns back, blocks of 64R steps, matrices of (64R)^2 bytes.
 template <int R>
-__global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict__ ext7, uint32_t n, uint32_t nblocks,
-                                                      uint8_t *__restrict__ Wt)
+__global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict__ ext7, const uint8_t *__restrict__ amin,
+                                                      uint32_t n, uint32_t nblocks, uint8_t *__restrict__ Wt)
 {
+    // amin (optional): per-step minimal block length -- the non-elastic recurrence, where a block ending at
+    // step j is valid iff it is at least j - v[j-1] long (fbg.cpp:625-627); 255 = no valid block ends there
     // one thread per source column k; the R waves of a block never need each other's values
     constexpr uint32_t WN = 64 * R;
     extern __shared__ uint8_t dyn_lds[];
     uint8_t *wl = dyn_lds;                   // wl[t * WN + k]: W of inside column (block start + 1 + t) for source k
     uint8_t *s_ext = dyn_lds + WN * WN;      // extensions of the inside columns
+    uint8_t *s_amin = s_ext + WN;            // minimal block length per step
     const uint32_t k = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const uint32_t jb = WN * b;
@@ -309,15 +312,18 @@ __global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict_
         const uint32_t ext_src = xs >= 0 ? ext7[xs] : 255u;
         __syncthreads();
         s_ext[k] = jb + 1 + k < n ? ext7[jb + 1 + k] : (uint8_t)255;
+        s_amin[k] = amin ? (jb + 1 + k <= n ? amin[jb + 1 + k] : (uint8_t)255) : (uint8_t)1;
         __syncthreads();
         uint32_t minext = 255;
         for (uint32_t q = 0; q < WN; q++) minext = min(minext, (uint32_t)s_ext[q]);
         uint8_t *out = Wt + (size_t)b * WN * WN;
         for (uint32_t t = 0; t < WN; t++) {
             const uint32_t age_src = t + WN - k;                          // (jb+1+t) - xs
-            uint32_t w = (ext_src <= age_src && age_src <= WN) ? age_src : DPB_INF;
-            // inside candidates need age >= their extension >= minext
-            const uint32_t tp_end = t >= minext ? t - minext + 1 : 0;
+            const uint32_t am = s_amin[t];
+            uint32_t w = (ext_src <= age_src && age_src <= WN && age_src >= am) ? age_src : DPB_INF;
+            // inside candidates need age >= their extension >= minext and age >= the step's minimum
+            const uint32_t need = max(minext, am);
+            const uint32_t tp_end = t >= need ? t - need + 1 : 0;
             for (uint32_t tp = 0; tp < tp_end; tp++) {
                 const uint32_t age = t - tp;
                 if (s_ext[tp] <= age) w = min(w, max((uint32_t)wl[tp * WN + k], age));   // wave-uniform test
@@ -643,7 +649,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                 const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN);
                 FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
                 uint8_t *Wt = ctx->tmp.as<uint8_t>();
-                const size_t lds = (size_t)WN * WN + WN, lds2 = 2 * (size_t)WN * WN;
+                const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
                 const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
                 const uint32_t Fg = 4;                                   // blocks per group of the chain
                 const uint32_t ngroups = (nblocks + Fg - 1) / Fg;
@@ -654,7 +660,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_blockW<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         if (lds2 > 64 * 1024)                                                                                            \
             FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_compose<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext7, (uint32_t)n, nblocks, Wt);             \
+        hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext7, (const uint8_t *)nullptr, (uint32_t)n, nblocks, Wt);             \
         hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
         hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);        \
         hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc);    \
@@ -739,6 +745,59 @@ __global__ void k_dp_repeatfree(const uint64_t *__restrict__ v, uint32_t n, uint
     result[0] = cnt; result[1] = 0;
 }
 
+// ---- non-elastic recurrence on the block-matrix machinery ---------------------------------------------
+// In prefix lengths (j' = j+1, x' = jp): s'[j'] = min over x' <= v[j'-1] of max(s'[x'], j' - x') for steps
+// with a valid block (v[j'-1] <= j'-1), no value otherwise (fbg.cpp:622-643).  A candidate is valid at a
+// step iff its age j'-x' is at least j' - v[j'-1]: a per-step threshold instead of a per-candidate one.
+__global__ void k_ne_prep(const uint64_t *__restrict__ v, uint32_t n, uint8_t *__restrict__ ext1, uint8_t *__restrict__ amin,
+                          unsigned long long *__restrict__ sc)
+{
+    const uint32_t jp = blockIdx.x * blockDim.x + threadIdx.x;   // prefix length 0..n
+    if (jp > n) return;
+    ext1[jp] = 1;
+    uint32_t am = 255;
+    if (jp >= 1) {
+        const uint64_t vj = v[jp - 1];
+        if (vj <= jp - 1) am = (uint32_t)min((uint64_t)255, (uint64_t)jp - vj);
+    }
+    amin[jp] = (uint8_t)am;
+    // longest minimal block, to size the window
+    unsigned long long e = am == 255 ? 0 : am;
+    for (int d = 32; d >= 1; d >>= 1) e = max(e, (unsigned long long)__shfl_down(e, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(sc + 3, e);
+}
+
+// s[j], prev[j] (fbg.cpp:623-636) from the prefix values: first (largest jp) candidate reaching the minimum
+__global__ void k_ne_finish(const uint32_t *__restrict__ sp, const uint8_t *__restrict__ amin, uint32_t n, uint32_t window,
+                            uint32_t *__restrict__ s, uint32_t *__restrict__ prev, uint32_t *__restrict__ btp,
+                            unsigned long long *__restrict__ flag)
+{
+    const uint32_t jp = blockIdx.x * blockDim.x + threadIdx.x;   // prefix length 1..n  <->  column j = jp-1
+    if (jp == 0) { if (blockIdx.x == 0) btp[0] = 0; return; }
+    if (jp > n) return;
+    const uint32_t L = sp[jp], am = amin[jp], j = jp - 1;
+    if (am == 255) { s[j] = j + 2; prev[j] = j + 1; btp[jp] = DP_NONE; return; }       // no valid block ends here
+    if (L >= DPB_INF) {   // no value inside the window: undecidable here, let the literal kernel do this input
+        flag[4] = 1; s[j] = j + 2; prev[j] = j + 1; btp[jp] = DP_NONE; return;
+    }
+    uint32_t best = 0;
+    const uint32_t amax = min(window, jp);
+    for (uint32_t a = am; a <= amax; a++) {
+        const uint32_t v = sp[jp - a];
+        if (v < DPB_INF && max(v, a) == L) { best = a; break; }
+    }
+    if (!best) { flag[4] = 1; best = am; }
+    s[j] = L;
+    prev[j] = jp - best;
+    btp[jp] = jp - best;
+}
+
+__global__ void k_ne_fix_last(uint64_t *__restrict__ boundaries, const unsigned long long *__restrict__ result)
+{
+    // the shared backtrack emits n as last boundary (elastic convention); segment() ends at n-1 (fbg.cpp:655-656)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && result[0] > 0) boundaries[result[0] - 1] -= 1;
+}
+
 int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s, uint64_t *d_prev,
                       uint64_t *d_boundaries, uint64_t *count_out)
 {
@@ -749,8 +808,66 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
     FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
     uint32_t *s = ctx->dp_g.as<uint32_t>(), *prev = ctx->dp_h.as<uint32_t>();
     unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
-    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 4 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_dp_repeatfree, dim3(1), dim3(64), 0, st, d_v, (uint32_t)n, s, prev, d_boundaries, sc);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 16 * sizeof(unsigned long long), st));
+    bool literal = getenv("FBG_DP_LITERAL") != nullptr;
+    if (!literal) {
+        const size_t w = (n + 2) * 4;
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_a, w));
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_b, w));
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_c, w));
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_e, w));
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_f, w));
+        FBG_TRY(fbg_reserve(ctx, ctx->list, w));
+        uint8_t *ext1 = ctx->dp_e.as<uint8_t>(), *amin = ctx->dp_f.as<uint8_t>();
+        uint32_t *sp = ctx->dp_a.as<uint32_t>(), *btp = ctx->dp_b.as<uint32_t>(), *rev = ctx->list.as<uint32_t>();
+        uint8_t *Sg = ctx->dp_c.as<uint8_t>();
+        hipLaunchKernelGGL(k_ne_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, d_v, (uint32_t)n, ext1, amin, sc);
+        unsigned long long hk[5];
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        const unsigned long long bound = 2 * hk[3] + 2;
+        const int R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 254 ? 4 : 0;
+        if (R == 0) {
+            literal = true;
+        } else {
+            const uint32_t WN = 64u * R;
+            const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN), Fg = 4, ngroups = (nblocks + Fg - 1) / Fg;
+            FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
+            uint8_t *Wt = ctx->tmp.as<uint8_t>();
+            const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
+            const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
+#define FBG_NE_PIPE(RR)                                                                                                   \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_blockW<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (lds2 > 64 * 1024)                                                                                            \
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_compose<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext1, amin, (uint32_t)n, nblocks, Wt);  \
+        hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
+        hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, sp, sc);         \
+        hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, sp, sc + 8); \
+    } while (0)
+            if (R == 1) FBG_NE_PIPE(1);
+            else if (R == 2) FBG_NE_PIPE(2);
+            else FBG_NE_PIPE(4);
+#undef FBG_NE_PIPE
+            hipLaunchKernelGGL(k_ne_finish, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, sp, amin, (uint32_t)n, WN, s, prev,
+                               btp, sc);
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (hk[4] != 0) {
+                literal = true;   // window too small for this input: statement-by-statement kernel
+                FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned long long), st));
+            } else {
+                // no proper segmentation <=> the last prefix has no value (fbg.cpp:648-652)
+                hipLaunchKernelGGL(k_dp_backtrack_wave, dim3(1), dim3(64), 0, st, btp, (uint32_t)n, rev, sc);
+                hipLaunchKernelGGL(k_reverse_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, rev, sc, d_boundaries);
+                hipLaunchKernelGGL(k_ne_fix_last, dim3(1), dim3(64), 0, st, d_boundaries, sc);
+            }
+        }
+    }
+    if (literal)
+        hipLaunchKernelGGL(k_dp_repeatfree, dim3(1), dim3(64), 0, st, d_v, (uint32_t)n, s, prev, d_boundaries, sc);
     if (d_s) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, s, n, d_s, 0);
     if (d_prev) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, prev, n, d_prev, 0);
     FBG_HIP_TRY(ctx, hipGetLastError());
