@@ -332,3 +332,21 @@ def test_full_size_properties(engine):
     assert int(b[-1]) == n2 - 1
     starts = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), b[:-1] + 1])
     assert bool((starts <= d_v[b]).all())                # block [start..end] is repeat-free iff start <= v[end]
+
+
+@pytest.mark.parametrize("max_len", [1, 3, 20, 31, 40, 100, 126, 200, 400])
+def test_nonelastic_dp_random_v(engine, max_len):
+    """s[]/prev[]/boundaries of fbg.cpp:616-664 for arbitrary v[] (valid, invalid and non-monotone entries):
+    block-matrix path for short blocks, statement-by-statement kernel beyond its window."""
+    rng = np.random.default_rng(900 + max_len)
+    for n in (1, 2, 64, 65, 700, 3000):
+        j = np.arange(n)
+        v = np.maximum(0, j + 1 - rng.integers(1, max_len + 1, n))        # block [v..j] of 1..max_len columns
+        v = np.where(rng.random(n) < 0.1, j + 1, v).astype(np.uint64)       # 10% of the ends have no valid block
+        s, prev, b = O.segment_dp(v)
+        gs, gprev, gb = engine.repeatfree_dp(v)
+        assert np.array_equal(gs, s), (n, np.flatnonzero(gs != s)[:5])
+        assert np.array_equal(gprev, prev), (n, np.flatnonzero(gprev != prev)[:5])
+        assert (b is None) == (gb is None)
+        if b is not None:
+            assert np.array_equal(gb, b)
