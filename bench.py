@@ -193,7 +193,10 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        scan_ms = stage_acc["scan"][0] / max(1, args.steps)            # one launch per step
+        # the extension scan is k_rank_scan (rank order, inside the index build) for gap-free MSAs,
+        # k_scan_stream (text order) otherwise; one launch per step either way
+        ranked = stage_acc.get("rank_kernel", [0.0, 0])[1] > 0
+        scan_ms = (stage_acc["rank_kernel"][0] if ranked else stage_acc["scan"][0]) / max(1, args.steps)
         scan_bytes = (13 * scan_rows + 8) * scan_cols
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
@@ -204,7 +207,7 @@ def main():
             "config": {"workload": f"synthetic {m} rows x {n} cols iid ACGT (seed 0x5EED0001), --elastic"
                                    f"{'' if world == 1 else f', {args.cols_per_gpu} columns per GPU, {mode}'}",
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
-            "roofline": {"bound": "hbm", "kernel": "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_rank_scan" if ranked else "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": measured_traffic(scan_rows, scan_cols) if world == 1 else None,
                          "traffic_source": "profiles/r01_pmc_scan_stream.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libfbg_hip.so")
 
 FBG_OK, FBG_ERR_INVALID, FBG_ERR_NO_SEGMENTATION, FBG_ERR_OOM, FBG_ERR_HIP, FBG_ERR_TOO_LARGE, \
     FBG_ERR_NO_DEVICE = range(7)
-STAGES = ("text", "suffix_sort", "lcp", "tile", "scan", "dp")
+STAGES = ("text", "suffix_sort", "lcp", "rank_scan", "scan", "dp", "rank_kernel")
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
 vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)

@@ -104,7 +104,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->rec,
-                      &ctx->xlist, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
+                      &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
                       &ctx->list, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d};
@@ -156,7 +156,8 @@ int fbg_release_scratch(fbg_ctx *ctx)
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // valsB stays: it is the suffix array
-    DevBuf *bufs[] = {&ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list,
+    // keysB stays as well: the rank-order index reads the sorted keys
+    DevBuf *bufs[] = {&ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
@@ -352,7 +353,16 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     size_t N = ctx->N;
     if (text) FBG_HIP_TRY(ctx, hipMemcpyAsync(text, ctx->text.p, N, hipMemcpyDeviceToHost, ctx->stream));
     if (sa) FBG_HIP_TRY(ctx, hipMemcpyAsync(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (isa || lcp_prev || lcp_next) {
+    if ((isa || lcp_prev || lcp_next) && ctx->ranked) {
+        // rank-order index: no per-position records exist; derive the three arrays from the sorted keys once
+        FBG_TRY(fbg_reserve(ctx, ctx->io_a, N * 4));
+        FBG_TRY(fbg_reserve(ctx, ctx->io_b, N * 4));
+        FBG_TRY(fbg_reserve(ctx, ctx->io_c, N * 4));
+        FBG_TRY(fbg_rank_materialize(ctx, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>()));
+        if (isa) FBG_HIP_TRY(ctx, hipMemcpyAsync(isa, ctx->io_a.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (lcp_prev) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_prev, ctx->io_b.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (lcp_next) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_next, ctx->io_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (isa || lcp_prev || lcp_next) {
         // records {rank, lcp_prev|hint, lcp_next|hint, -}: pull one word column at a time (strided 2-D copy)
         uint32_t *dst[3] = {isa, lcp_prev, lcp_next};
         for (int w = 0; w < 3; w++) {

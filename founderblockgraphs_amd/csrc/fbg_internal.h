@@ -50,6 +50,13 @@ struct fbg_ctx {
     bool lcp_from_keys = false; // neighbour LCPs came from the sorted keys (few ties) or from text compares
     DevBuf colT;               // u32[N]: MSA column of each text position (gapped MSAs only)
     DevBuf xlist;              // u32[n+1]: columns whose coloured ranks may contain consecutive integers
+    // rank-order scan (rank_scan.hip): valid when `ranked`
+    bool ranked = false;
+    DevBuf gmax, excol, xslot; // u32[n+1]: column maxima of g, exception flags, exception slots
+    DevBuf exc;                // uint4[n_exc * m]: (rank, lcp_prev, lcp_next) of the rows of the exception columns
+    uint32_t n_exc = 0;
+    const uint64_t *rk_keys = nullptr;
+    int rk_b = 0, rk_key_bits = 0, rk_K = 0;
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tmp, small, scalars;
@@ -83,6 +90,11 @@ int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);
 int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len);  // text_build.hip
 int fbg_suffix_sort(fbg_ctx *ctx);                                            // suffix_sort.hip
 int fbg_neighbour_lcp(fbg_ctx *ctx);                                          // lcp.hip
+int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b, int key_bits, int K,
+                      int *done);                                             // rank_scan.hip
+int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out);
+int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
+#define FBG_STAGE_RANKSCAN FBG_STAGE_TILE
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
                      uint64_t *d_out);                                        // scan.hip
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,

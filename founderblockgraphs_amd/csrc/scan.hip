@@ -31,6 +31,7 @@
 
 struct ScanArgs {
     const uint4 *rec;
+    const uint4 *exc;                           // rank-order index: dense rows of the exception columns, else nullptr
     const uint32_t *prow, *igrow;               // row-major per-cell tables (gapped / ignore chars), optional
     const uint32_t *pos, *tot, *colT;           // per-row / per-text-position tables
     uint64_t m, n, N;
@@ -133,13 +134,14 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_exceptions(ScanArgs a, uint
 
     for (uint64_t c = blockIdx.x; c < ncols; c += gridDim.x) {
         const uint64_t x = a.xlist[c];
+        if (x < a.x0 || x >= a.x1) continue;       // block-uniform: outside the requested column range
         for (uint32_t s = tid; s < a.H; s += SC_THREADS) hkey[s] = SC_EMPTY;
         __syncthreads();
 
         // ---- load the column, colour the active rows, insert their ranks -------------------
         for (uint32_t i = tid; i < m; i += SC_THREADS) {
             const uint32_t p = cell_ptr(a, i, x);
-            const uint4 r4 = a.rec[p];
+            const uint4 r4 = a.exc ? a.exc[c * a.m + i] : a.rec[p];
             uint32_t r = r4.x;
             vL[i] = r4.y & FBG_LCP_MASK;
             vR[i] = r4.z & FBG_LCP_MASK;
@@ -242,13 +244,39 @@ int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disab
                         (unsigned long long)ctx->m);
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SCAN));
     int launches = 0;
-    if (x1 > x0) {
+    if (x1 > x0 && ctx->ranked) {
+        // rank-order index: column maxima are ready, only the exception columns need the per-column kernel
+        hipStream_t st = ctx->stream;
+        FBG_TRY(fbg_rank_finish(ctx, x0, x1, mode, disable_tricks, d_out));
+        launches++;
+        if (ctx->n_exc > 0) {
+            ScanArgs a;
+            a.rec = nullptr; a.exc = ctx->exc.as<uint4>();
+            a.prow = nullptr; a.igrow = nullptr;
+            a.pos = ctx->pos.as<uint32_t>(); a.tot = ctx->tot.as<uint32_t>(); a.colT = nullptr;
+            a.m = ctx->m; a.n = ctx->n; a.N = ctx->N;
+            a.mode = mode; a.disable_tricks = disable_tricks; a.reversed = ctx->reversed;
+            a.x0 = x0; a.x1 = x1; a.out = d_out;
+            a.xlist = ctx->xlist.as<uint32_t>(); a.xcount = nullptr;
+            uint32_t logH = 7;
+            while ((1u << logH) < 2 * ctx->m) logH++;
+            a.H = 1u << logH; a.logH = logH;
+            const size_t lds = (size_t)a.H * 6 + (size_t)a.m * 20;
+            if (lds > 150 * 1024) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel LDS budget exceeded (%zu bytes)", lds);
+            if (lds > 64 * 1024)
+                FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_scan_exceptions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_scan_exceptions, dim3(fbg_blocks(ctx->n_exc, 1, 256 * 8)), dim3(SC_THREADS), lds, st, a,
+                               (uint64_t)ctx->n_exc);
+            launches++;
+        }
+        FBG_HIP_TRY(ctx, hipGetLastError());
+    } else if (x1 > x0) {
         hipStream_t st = ctx->stream;
         FBG_TRY(fbg_reserve(ctx, ctx->xlist, (ctx->n + 1) * 4));
         unsigned long long *xcount = ctx->scalars.as<unsigned long long>() + 24;
         FBG_HIP_TRY(ctx, hipMemsetAsync(xcount, 0, sizeof(unsigned long long), st));
         ScanArgs a;
-        a.rec = ctx->rec.as<uint4>();
+        a.rec = ctx->rec.as<uint4>(); a.exc = nullptr;
         a.prow = ctx->gapfree ? nullptr : ctx->prow.as<uint32_t>();
         a.igrow = (mode == FBG_SCAN_F && ctx->have_ignore) ? ctx->igrow.as<uint32_t>() : nullptr;
         a.pos = ctx->pos.as<uint32_t>(); a.tot = ctx->tot.as<uint32_t>();

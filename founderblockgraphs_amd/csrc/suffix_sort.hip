@@ -281,14 +281,11 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->valsB, N * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->flags, N));
-    FBG_TRY(fbg_reserve(ctx, ctx->rec, N * 16));
     uint64_t *keysA = ctx->keysA.as<uint64_t>(), *keysB = ctx->keysB.as<uint64_t>();
     uint32_t *valsA = ctx->valsA.as<uint32_t>(), *valsB = ctx->valsB.as<uint32_t>();
-    uint32_t *grp = ctx->grp.as<uint32_t>();
-    uint4 *rec = ctx->rec.as<uint4>();
-    uint8_t *flags = ctx->flags.as<uint8_t>();
+    uint32_t *grp = nullptr;
+    uint4 *rec = nullptr;
+    uint8_t *flags = nullptr;
     unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
     uint32_t *sa = valsB;                     // the sorted positions ARE the suffix array
     ctx->sa_ptr = sa;
@@ -304,6 +301,20 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
         return rocprim::radix_sort_pairs(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, 0u, (unsigned)key_bits, st);
     }));
+    {   // gap-free MSAs: the whole extension scan can be done right here, in rank order (rank_scan.hip)
+        int done = 0;
+        FBG_TRY(fbg_rank_scan_try(ctx, keysB, valsB, b, key_bits, K, &done));
+        if (done) {
+            FBG_HIP_TRY(ctx, hipGetLastError());
+            return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
+        }
+    }
+    FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->flags, N));
+    FBG_TRY(fbg_reserve(ctx, ctx->rec, N * 16));
+    grp = ctx->grp.as<uint32_t>();
+    rec = ctx->rec.as<uint4>();
+    flags = ctx->flags.as<uint8_t>();
     // groups of equal keys -> records (rank = SA index of the group head, key-derived LCPs), unresolved flags
     hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keysB, N, (const uint32_t *)nullptr, grp);
     FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {

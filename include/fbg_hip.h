@@ -49,9 +49,11 @@ enum {
     FBG_STAGE_TEXT = 0,      /* MSA -> gap-stripped text + per-row tables (fbg.cpp:372-386,1845-1917) */
     FBG_STAGE_SUFFIX_SORT,   /* suffix array + inverse (sdsl::construct, fbg.cpp:428) */
     FBG_STAGE_LCP,           /* per-position LCP with SA predecessor / successor */
-    FBG_STAGE_TILE,          /* (unused since the record layout: always 0) */
+    FBG_STAGE_TILE,          /* rank-order extension scan (gap-free MSAs; runs inside fbg_index_build; its time
+                                is also contained in FBG_STAGE_SUFFIX_SORT) */
     FBG_STAGE_SCAN,          /* compute_f / v[] column scan (fbg.cpp:1579-1695, 552-611) */
     FBG_STAGE_DP,            /* bucket pass + DP sweep + backtrack (fbg.cpp:1940-2039, 616-664) */
+    FBG_STAGE_RANK_KERNEL,   /* the k_rank_scan launch alone (1 launch), for roofline accounting */
     FBG_STAGE_COUNT
 };
 
