@@ -104,7 +104,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->rec,
-                      &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
+                      &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->xbits, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
                       &ctx->list, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d};

@@ -53,6 +53,7 @@ struct fbg_ctx {
     // rank-order scan (rank_scan.hip): valid when `ranked`
     bool ranked = false;
     DevBuf gmax, excol, xslot; // u32[n+1]: column maxima of g, exception flags, exception slots
+    DevBuf xbits;              // bitmap of the exception columns
     DevBuf exc;                // uint4[n_exc * m]: (rank, lcp_prev, lcp_next) of the rows of the exception columns
     uint32_t n_exc = 0;
     const uint64_t *rk_keys = nullptr;

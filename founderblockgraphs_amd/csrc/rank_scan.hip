@@ -31,6 +31,8 @@ __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, in
 }
 
 struct RankArgs {
+    uint64_t magic;            // floor(2^64 / row_len) + 1: p / row_len == umul64hi(p, magic) for p < 2^32
+    const uint32_t *xbits;     // bitmap of the exception columns (k_exc_collect)
     const uint64_t *keys;      // sorted round-0 keys
     uint32_t *vals;            // positions in SA order (final once the tie groups are ordered)
     const uint8_t *T;
@@ -47,7 +49,7 @@ struct RankArgs {
 __device__ __forceinline__ uint32_t rs_col(const RankArgs &a, uint32_t p)
 {
     if (p == a.N - 1) return (uint32_t)a.n;
-    const uint32_t c = p % a.row_len;
+    const uint32_t c = p - (uint32_t)__umul64hi((uint64_t)p, a.magic) * a.row_len;    // p mod (n+1)
     if (c == a.n) return c;
     return a.reversed ? (uint32_t)a.n - 1 - c : c;
 }
@@ -61,25 +63,56 @@ __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint3
 __global__ __launch_bounds__(256) void k_rank_scan(RankArgs a)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.N) return;
-    const uint64_t key = a.keys[k];
-    const uint64_t kp = k > 0 ? a.keys[k - 1] : ~key, kn = k + 1 < a.N ? a.keys[k + 1] : ~key;
-    if (kp == key || kn == key) {                      // ties on all K symbols: ordered later
-        const unsigned long long slot = atomicAdd(&a.counters[0], 1ull);
-        if (slot < a.N / 32 + 1) a.ties[slot] = (uint32_t)k;
-        return;
-    }
-    const uint32_t p = a.vals[k];
+    const bool in = k < a.N;
+    const int lane = threadIdx.x & 63;
+    const uint64_t key = in ? a.keys[k] : 0ull;
+    const uint32_t p = in ? a.vals[k] : (uint32_t)(a.N - 1);
     const uint32_t col = rs_col(a, p);
+    // keys / columns of the SA neighbours: adjacent lanes, one extra load at the wave's edges
+    uint64_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
+    uint32_t cp = __shfl_up(col, 1, 64), cn = __shfl_down(col, 1, 64);
+    if (!in) return;
+    if (lane == 0) { kp = k > 0 ? a.keys[k - 1] : ~key; cp = k > 0 ? rs_col(a, a.vals[k - 1]) : (uint32_t)a.n; }
+    if (lane == 63 || k + 1 == a.N) {
+        kn = k + 1 < a.N ? a.keys[k + 1] : ~key;
+        cn = k + 1 < a.N ? rs_col(a, a.vals[k + 1]) : (uint32_t)a.n;
+    }
+    const bool tie = kp == key || kn == key;           // ties on all K symbols: ordered later
+    const unsigned long long tmask = __ballot(tie);
+    if (tmask) {                                       // one counter update per wave
+        unsigned long long base = 0;
+        const int leader = __ffsll((long long)tmask) - 1;
+        if (lane == leader) base = atomicAdd(&a.counters[0], (unsigned long long)__popcll(tmask));
+        base = __shfl(base, leader, 64);
+        if (tie) {
+            const unsigned long long slot = base + __popcll(tmask & ((1ull << lane) - 1));
+            if (slot < a.N / 32 + 1) a.ties[slot] = (uint32_t)k;
+            return;
+        }
+    }
     if (col == a.n) return;
     const uint32_t lp = k > 0 ? rs_key_lcp(kp, key, a.b, a.key_bits) : 0u;
     const uint32_t ln = k + 1 < a.N ? rs_key_lcp(key, kn, a.b, a.key_bits) : 0u;
     rs_update(a, col, max(lp, ln) + 1);
     // run hint (fbg.cpp:1633-1641): an SA neighbour that is the row pointer of another row in this column
-    bool hint = false;
-    if (k > 0) hint |= rs_col(a, a.vals[k - 1]) == col;
-    if (k + 1 < a.N) hint |= rs_col(a, a.vals[k + 1]) == col;
-    if (hint) a.excol[col] = 1;
+    if (cp == col || cn == col) a.excol[col] = 1;
+}
+
+// cheap regime test: ties among every 64th block of 256 SA slots
+__global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__ keys, uint64_t N,
+                                                    unsigned long long *__restrict__ counters)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 64 * 256 + threadIdx.x;
+    bool tie = false;
+    if (k < N) {
+        const uint64_t key = keys[k];
+        tie = (k > 0 && keys[k - 1] == key) || (k + 1 < N && keys[k + 1] == key);
+    }
+    const unsigned long long mask = __ballot(tie);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counters[2], (unsigned long long)__popcll(mask));
+        atomicAdd(&counters[3], 64ull);
+    }
 }
 
 // heads[t] = 1 when ties[t] (sorted) starts a group of consecutive SA slots with one key
@@ -170,7 +203,7 @@ __global__ __launch_bounds__(256) void k_exc_collect(RankArgs a, const uint32_t 
     if (k >= a.N) return;
     const uint32_t p = a.vals[k];
     const uint32_t col = rs_col(a, p);
-    if (col == a.n || !a.excol[col]) return;
+    if (col == a.n || !((a.xbits[col >> 5] >> (col & 31)) & 1u)) return;
     const uint64_t key = a.keys[k];
     uint32_t lp = 0, ln = 0;
     if (k > 0) {
@@ -183,7 +216,7 @@ __global__ __launch_bounds__(256) void k_exc_collect(RankArgs a, const uint32_t 
         ln = kq != key ? rs_key_lcp(key, kq, a.b, a.key_bits)
                        : fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)p + a.K, (uint64_t)a.vals[k + 1] + a.K, 0) + (uint32_t)a.K);
     }
-    const uint64_t row = p / a.row_len;
+    const uint64_t row = __umul64hi((uint64_t)p, a.magic);
     exc[(uint64_t)slot[col] * m + row] = make_uint4((uint32_t)k, lp, ln, 0u);
 }
 
@@ -214,10 +247,14 @@ __global__ void k_rank_finish(FinishArgs a)
 }
 
 __global__ void k_iota_if(const uint32_t *__restrict__ excol, const uint32_t *__restrict__ slot, uint64_t n,
-                          uint32_t *__restrict__ xlist)
+                          uint32_t *__restrict__ xlist, uint32_t *__restrict__ xbits)
 {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < n && excol[x]) xlist[slot[x]] = (uint32_t)x;
+    const bool e = x < n && excol[x];
+    if (e) xlist[slot[x]] = (uint32_t)x;
+    const unsigned long long bal = __ballot(e);
+    if ((threadIdx.x & 31) == 0 && x < n + 32)       // two 32-bit words per wave
+        xbits[x >> 5] = (uint32_t)(bal >> (threadIdx.x & 32));
 }
 
 template <class F> static int rs_with_tmp(fbg_ctx *ctx, F &&call)
@@ -245,6 +282,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->excol, (n + 1) * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->xslot, (n + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->xbits, (n / 32 + 4) * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->xlist, (n + 1) * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->list, (N / 32 + 2) * 4));
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
@@ -254,9 +292,18 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     RankArgs a;
     a.keys = keys; a.vals = vals; a.T = ctx->text.as<uint8_t>();
     a.N = N; a.n = n; a.row_len = (uint32_t)(n + 1);
+    a.magic = ~0ull / (n + 1) + 1;
+    a.xbits = ctx->xbits.as<uint32_t>();
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>(); a.excol = ctx->excol.as<uint32_t>();
     a.ties = ctx->list.as<uint32_t>(); a.counters = cnt;
+    if (N > (1u << 22)) {   // similar rows tie almost everywhere: do not even try the rank-order scan then
+        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(N, 64 * 256)), dim3(256), 0, st, keys, N, cnt);
+        unsigned long long hs[4];
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (hs[2] * 16 > hs[3]) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, 1);
+    }
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     hipLaunchKernelGGL(k_rank_scan, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
@@ -296,8 +343,8 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     ctx->n_exc = ne;
     if (ne > 0) {
         FBG_TRY(fbg_reserve(ctx, ctx->exc, (size_t)ne * m * 16));
-        hipLaunchKernelGGL(k_iota_if, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.excol, ctx->xslot.as<uint32_t>(), n,
-                           ctx->xlist.as<uint32_t>());
+        hipLaunchKernelGGL(k_iota_if, dim3(fbg_blocks(n + 32, 256)), dim3(256), 0, st, a.excol, ctx->xslot.as<uint32_t>(), n,
+                           ctx->xlist.as<uint32_t>(), ctx->xbits.as<uint32_t>());
         hipLaunchKernelGGL(k_exc_collect, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a, ctx->xslot.as<uint32_t>(), m,
                            ctx->exc.as<uint4>());
         launches += 2;
@@ -325,6 +372,7 @@ int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_isa, uint32_t *d_pl, uint32_t
     RankArgs a;
     a.keys = ctx->rk_keys; a.vals = ctx->sa_ptr; a.T = ctx->text.as<uint8_t>();
     a.N = ctx->N; a.n = ctx->n; a.row_len = (uint32_t)(ctx->n + 1);
+    a.magic = ~0ull / (ctx->n + 1) + 1; a.xbits = nullptr;
     a.b = ctx->rk_b; a.key_bits = ctx->rk_key_bits; a.K = ctx->rk_K; a.reversed = ctx->reversed;
     a.gmax = nullptr; a.excol = nullptr; a.ties = nullptr; a.counters = nullptr;
     hipLaunchKernelGGL(k_rank_materialize, dim3(fbg_blocks(ctx->N, 256)), dim3(256), 0, ctx->stream, a, d_isa, d_pl, d_pr);
