@@ -107,7 +107,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
                       &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->xbits, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
                       &ctx->list, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
-                      &ctx->io_c, &ctx->io_d};
+                      &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     for (auto &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);

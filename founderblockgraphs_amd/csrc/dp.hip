@@ -547,6 +547,50 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
     if (lane == 0) { result[0] = err ? 0 : cnt; result[1] = err ? 1 : 0; }
 }
 
+// ---- parallel backtrack (fbg.cpp:2026-2039) by binary lifting --------------------------------------
+// backtrack[] is a forest towards column 0.  up[k][j] = the column reached from j after 2^k hops (0 absorbs),
+// dep[j] = number of hops from j to 0.  The boundary list of the reference, [.., backtrack-1, .., n], has
+// dep[n] entries; entry t is found independently by jumping dep[n]-1-t hops from n.
+__global__ void k_bt_lift0(const uint32_t *__restrict__ bt, uint32_t n, uint32_t *__restrict__ up0,
+                           uint32_t *__restrict__ dep)
+{
+    // index n+1 is a dead end that absorbs every pointer that is not a backward pointer (columns without a
+    // value, fbg.cpp:2004-2009 with backtrack_S still -1, or the non-elastic "no valid range" marker)
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n + 1) return;
+    if (j == n + 1) { up0[j] = j; dep[j] = 0; return; }
+    const uint32_t b = j == 0 ? 0u : bt[j];
+    up0[j] = (b >= j && j != 0) ? n + 1 : b;
+    dep[j] = j == 0 ? 0u : 1u;
+}
+
+__global__ void k_bt_lift(const uint32_t *__restrict__ up_prev, const uint32_t *__restrict__ dep_prev, uint32_t n,
+                          uint32_t *__restrict__ up_next, uint32_t *__restrict__ dep_next)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n + 1) return;
+    const uint32_t a = up_prev[j];
+    up_next[j] = up_prev[a];
+    dep_next[j] = dep_prev[j] + dep_prev[a];      // hops counted so far: exact once the chain reaches 0
+}
+
+__global__ void k_bt_emit(const uint32_t *__restrict__ up, const uint32_t *__restrict__ dep_final, uint32_t n,
+                          uint32_t levels, uint64_t *__restrict__ boundaries, unsigned long long *__restrict__ result)
+{
+    // the chain from n is valid iff it ends in column 0 and not in the dead end
+    uint32_t e = n;
+    for (uint32_t k = 0; k < levels; k++) e = up[(size_t)k * (n + 2) + e];
+    const bool ok = e == 0;
+    const uint32_t cnt = dep_final[n];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { result[0] = ok ? cnt : 0; result[1] = ok ? 0 : 1; }
+    if (!ok || t >= cnt) return;
+    uint32_t hops = cnt - 1 - t, j = n;
+    for (uint32_t k = 0; k < levels && hops; k++, hops >>= 1)
+        if (hops & 1u) j = up[(size_t)k * (n + 2) + j];
+    boundaries[t] = t == cnt - 1 ? (uint64_t)n : (uint64_t)j - 1;
+}
+
 __global__ void k_reverse_widen(const uint32_t *__restrict__ rev, const unsigned long long *__restrict__ result,
                                 uint64_t *__restrict__ boundaries)
 {
@@ -579,6 +623,29 @@ __global__ void k_widen(const uint32_t *__restrict__ src, uint64_t cnt, uint64_t
     if (k >= cnt) return;
     uint32_t v = src[k];
     dst[k] = (none_is_minus1 && v == DP_NONE) ? ~0ull : (uint64_t)v;
+}
+
+static int fbg_backtrack_lifted(fbg_ctx *ctx, const uint32_t *bt, uint32_t n, uint64_t *d_boundaries,
+                                unsigned long long *sc)
+{
+    hipStream_t st = ctx->stream;
+    uint32_t levels = 1;
+    while ((1ull << (levels - 1)) <= (uint64_t)n) levels++;   // the last table spans 2^(levels-1) > n hops
+    const size_t stride = (size_t)n + 2;
+    FBG_TRY(fbg_reserve(ctx, ctx->bt_up, (size_t)levels * stride * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->bt_dep, 2 * stride * 4));
+    uint32_t *up = ctx->bt_up.as<uint32_t>(), *dep0 = ctx->bt_dep.as<uint32_t>(), *dep1 = dep0 + stride;
+    const unsigned grid = fbg_blocks(stride, 256);
+    hipLaunchKernelGGL(k_bt_lift0, dim3(grid), dim3(256), 0, st, bt, n, up, dep0);
+    uint32_t *dp = dep0, *dn = dep1;
+    for (uint32_t k = 1; k < levels; k++) {
+        hipLaunchKernelGGL(k_bt_lift, dim3(grid), dim3(256), 0, st, up + (size_t)(k - 1) * stride, dp, n,
+                           up + (size_t)k * stride, dn);
+        uint32_t *t = dp; dp = dn; dn = t;
+    }
+    hipLaunchKernelGGL(k_bt_emit, dim3(grid), dim3(256), 0, st, up, dp, n, levels, d_boundaries, sc);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return FBG_OK;
 }
 
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries, uint64_t *count_out,
@@ -693,8 +760,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         hipLaunchKernelGGL(k_dp_minmax, dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, count, bcount, cur, tnext, mml, bt);
         hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
     } else if (tiled) {
-        hipLaunchKernelGGL(k_dp_backtrack_wave, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, tnext, sc);
-        hipLaunchKernelGGL(k_reverse_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, tnext, sc, d_boundaries);
+        FBG_TRY(fbg_backtrack_lifted(ctx, bt, (uint32_t)n, d_boundaries, sc));
     } else {
         hipLaunchKernelGGL(k_dp_backtrack, dim3(1), dim3(64), 0, st, bt, (uint32_t)n, d_boundaries, sc);
     }
@@ -860,8 +926,8 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
                 FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned long long), st));
             } else {
                 // no proper segmentation <=> the last prefix has no value (fbg.cpp:648-652)
-                hipLaunchKernelGGL(k_dp_backtrack_wave, dim3(1), dim3(64), 0, st, btp, (uint32_t)n, rev, sc);
-                hipLaunchKernelGGL(k_reverse_widen, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, rev, sc, d_boundaries);
+                (void)rev;
+                FBG_TRY(fbg_backtrack_lifted(ctx, btp, (uint32_t)n, d_boundaries, sc));
                 hipLaunchKernelGGL(k_ne_fix_last, dim3(1), dim3(64), 0, st, d_boundaries, sc);
             }
         }

@@ -62,6 +62,7 @@ struct fbg_ctx {
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tmp, small, scalars;
     DevBuf dp_a, dp_b, dp_c, dp_d, dp_e, dp_f, dp_g, dp_h, io_a, io_b, io_c, io_d;
+    DevBuf bt_up, bt_dep;      // binary-lifting tables of the parallel backtrack
 
     StageTimer timers[FBG_STAGE_COUNT];
 };

@@ -98,11 +98,11 @@ __global__ __launch_bounds__(256) void k_rank_scan(RankArgs a)
     if (cp == col || cn == col) a.excol[col] = 1;
 }
 
-// cheap regime test: ties among every 64th block of 256 SA slots
+// cheap regime test: ties among every 1024th block of 256 SA slots
 __global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__ keys, uint64_t N,
                                                     unsigned long long *__restrict__ counters)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * 64 * 256 + threadIdx.x;
+    const uint64_t k = (uint64_t)blockIdx.x * 1024 * 256 + threadIdx.x;
     bool tie = false;
     if (k < N) {
         const uint64_t key = keys[k];
@@ -298,7 +298,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     a.gmax = ctx->gmax.as<uint32_t>(); a.excol = ctx->excol.as<uint32_t>();
     a.ties = ctx->list.as<uint32_t>(); a.counters = cnt;
     if (N > (1u << 22)) {   // similar rows tie almost everywhere: do not even try the rank-order scan then
-        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(N, 64 * 256)), dim3(256), 0, st, keys, N, cnt);
+        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(N, 1024 * 256)), dim3(256), 0, st, keys, N, cnt);
         unsigned long long hs[4];
         FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
