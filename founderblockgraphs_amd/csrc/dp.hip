@@ -663,7 +663,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     FBG_TRY(fbg_reserve(ctx, ctx->dp_g, w));   // mml
     FBG_TRY(fbg_reserve(ctx, ctx->dp_h, w));   // bt
     FBG_TRY(fbg_reserve(ctx, ctx->list, w));   // tnext
-    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 256 * sizeof(unsigned long long)));
     uint32_t *e = ctx->dp_a.as<uint32_t>(), *bstart = ctx->dp_b.as<uint32_t>(), *cur = ctx->dp_c.as<uint32_t>(),
              *items = ctx->dp_d.as<uint32_t>(), *count = ctx->dp_e.as<uint32_t>(), *bcount = ctx->dp_f.as<uint32_t>(),
              *mml = ctx->dp_g.as<uint32_t>(), *bt = ctx->dp_h.as<uint32_t>(), *tnext = ctx->list.as<uint32_t>();
@@ -871,7 +871,7 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_DP));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_g, (n + 2) * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_h, (n + 2) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 256 * sizeof(unsigned long long)));
     uint32_t *s = ctx->dp_g.as<uint32_t>(), *prev = ctx->dp_h.as<uint32_t>();
     unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
     FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 16 * sizeof(unsigned long long), st));

@@ -184,7 +184,7 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     int launches = 0;
     FBG_TRY(fbg_reserve(ctx, ctx->pos, m * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->tot, m * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 64 * sizeof(unsigned long long)));
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 256 * sizeof(unsigned long long)));
     FBG_TRY(fbg_reserve(ctx, ctx->small, 4096));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->scalars.p, 0, 64 * sizeof(unsigned long long), st));
 
