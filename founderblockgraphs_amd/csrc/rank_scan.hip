@@ -23,10 +23,14 @@
 #include "text_cmp.h"
 #include <rocprim/rocprim.hpp>
 
+// number of equal leading symbols of two keys: (leading equal bits) / b, the division as a multiply-shift
+// (exact for numerators <= 64: inv_b = ceil(2^16 / b))
 __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
 {
     const uint64_t d = a ^ c;
-    return (uint32_t)((__clzll((long long)d) - (64 - key_bits)) / b);
+    const uint32_t bits = (uint32_t)(__clzll((long long)d) - (64 - key_bits));
+    const uint32_t inv_b = (65536u + (uint32_t)b - 1) / (uint32_t)b;   // hoisted: b is uniform
+    return (bits * inv_b) >> 16;
 }
 
 struct RankArgs {
@@ -59,34 +63,32 @@ __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint3
     if (a.gmax[col] < g) atomicMax(&a.gmax[col], g);
 }
 
-__global__ __launch_bounds__(256) void k_rank_scan(RankArgs a)
+__device__ __forceinline__ void rank_scan_slot(const RankArgs &a, const uint64_t k)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = k < a.N;
     const int lane = threadIdx.x & 63;
     const uint64_t key = in ? a.keys[k] : 0ull;
     const uint32_t p = in ? a.vals[k] : (uint32_t)(a.N - 1);
     const uint32_t col = rs_col(a, p);
-    // keys / columns of the SA neighbours (one and two slots away): adjacent lanes, extra loads at the wave's edges
+    // keys / columns of the SA neighbours: adjacent lanes, extra loads at the wave's edges
     uint64_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
-    uint64_t kpp = __shfl_up(key, 2, 64), knn = __shfl_down(key, 2, 64);
     uint32_t cp = __shfl_up(col, 1, 64), cn = __shfl_down(col, 1, 64);
+    if (lane == 0 && in) { kp = k > 0 ? a.keys[k - 1] : ~key; cp = k > 0 ? rs_col(a, a.vals[k - 1]) : (uint32_t)a.n; }
+    if (lane == 63 || k + 1 >= a.N) {
+        kn = k + 1 < a.N ? a.keys[k + 1] : ~key;
+        cn = k + 1 < a.N ? rs_col(a, a.vals[k + 1]) : (uint32_t)a.n;
+    }
+    const bool tie = in && (kp == key || kn == key);
+    // is a neighbour slot a tie?  one ballot; the wave's edge lanes look one key further
+    const unsigned long long tmask = __ballot(tie);
+    bool tie_prev = lane > 0 ? (tmask >> (lane - 1)) & 1ull : false;
+    bool tie_next = lane < 63 ? (tmask >> (lane + 1)) & 1ull : false;
+    if (lane == 0 && in && k > 0) tie_prev = kp == key || (k > 1 && a.keys[k - 2] == kp);
+    if (lane == 63 && in && k + 1 < a.N) tie_next = kn == key || (k + 2 < a.N && a.keys[k + 2] == kn);
     if (!in) return;
-    if (lane < 2) {
-        if (lane == 0) { kp = k > 0 ? a.keys[k - 1] : ~key; cp = k > 0 ? rs_col(a, a.vals[k - 1]) : (uint32_t)a.n; }
-        kpp = k > 1 ? a.keys[k - 2] : ~kp;
-    }
-    if (lane > 61 || k + 2 >= a.N) {
-        if (lane == 63 || k + 1 >= a.N) {
-            kn = k + 1 < a.N ? a.keys[k + 1] : ~key;
-            cn = k + 1 < a.N ? rs_col(a, a.vals[k + 1]) : (uint32_t)a.n;
-        }
-        knn = k + 2 < a.N ? a.keys[k + 2] : ~kn;
-    }
     // candidate: ties (order not final yet), neighbours of ties (their neighbour is not final yet), and
     // slots with a same-column neighbour (runs, fbg.cpp:1633-1641)
-    const bool tie = kp == key || kn == key;
-    const bool near_tie = (k > 0 && kpp == kp) || (k + 1 < a.N && knn == kn);
+    const bool near_tie = tie_prev || tie_next;
     const bool run = col != a.n && (cp == col || cn == col);
     const bool cand = tie || (col != a.n && (near_tie || run));
     const unsigned long long cmask = __ballot(cand);
@@ -108,6 +110,14 @@ __global__ __launch_bounds__(256) void k_rank_scan(RankArgs a)
     // near the end of a row few suffixes compete and extensions stay short: no threshold there
     const uint32_t c_raw = a.reversed ? (uint32_t)a.n - 1 - col : col;
     if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
+}
+
+// a few thousand workgroups, each walking 256-slot chunks of the SA (a launch of N/256 tiny workgroups spends
+// more time being dispatched than working)
+__global__ __launch_bounds__(256) void k_rank_scan(RankArgs a)
+{
+    const uint64_t nchunks = (a.N + 255) / 256;
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) rank_scan_slot(a, c * 256 + threadIdx.x);
 }
 
 // cheap regime test + extension histogram over every 1024th block of 256 SA slots:
@@ -341,7 +351,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
         }
     }
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    hipLaunchKernelGGL(k_rank_scan, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rank_scan, dim3(fbg_blocks(N, 256, 256 * 32)), dim3(256), 0, st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     launches++;
     unsigned long long h[5];
