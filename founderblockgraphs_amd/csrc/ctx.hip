@@ -351,17 +351,20 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     if (!ctx) return FBG_ERR_INVALID;
     if (!ctx->index_valid) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: no index");
     size_t N = ctx->N;
-    if (text) FBG_HIP_TRY(ctx, hipMemcpyAsync(text, ctx->text.p, N, hipMemcpyDeviceToHost, ctx->stream));
-    if (sa) FBG_HIP_TRY(ctx, hipMemcpyAsync(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // test / debugging API: plain blocking copies
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (text) FBG_HIP_TRY(ctx, hipMemcpy(text, ctx->text.p, N, hipMemcpyDeviceToHost));
+    if (sa) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost));
     if ((isa || lcp_prev || lcp_next) && ctx->ranked) {
         // rank-order index: no per-position records exist; derive the three arrays from the sorted keys once
         FBG_TRY(fbg_reserve(ctx, ctx->io_a, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_b, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_c, N * 4));
         FBG_TRY(fbg_rank_materialize(ctx, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>()));
-        if (isa) FBG_HIP_TRY(ctx, hipMemcpyAsync(isa, ctx->io_a.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (lcp_prev) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_prev, ctx->io_b.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (lcp_next) FBG_HIP_TRY(ctx, hipMemcpyAsync(lcp_next, ctx->io_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (isa) FBG_HIP_TRY(ctx, hipMemcpy(isa, ctx->io_a.p, N * 4, hipMemcpyDeviceToHost));
+        if (lcp_prev) FBG_HIP_TRY(ctx, hipMemcpy(lcp_prev, ctx->io_b.p, N * 4, hipMemcpyDeviceToHost));
+        if (lcp_next) FBG_HIP_TRY(ctx, hipMemcpy(lcp_next, ctx->io_c.p, N * 4, hipMemcpyDeviceToHost));
     } else if (isa || lcp_prev || lcp_next) {
         // records {rank, lcp_prev|hint, lcp_next|hint, -}: pull one word column at a time (strided 2-D copy)
         uint32_t *dst[3] = {isa, lcp_prev, lcp_next};

@@ -92,6 +92,8 @@ int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);
 int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len);  // text_build.hip
 int fbg_suffix_sort(fbg_ctx *ctx);                                            // suffix_sort.hip
 int fbg_neighbour_lcp(fbg_ctx *ctx);                                          // lcp.hip
+int fbg_group_sort(fbg_ctx *ctx, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
+                   uint32_t *vals_out, uint64_t N, int top_shift, int *ok);   // group_sort.hip
 int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b, int key_bits, int K,
                       int *done);                                             // rank_scan.hip
 int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out);

@@ -44,6 +44,8 @@ struct RankArgs {
     int b, key_bits, K, reversed;
     uint32_t *gmax;            // per column: max over rows of g (0 = no row pointer seen)
     uint32_t *cand;            // SA slots that need the run treatment (see header)
+    uint32_t *blk_count;       // k_rank_scan: candidates found by each workgroup (its private region of cand[])
+    uint32_t region;           // capacity of one workgroup's region
     uint32_t *pm;              // scratch parallel to cand: prefix minima of the forward walk
     unsigned long long *counters;   // [0] candidates, [1] fallback flag
 };
@@ -92,14 +94,14 @@ __device__ __forceinline__ void rank_scan_slot(const RankArgs &a, const uint64_t
     const bool run = col != a.n && (cp == col || cn == col);
     const bool cand = tie || (col != a.n && (near_tie || run));
     const unsigned long long cmask = __ballot(cand);
-    if (cmask) {                                       // one counter update per wave
-        unsigned long long base = 0;
+    if (cmask) {                                       // one counter update per wave, on the workgroup's own counter
+        uint32_t base = 0;
         const int leader = __ffsll((long long)cmask) - 1;
-        if (lane == leader) base = atomicAdd(&a.counters[0], (unsigned long long)__popcll(cmask));
+        if (lane == leader) base = atomicAdd(&a.blk_count[blockIdx.x], (uint32_t)__popcll(cmask));
         base = __shfl(base, leader, 64);
         if (cand) {
-            const unsigned long long slot = base + __popcll(cmask & ((1ull << lane) - 1));
-            if (slot < a.N / 32 + 1) a.cand[slot] = (uint32_t)k;
+            const uint32_t slot = base + (uint32_t)__popcll(cmask & ((1ull << lane) - 1));
+            if (slot < a.region) a.cand[(size_t)blockIdx.x * a.region + slot] = (uint32_t)k;
             return;
         }
     }
@@ -158,6 +160,14 @@ __global__ void k_count_unfilled(const uint32_t *__restrict__ gmax, uint64_t n, 
     const bool miss = x < n && gmax[x] == 0;
     const unsigned long long mask = __ballot(miss);
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&counters[1 + 3], (unsigned long long)__popcll(mask));   // counters[4]
+}
+
+// candidate regions of the workgroups -> one contiguous list (offsets = exclusive scan of the counts)
+__global__ void k_cand_compact(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ counts,
+                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out)
+{
+    const uint32_t c = counts[blockIdx.x] < region ? counts[blockIdx.x] : region, o = offsets[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) out[o + i] = regions[(size_t)blockIdx.x * region + i];
 }
 
 // second chance for columns the threshold starved: same classification as k_rank_scan, values only
@@ -219,6 +229,17 @@ __device__ __forceinline__ uint32_t rs_slot_lcp(const RankArgs &a, uint64_t k)
     return fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)a.vals[k - 1] + a.K, (uint64_t)a.vals[k] + a.K, 0) + (uint32_t)a.K);
 }
 
+// test / debugging aid (fbg_index_download): inverse suffix array and neighbour LCPs by text position
+__global__ void k_rank_materialize(RankArgs a, uint32_t *isa, uint32_t *pl, uint32_t *pr)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.N) return;
+    const uint32_t p = a.vals[k];
+    isa[p] = (uint32_t)k;
+    pl[p] = rs_slot_lcp(a, k);
+    pr[p] = rs_slot_lcp(a, k + 1);
+}
+
 // candidates (sorted, final SA order): one thread per run head walks its run of same-column slots
 __global__ void k_runs(RankArgs a, uint64_t T)
 {
@@ -242,27 +263,6 @@ __global__ void k_runs(RankArgs a, uint64_t T)
         rmin = min(rmin, rs_slot_lcp(a, (uint64_t)k0 + i + 1));
         rs_update(a, col, max(a.pm[t + i], rmin) + 1);
     }
-}
-
-// test / debugging aid (fbg_index_download): inverse suffix array and neighbour LCPs by text position
-__global__ void k_rank_materialize(RankArgs a, uint32_t *__restrict__ isa, uint32_t *__restrict__ pl, uint32_t *__restrict__ pr)
-{
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.N) return;
-    const uint32_t p = a.vals[k];
-    const uint64_t key = a.keys[k];
-    uint32_t lp = 0, ln = 0;
-    if (k > 0) {
-        const uint64_t kq = a.keys[k - 1];
-        lp = kq != key ? rs_key_lcp(kq, key, a.b, a.key_bits)
-                       : fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)a.vals[k - 1] + a.K, (uint64_t)p + a.K, 0) + (uint32_t)a.K);
-    }
-    if (k + 1 < a.N) {
-        const uint64_t kq = a.keys[k + 1];
-        ln = kq != key ? rs_key_lcp(key, kq, a.b, a.key_bits)
-                       : fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)p + a.K, (uint64_t)a.vals[k + 1] + a.K, 0) + (uint32_t)a.K);
-    }
-    isa[p] = (uint32_t)k; pl[p] = lp; pr[p] = ln;
 }
 
 struct FinishArgs {
@@ -314,7 +314,12 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->list, (N / 32 + 2) * 4));
+    const unsigned rs_blocks = fbg_blocks(N, 256, 256 * 32);
+    const uint32_t region = (uint32_t)((N / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
+    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rs_blocks * region * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (size_t)(rs_blocks + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)(rs_blocks + 1) * 4));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->dp_c.p, 0, (size_t)(rs_blocks + 1) * 4, st));
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
     FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
@@ -325,6 +330,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>();
     a.cand = ctx->list.as<uint32_t>(); a.pm = nullptr; a.counters = cnt;
+    a.blk_count = ctx->dp_c.as<uint32_t>(); a.region = region;
     a.g_min = 0;
     int launches = 0;
     if (N > (1u << 22)) {
@@ -351,21 +357,36 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
         }
     }
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    hipLaunchKernelGGL(k_rank_scan, dim3(fbg_blocks(N, 256, 256 * 32)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_rank_scan, dim3(rs_blocks), dim3(256), 0, st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     launches++;
     unsigned long long h[5];
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    // candidate counts per workgroup -> offsets; total and the largest count come back to the host
+    uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
+    FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::exclusive_scan(tmp, bytes, d_counts, d_offs, 0u, (size_t)(rs_blocks + 1), rocprim::plus<uint32_t>(), st);
+    }));
+    uint32_t *d_max = reinterpret_cast<uint32_t *>(cnt + 6);
+    FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::reduce(tmp, bytes, d_counts, d_max, 0u, (size_t)rs_blocks, rocprim::maximum<uint32_t>(), st);
+    }));
+    uint32_t tot = 0, mx = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot, d_offs + rs_blocks, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    const uint64_t T = h[0];
-    if (T > N / 32) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);       // similar rows: record path
+    const uint64_t T = tot;
+    if (mx > region) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
     if (T > 0) {
         // candidates in SA order; tie groups first (final order), then the runs
         FBG_TRY(fbg_reserve(ctx, ctx->dp_a, T * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->dp_b, T * 4));
+        // regions are in SA order already (workgroup b owns chunks b, b+G, ...: not contiguous) -> compact, then sort
         uint32_t *sorted = ctx->dp_a.as<uint32_t>();
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
+        uint32_t *flat = ctx->dp_e.as<uint32_t>();
+        hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat);
         FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_keys(tmp, bytes, a.cand, sorted, (size_t)T, 0u, 32u, st);
+            return rocprim::radix_sort_keys(tmp, bytes, flat, sorted, (size_t)T, 0u, 32u, st);
         }));
         a.cand = sorted;
         a.pm = ctx->dp_b.as<uint32_t>();

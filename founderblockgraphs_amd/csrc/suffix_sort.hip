@@ -23,6 +23,8 @@
 #include "fbg_internal.h"
 #include "text_cmp.h"
 #include <rocprim/rocprim.hpp>
+#include <utility>
+#include <cmath>
 
 #define SS_THREADS 256
 
@@ -287,7 +289,20 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         return fbg_fail(ctx, FBG_ERR_INVALID, "the MSA contains a NUL byte; the text needs a unique 0 sentinel");
     int b = 1;
     while ((1 << b) < sigma) b++;
-    const int K = 64 / b;            // symbols per 64-bit key
+    // symbols per key: enough that only a few percent of the suffixes tie on the whole key (those are ordered by
+    // text comparison afterwards), rounded up to whole 9-bit radix passes, at most 64 bits.  The symbol entropy H
+    // of the text tells how many symbols that takes: ties ~ N * 2^(-H*K)  =>  K >= (log2 N + 5) / H.
+    double H = 0;
+    for (int c = 1; c < 256; c++)
+        if (hist[c]) { const double q = (double)hist[c] / (double)N; H -= q * log2(q); }
+    if (H < 0.05) H = 0.05;
+    int K = (int)ceil((log2((double)N) + 5.0) / H);
+    if (getenv("FBG_FULL_KEYS") || K > 64 / b) K = 64 / b;
+    {
+        const int passes = (K * b + 8) / 9;                  // 9-bit digits
+        const int Kfill = (9 * passes) / b;                  // symbols that fit the same number of passes
+        K = Kfill < 64 / b ? Kfill : 64 / b;
+    }
     const int key_bits = K * b;
     FBG_HIP_TRY(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // code[] lives on this stack frame
@@ -314,9 +329,38 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
                        keysA, valsA);
     launches += 2;
-    FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-        return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, 0u, (unsigned)key_bits, st);
-    }));
+    // hybrid sort: radix passes on the leading ~log2(N)-3 key bits only, then every small group of pairs sharing
+    // those bits is finished locally in one pass (group_sort.hip); all bits by radix if a group is too long
+    int top_bits = 9;
+    while (top_bits < key_bits && (1ull << top_bits) < N / 8) top_bits += 9;
+    bool hybrid = top_bits < key_bits && N > (1u << 20) && getenv("FBG_HYBRID_SORT");   // off by default: see DESIGN.md
+    if (hybrid) {
+        const unsigned lo = (unsigned)(key_bits - top_bits);
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, lo, (unsigned)key_bits, st);
+        }));
+        int ok = 0;
+        FBG_TRY(fbg_group_sort(ctx, keysB, valsB, keysA, valsA, N, (int)lo, &ok));
+        launches += 1;
+        if (ok) {
+            // the sorted pairs are in the A buffers: make "B" name them, as the rest of the pipeline expects
+            std::swap(ctx->keysA, ctx->keysB);
+            std::swap(ctx->valsA, ctx->valsB);
+            keysA = ctx->keysA.as<uint64_t>(); keysB = ctx->keysB.as<uint64_t>();
+            valsA = ctx->valsA.as<uint32_t>(); valsB = ctx->valsB.as<uint32_t>();
+            sa = valsB;
+            ctx->sa_ptr = sa;
+        } else {
+            hybrid = false;   // skewed keys: start over with all bits
+            hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code,
+                               b, K, keysA, valsA);
+        }
+    }
+    if (!hybrid) {
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, 0u, (unsigned)key_bits, st);
+        }));
+    }
     {   // gap-free MSAs: the whole extension scan can be done right here, in rank order (rank_scan.hip)
         int done = 0;
         FBG_TRY(fbg_rank_scan_try(ctx, keysB, valsB, b, key_bits, K, &done));

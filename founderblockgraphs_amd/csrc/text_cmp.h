@@ -20,11 +20,12 @@ __device__ __forceinline__ uint64_t fbg_load8(const uint8_t *__restrict__ T, uin
 // terminates at the unique 0 sentinel at the latest
 __device__ __forceinline__ uint32_t fbg_extend_match(const uint8_t *__restrict__ T, uint64_t p, uint64_t q, uint32_t h)
 {
-    for (;;) {
-        uint64_t x = fbg_load8(T, p + h) ^ fbg_load8(T, q + h);
-        if (x) return h + (uint32_t)(__ffsll((unsigned long long)x) - 1) / 8;
+    uint64_t x = fbg_load8(T, p + h) ^ fbg_load8(T, q + h);
+    while (x == 0) {
         h += 8;
+        x = fbg_load8(T, p + h) ^ fbg_load8(T, q + h);
     }
+    return h + (uint32_t)(__ffsll((unsigned long long)x) - 1) / 8;
 }
 
 __device__ __forceinline__ uint32_t fbg_clamp_lcp(uint32_t h) { return h > FBG_LCP_MASK ? FBG_LCP_MASK : h; }

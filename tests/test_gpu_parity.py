@@ -350,3 +350,23 @@ def test_nonelastic_dp_random_v(engine, max_len):
         assert (b is None) == (gb is None)
         if b is not None:
             assert np.array_equal(gb, b)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(similar=0.97), dict(gap_p=0.01, gap_run=8)], ids=["iid", "similar", "gaps"])
+def test_hybrid_sort_regime(engine, kw):
+    """Texts above 2^20 symbols take the hybrid sort (radix on the leading bits + local group sort), similar rows
+    make it fall back to the full radix sort: index arrays and f must equal the oracle's either way."""
+    rng = np.random.default_rng(77)
+    msa = random_msa(rng, 48, 24000, **kw)
+    T, SA, ISA, LCP = O.msa_index(msa)
+    engine.msa_load_host(msa)
+    engine.index_build()
+    gT, gSA, gISA, gPL, gPR = engine.index_download()
+    assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64))
+    assert np.array_equal(gISA.astype(np.int64), ISA.astype(np.int64))
+    lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
+    assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA])
+    assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1])
+    again = engine.index_download()                      # same index, second read-out: must be bit-identical
+    assert all(np.array_equal(x, y) for x, y in zip((gT, gSA, gISA, gPL, gPR), again))
+    assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))
