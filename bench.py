@@ -70,14 +70,15 @@ def cpu_baseline(m, n_total, sample_cols):
     }
 
 
-def measured_traffic(m, n):
-    """HBM bytes per k_scan_stream launch from the committed rocprofv3 PMC pass (profiles/, collected and
-    corrected as MI355X_MICROARCH.md prescribes); None when no pass exists for this workload."""
+def measured_traffic(m, n, kernel):
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected and
+    corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled);
+    None when no pass exists for this workload / kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_stream.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_kernels.json")) as fh:
             d = json.load(fh)
         if d["workload"] == {"rows": m, "cols": n}:
-            return d["kernels"]["k_scan_stream"]["hbm_bytes_per_launch"]
+            return d["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         pass
     return None
@@ -209,8 +210,10 @@ def main():
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
             "roofline": {"bound": "hbm", "kernel": "k_rank_scan" if ranked else "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(scan_rows, scan_cols) if world == 1 else None,
-                         "traffic_source": "profiles/r01_pmc_scan_stream.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                         "traffic": measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
+                         if world == 1 else None,
+                         "traffic_source": "profiles/r01_pmc_scan_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                           "passes; the x2 FETCH_SIZE correction is calibrated for 16-B loads only: upper bound here)",
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "device_bytes": eng.device_bytes(),
