@@ -1,0 +1,16 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python - <<'PY'
+import numpy as np, time, sys
+sys.path.insert(0,'.')
+from bench import synth_msa_host
+m,n=1000,200000
+a=synth_msa_host(m,n,n)
+t=time.time()
+with open('/tmp/c3s.fasta','wb') as fh:
+    for i in range(m):
+        fh.write(b'>r%d\n'%i); fh.write(a[i].tobytes()); fh.write(b'\n')
+print('fasta written', time.time()-t)
+PY
+/usr/bin/time -v ./founderblockgraphs_amd/founderblockgraph --input /tmp/c3s.fasta --output /tmp/c3s.xgfa --elastic --gfa -p 2> gpurun_out/cli_e2e.log; tail -25 gpurun_out/cli_e2e.log | grep -E "Time taken|Elapsed|Maximum resident|Input MSA|optimal"; ls -la /tmp/c3s.xgfa; head -c 300 /tmp/c3s.xgfa | head -3 | cut -c1-100

@@ -370,3 +370,47 @@ def test_hybrid_sort_regime(engine, kw):
     again = engine.index_download()                      # same index, second read-out: must be bit-identical
     assert all(np.array_equal(x, y) for x, y in zip((gT, gSA, gISA, gPL, gPR), again))
     assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))
+
+
+ALT_PATHS = [
+    {"FBG_NO_RANKED": "1"},                          # record path even for gap-free MSAs
+    {"FBG_NO_RANKED": "1", "FBG_LCP_TEXT": "1"},     # ... with Kasai text comparison instead of key-derived LCPs
+    {"FBG_FULL_KEYS": "1"},                          # 64-bit keys instead of entropy-sized ones
+    {"FBG_RANK_NO_THRESHOLD": "1"},                  # rank-order scan without the sampled threshold
+    {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
+    {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
+    {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
+]
+
+
+@pytest.mark.parametrize("env", ALT_PATHS, ids=["+".join(sorted(e)) for e in ALT_PATHS])
+def test_alternative_paths_stay_bit_identical(engine, env):
+    """Every fallback / alternative code path of the engine must give the oracle's answer too."""
+    import os
+    rng = np.random.default_rng(4242)
+    cases = [random_msa(rng, 20, 900, similar=0.96), random_msa(rng, 64, 400), random_msa(rng, 7, 1500, alphabet="AC", similar=0.99),
+             random_msa(rng, 15, 700, gap_p=0.02, gap_run=5, n_p=0.01)]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for msa in cases:
+            f = O.compute_f(msa, ignore="N")
+            g = engine.elastic_f(msa, ignorechars="N")
+            assert np.array_equal(g, f)
+            mml, bt, b = O.minmax_dp(f)
+            gb, gmml, gbt = engine.minmax_dp(g, full=True)
+            assert np.array_equal(gmml, mml) and np.array_equal(gbt, bt) and np.array_equal(gb, b)
+            if ord("-") not in msa:
+                v = O.segment_v(msa)
+                gv = engine.repeatfree_v(msa)
+                assert np.array_equal(gv, v)
+                s, prev, bb = O.segment_dp(v)
+                gs, gprev, gbb = engine.repeatfree_dp(gv)
+                assert np.array_equal(gs, s) and np.array_equal(gprev, prev)
+                assert (bb is None) == (gbb is None) and (bb is None or np.array_equal(gbb, bb))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
