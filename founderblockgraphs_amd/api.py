@@ -145,6 +145,22 @@ class Engine:
         ig, il = _ignore(ignorechars)
         self._chk(self._L.fbg_index_build(self._h, int(reversed), _u8(ig), il))
 
+    # partitioned index (multi-GPU, include/fbg_hip.h): each returns ok; False = use index_build on every rank
+    def part_index_build(self, part, nparts, d_blob_ptr, reversed=False):
+        ok = C.c_int(0)
+        self._chk(self._L.fbg_part_index_build(self._h, int(reversed), part, nparts, C.c_void_p(d_blob_ptr), C.byref(ok)))
+        return bool(ok.value)
+
+    def part_scan(self, d_blobs_ptr, d_gmax_ptr):
+        ok = C.c_int(0)
+        self._chk(self._L.fbg_part_scan(self._h, C.c_void_p(d_blobs_ptr), C.c_void_p(d_gmax_ptr), C.byref(ok)))
+        return bool(ok.value)
+
+    def part_finish(self, d_gmax_ptr):
+        ok = C.c_int(0)
+        self._chk(self._L.fbg_part_finish(self._h, C.c_void_p(d_gmax_ptr), C.byref(ok)))
+        return bool(ok.value)
+
     def scan_f(self, x0, x1, d_f_ptr, disable_efg_tricks=False):
         self._chk(self._L.fbg_scan_f(self._h, x0, x1, int(disable_efg_tricks), C.c_void_p(d_f_ptr)))
 

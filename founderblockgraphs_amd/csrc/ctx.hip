@@ -219,6 +219,46 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     return FBG_OK;
 }
 
+int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void *d_blob, int *ok)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->d_msa) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_index_build: no MSA set");
+    if (!d_blob || !ok || nparts < 1 || part < 0 || part >= nparts)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_index_build: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->index_valid = false;
+    ctx->ranked = false;
+    ctx->reversed = reversed ? 1 : 0;
+    FBG_TRY(fbg_build_text(ctx, nullptr, 0));
+    return fbg_part_sort(ctx, part, nparts, static_cast<uint8_t *>(d_blob), ok);
+}
+
+int fbg_part_scan(fbg_ctx *ctx, const void *d_blobs, uint32_t *d_gmax, int *ok)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->part_active || ctx->index_valid)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_scan needs fbg_part_index_build first");
+    if (!d_blobs || !d_gmax || !ok) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_scan: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return fbg_rank_part_runs(ctx, static_cast<const uint8_t *>(d_blobs), d_gmax, ok);
+}
+
+int fbg_part_finish(fbg_ctx *ctx, const uint32_t *d_gmax, int *ok)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->part_active || ctx->index_valid)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_finish needs fbg_part_scan first");
+    if (!d_gmax || !ok) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_finish: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t verdict = 1;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->gmax.p, d_gmax, (ctx->n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&verdict, d_gmax + ctx->n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *ok = verdict == 0;
+    if (*ok) { ctx->n_exc = 0; ctx->ranked = true; ctx->index_valid = true; }
+    return FBG_OK;
+}
+
 int fbg_scan_f(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_f)
 {
     if (!ctx) return FBG_ERR_INVALID;
@@ -350,6 +390,7 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
 {
     if (!ctx) return FBG_ERR_INVALID;
     if (!ctx->index_valid) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: no index");
+    if (ctx->part_active) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: the index is partitioned over several GPUs");
     size_t N = ctx->N;
     // test / debugging API: plain blocking copies
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

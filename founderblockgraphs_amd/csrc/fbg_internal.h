@@ -58,6 +58,11 @@ struct fbg_ctx {
     uint32_t n_exc = 0;
     const uint64_t *rk_keys = nullptr;
     int rk_b = 0, rk_key_bits = 0, rk_K = 0;
+    // partitioned index (partition.hip): this GPU holds the SA slots of key range `part` of `nparts`
+    bool part_active = false;
+    int part = 0, nparts = 1;
+    uint64_t part_count = 0;   // owned slots (keys / vals arrays: FBG_PART_HALO + part_count + FBG_PART_HALO)
+    uint64_t part_T = 0;       // candidates found by phase 1
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tmp, small, scalars;
@@ -99,6 +104,11 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
 int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out);
 int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
 #define FBG_STAGE_RANKSCAN FBG_STAGE_TILE
+int fbg_key_setup(fbg_ctx *ctx, int *b, int *K, int *key_bits, const uint8_t **d_code, int *launches);   // suffix_sort.hip
+int fbg_rank_part_classify(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, uint64_t count, int b, int key_bits,
+                           int K, int pre_ok, uint8_t *d_blob, int *ok);      // rank_scan.hip
+int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok);
+int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);                        // suffix_sort.hip
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
                      uint64_t *d_out);                                        // scan.hip
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,

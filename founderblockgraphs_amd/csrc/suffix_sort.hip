@@ -266,15 +266,12 @@ template <class F> static int with_tmp(fbg_ctx *ctx, F &&call)
     return FBG_OK;
 }
 
-int fbg_suffix_sort(fbg_ctx *ctx)
+// Alphabet compaction (order preserving) and the key geometry: b bits per symbol, K symbols per key.
+int fbg_key_setup(fbg_ctx *ctx, int *b_out, int *K_out, int *key_bits_out, const uint8_t **d_code_out, int *launches)
 {
     const uint64_t N = ctx->N;
     hipStream_t st = ctx->stream;
-    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SUFFIX_SORT));
-    int launches = 0;
     const uint8_t *T = ctx->text.as<uint8_t>();
-
-    // ---- alphabet compaction (order preserving) -------------------------------------------
     unsigned *d_hist = ctx->small.as<unsigned>() + 256;   // small: bytes [0,256) ignore table, [1024,2048) histogram, [2048,2304) code table
     uint8_t *d_code = ctx->small.as<uint8_t>() + 2048;
     FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
@@ -303,9 +300,24 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         const int Kfill = (9 * passes) / b;                  // symbols that fit the same number of passes
         K = Kfill < 64 / b ? Kfill : 64 / b;
     }
-    const int key_bits = K * b;
     FBG_HIP_TRY(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // code[] lives on this stack frame
+    *b_out = b; *K_out = K; *key_bits_out = K * b; *d_code_out = d_code;
+    *launches += 2;
+    return FBG_OK;
+}
+
+int fbg_suffix_sort(fbg_ctx *ctx)
+{
+    const uint64_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SUFFIX_SORT));
+    int launches = 0;
+    const uint8_t *T = ctx->text.as<uint8_t>();
+    int b = 0, K = 0, key_bits = 0;
+    const uint8_t *d_code = nullptr;
+    FBG_TRY(fbg_key_setup(ctx, &b, &K, &key_bits, &d_code, &launches));
+    ctx->part_active = false;
 
     // ---- round 0: sort all suffixes by their first K symbols -------------------------------
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
@@ -328,7 +340,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
 
     hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
                        keysA, valsA);
-    launches += 2;
+    launches += 1;
     // hybrid sort: radix passes on the leading ~log2(N)-3 key bits only, then every small group of pairs sharing
     // those bits is finished locally in one pass (group_sort.hip); all bits by radix if a group is too long
     int top_bits = 9;
@@ -458,4 +470,155 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
     return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
+}
+
+// ---- partitioned index: this GPU sorts only the suffixes whose key lies in its range ------------------------
+// Every rank of a multi-GPU job holds the whole text (MSAs are small next to their index: 1 byte per symbol
+// against 24 bytes of sort state), computes the same splitters from the same key sample, and then packs,
+// sorts and scans only its own key range: sort state and sort time divide by the number of GPUs.  The ranks
+// exchange nothing but FBG_PART_HALO edge slots each and the per-column maxima (rank_scan.hip, distributed.py).
+__global__ void k_sample_keys(const uint8_t *__restrict__ T, uint64_t N, const uint8_t *__restrict__ code, int b, int K,
+                              uint64_t stride, uint64_t S, uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const uint64_t p = i * stride;
+    uint64_t key = 0;
+    for (int k = 0; k < K; k++) key = (key << b) | (p + k < N ? code[T[p + k]] : 0);
+    out[i] = key;
+}
+
+// k_pack_keys, keeping only keys in [lo, hi) (hi ignored when nohi): compacted, in no particular order
+__global__ __launch_bounds__(SS_THREADS) void k_pack_filter(const uint8_t *__restrict__ T, uint64_t N,
+                                                            const uint8_t *__restrict__ code, int b, int K, uint64_t lo,
+                                                            uint64_t hi, int nohi, uint64_t cap,
+                                                            unsigned long long *__restrict__ counter,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    constexpr int TILE = SS_THREADS * PK_ITEMS;
+    __shared__ uint8_t tile[TILE + 64];
+    __shared__ uint8_t cd[256];
+    __shared__ uint64_t skeys[TILE];
+    __shared__ uint32_t wsum[SS_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    cd[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    for (int k = threadIdx.x; k < TILE + 64; k += SS_THREADS) {
+        const uint64_t p = base + k;
+        tile[k] = p < N ? cd[T[p]] : 0;
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * PK_ITEMS;
+    const uint64_t mask = (K * b) >= 64 ? ~0ull : ((1ull << (K * b)) - 1);
+    uint64_t key = 0;
+    for (int k = 0; k < K; k++) key = (key << b) | tile[t0 + k];
+#pragma unroll
+    for (int i = 0; i < PK_ITEMS; i++) {
+        skeys[t0 + i] = key;
+        key = ((key << b) | tile[t0 + K + i]) & mask;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long keep[PK_ITEMS];
+    uint32_t wtot = 0;
+#pragma unroll
+    for (int i = 0; i < PK_ITEMS; i++) {
+        const int j = threadIdx.x + i * SS_THREADS;
+        const uint64_t kj = skeys[j];
+        keep[i] = __ballot(base + j < N && kj >= lo && (nohi || kj < hi));
+        wtot += (uint32_t)__popcll(keep[i]);
+    }
+    if (lane == 0) wsum[w] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int q = 0; q < SS_THREADS / 64; q++) tot += wsum[q];
+        s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;     // one counter update per workgroup
+    }
+    __syncthreads();
+    uint64_t off = s_base;
+    for (int q = 0; q < w; q++) off += wsum[q];
+#pragma unroll
+    for (int i = 0; i < PK_ITEMS; i++) {
+        const int j = threadIdx.x + i * SS_THREADS;
+        if ((keep[i] >> lane) & 1ull) {
+            const uint64_t o = off + (uint64_t)__popcll(keep[i] & ((1ull << lane) - 1));
+            if (o < cap) { keys[o] = skeys[j]; vals[o] = (uint32_t)(base + j); }
+        }
+        off += (uint64_t)__popcll(keep[i]);
+    }
+}
+
+int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
+{
+    const uint64_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SUFFIX_SORT));
+    int launches = 0;
+    const uint8_t *T = ctx->text.as<uint8_t>();
+    int b = 0, K = 0, key_bits = 0;
+    const uint8_t *d_code = nullptr;
+    FBG_TRY(fbg_key_setup(ctx, &b, &K, &key_bits, &d_code, &launches));
+    ctx->part = part; ctx->nparts = nparts; ctx->part_active = true;
+    int pre_ok = ctx->gapfree && !ctx->have_ignore && !getenv("FBG_NO_RANKED");
+    uint64_t count = 0;
+    // splitters: quantiles of a sorted key sample -- the same on every rank, ties never straddle a boundary
+    uint64_t S = N / 64;
+    if (S > (1u << 20)) S = 1u << 20;
+    if (S < 1024) S = N < 1024 ? N : 1024;
+    const uint64_t stride = N / S;
+    uint64_t lo = 0, hi = 0;
+    if (pre_ok && nparts > 1) {
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_g, S * 8));
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_h, S * 8));
+        uint64_t *smp = ctx->dp_g.as<uint64_t>(), *smp_sorted = ctx->dp_h.as<uint64_t>();
+        hipLaunchKernelGGL(k_sample_keys, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, T, N, d_code, b, K, stride, S, smp);
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::radix_sort_keys(tmp, bytes, smp, smp_sorted, (size_t)S, 0u, (unsigned)key_bits, st);
+        }));
+        launches += 2;
+        if (part > 0)
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(&lo, smp_sorted + (uint64_t)part * S / nparts, 8, hipMemcpyDeviceToHost, st));
+        if (part + 1 < nparts)
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(&hi, smp_sorted + (uint64_t)(part + 1) * S / nparts, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    const int nohi = part + 1 >= nparts;
+    uint64_t *keys_out = nullptr;
+    uint32_t *vals_out = nullptr;
+    if (pre_ok) {
+        unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
+        uint64_t cap = N / nparts + N / 8 + 65536;
+        if (cap > N) cap = N;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            FBG_TRY(fbg_reserve(ctx, ctx->keysA, cap * 8));
+            FBG_TRY(fbg_reserve(ctx, ctx->valsA, cap * 4));
+            FBG_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, st));
+            hipLaunchKernelGGL(k_pack_filter, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code,
+                               b, K, lo, hi, nohi, cap, d_count, ctx->keysA.as<uint64_t>(), ctx->valsA.as<uint32_t>());
+            launches++;
+            unsigned long long hc = 0;
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(&hc, d_count, 8, hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            count = hc;
+            if (count <= cap) break;
+            cap = count;                               // a skewed sample: once more with room for all of them
+        }
+    }
+    const uint64_t slots = count + 2 * FBG_PART_HALO;
+    FBG_TRY(fbg_reserve(ctx, ctx->keysB, slots * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->valsB, slots * 4));
+    keys_out = ctx->keysB.as<uint64_t>();
+    vals_out = ctx->valsB.as<uint32_t>();
+    if (pre_ok && count > 0) {
+        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, ctx->keysA.as<uint64_t>(), keys_out + FBG_PART_HALO,
+                                                              ctx->valsA.as<uint32_t>(), vals_out + FBG_PART_HALO,
+                                                              (size_t)count, 0u, (unsigned)key_bits, st);
+        }));
+    }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches));
+    return fbg_rank_part_classify(ctx, keys_out, vals_out, count, b, key_bits, K, pre_ok, d_blob, ok);
 }

@@ -105,3 +105,37 @@ def plan_row_pairs(m, n, world, limit=(1 << 32) - 2):
 def all_reduce_max(f_partial, group=None):
     dist.all_reduce(f_partial, op=dist.ReduceOp.MAX, group=group)
     return f_partial
+
+
+# ---- partitioned index: sort state and sort time divided by the number of GPUs ----------------------
+#
+# Every rank holds the whole MSA but sorts and scans only the suffixes whose leading symbols fall into its key
+# range (include/fbg_hip.h, fbg_part_*).  Two collectives: an all-gather of the partitions' edge slots (1.5 KB
+# per rank) and an all-reduce(MAX) of the per-column maxima ((n + 1) * 4 bytes).  Gap-free MSAs without ignore
+# characters only; every rank learns from the collectives whether all partitions succeeded, so the fall-back
+# to the replicated index is taken by all ranks or none.
+
+def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=False, device="cuda"):
+    """Build the index of the engine's current MSA partitioned over the ranks.  True: the engine is ready for
+    scan_f / scan_v (any column range, normally all of them on rank 0).  False: nothing usable was built --
+    call engine.index_build() on every rank instead."""
+    from ._lib import PART_HALO_BYTES
+    world = dist.get_world_size(group) if world is None else world
+    rank = dist.get_rank(group) if rank is None else rank
+    blob = torch.empty(PART_HALO_BYTES, dtype=torch.uint8, device=device)
+    blobs = torch.empty(world * PART_HALO_BYTES, dtype=torch.uint8, device=device)
+    gmax = torch.empty(n + 1, dtype=torch.int32, device=device)
+    torch.cuda.current_stream().synchronize()
+    engine.part_index_build(rank, world, blob.data_ptr(), reversed)   # verdict travels inside the blob
+    engine.sync()
+    if world > 1:
+        dist.all_gather_into_tensor(blobs, blob, group=group)
+    else:
+        blobs.copy_(blob)
+    torch.cuda.current_stream().synchronize()
+    engine.part_scan(blobs.data_ptr(), gmax.data_ptr())               # verdict travels in gmax[n]
+    engine.sync()
+    if world > 1:
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    torch.cuda.current_stream().synchronize()
+    return engine.part_finish(gmax.data_ptr())

@@ -136,6 +136,29 @@ int fbg_msa_synthetic(fbg_ctx *ctx, uint8_t *d_msa, uint64_t m, uint64_t n, uint
  * reversed = 0.  Every rank of a multi-GPU job builds the same index (replicas).
  */
 int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uint64_t ignore_len);
+/*
+ * Partitioned index for multi-GPU jobs (gap-free MSAs without ignore characters): every rank holds the same
+ * MSA, but sorts and scans only the suffixes of key range `part` of `nparts`, so index memory and sort time
+ * divide by the number of GPUs.  The caller moves two small things between the ranks:
+ *
+ *   fbg_part_index_build   text, splitters (identical on every rank), local sort, local classification;
+ *                          d_blob (FBG_PART_HALO_BYTES, device) receives this partition's edge slots
+ *       -> all-gather the blobs of all ranks, in rank order, into d_blobs (nparts * FBG_PART_HALO_BYTES)
+ *   fbg_part_scan          halos in, runs walked; d_gmax (n + 1 words, device) receives the per-column maxima
+ *                          of this partition's suffixes, word n its verdict
+ *       -> all-reduce(MAX) d_gmax over the ranks
+ *   fbg_part_finish        takes the reduced maxima; afterwards fbg_scan_f / fbg_scan_v work as after
+ *                          fbg_index_build.
+ *
+ * *ok = 0 (from any of the three; the same value on every rank after the collective that follows) means the
+ * input does not suit this path (similar rows, long runs): fall back to fbg_index_build on every rank.
+ * Replaces the same reference code as fbg_index_build + fbg_scan_f (fbg.cpp:428, 1610-1694).
+ */
+#define FBG_PART_HALO 64
+#define FBG_PART_HALO_BYTES (2 * FBG_PART_HALO * 12 + 16)
+int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void *d_blob, int *ok);
+int fbg_part_scan(fbg_ctx *ctx, const void *d_blobs, uint32_t *d_gmax, int *ok);
+int fbg_part_finish(fbg_ctx *ctx, const uint32_t *d_gmax, int *ok);
 /* Columns [x0, x1) of f, max-merged into d_f[x0..x1) (d_f has n entries, device memory). */
 int fbg_scan_f(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_f);
 /* Columns [x0, x1) of v, written to d_v[x0..x1). Requires fbg_index_build(reversed = 1). */

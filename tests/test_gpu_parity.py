@@ -414,3 +414,119 @@ def test_alternative_paths_stay_bit_identical(engine, env):
                 del os.environ[k]
             else:
                 os.environ[k] = v
+
+
+def _partitioned(engines, n, reversed=False):
+    """fbg_part_* with the partitions of a multi-GPU job played by several contexts on one GPU: what
+    distributed.partitioned_index does, with torch.cat / torch.maximum standing in for the two collectives.
+    Returns the list of per-partition verdicts after each phase."""
+    import torch
+    from founderblockgraphs_amd._lib import PART_HALO_BYTES
+    P = len(engines)
+    blobs = torch.zeros(P * PART_HALO_BYTES, dtype=torch.uint8, device="cuda")
+    gm = [torch.zeros(n + 1, dtype=torch.int32, device="cuda") for _ in range(P)]
+    torch.cuda.synchronize()
+    ok1 = [e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, reversed) for r, e in enumerate(engines)]
+    for e in engines:
+        e.sync()
+    ok2 = [e.part_scan(blobs.data_ptr(), gm[r].data_ptr()) for r, e in enumerate(engines)]
+    for e in engines:
+        e.sync()
+    red = gm[0]
+    for g in gm[1:]:
+        red = torch.maximum(red, g)
+    torch.cuda.synchronize()
+    ok3 = [e.part_finish(red.data_ptr()) for e in engines]
+    return ok1, ok2, ok3
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5])
+def test_partitioned_index_matches_oracle(P):
+    """Key-range partitioned index (multi-GPU path): f and v from P partitions == the oracle's."""
+    import torch
+    from founderblockgraphs_amd import Engine
+    rng = np.random.default_rng(40 + P)
+    engines = [Engine() for _ in range(P)]
+    try:
+        for (m, n, kw) in [(24, 500, {}), (50, 300, dict(alphabet="AC")), (9, 2500, dict(alphabet="ACGTN")),
+                           (40, 400, dict(similar=0.5))]:
+            msa = random_msa(rng, m, n, **kw)
+            for e in engines:
+                e.msa_load_host(msa)
+            ok1, ok2, ok3 = _partitioned(engines, n)
+            assert all(ok1) and all(ok2) and all(ok3), (m, n, kw, ok1, ok2, ok3)
+            f = O.compute_f(msa)
+            for tricks_off in (False, True):
+                exp = O.compute_f(msa, disable_tricks=tricks_off)
+                d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                engines[P - 1].scan_f(0, n, d_f.data_ptr(), tricks_off)     # any rank can finish: the maxima are global
+                engines[P - 1].sync()
+                assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), exp)
+            # non-elastic: reversed rows
+            ok1, ok2, ok3 = _partitioned(engines, n, reversed=True)
+            assert all(ok1) and all(ok2) and all(ok3)
+            d_v = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            engines[0].scan_v(0, n, d_v.data_ptr())
+            engines[0].sync()
+            assert np.array_equal(d_v.cpu().numpy().astype(np.uint64), O.segment_v(msa))
+            del f
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_partitioned_index_declines_consistently():
+    """Inputs the partitioned path does not take (gaps, near-identical rows, tiny partitions): every partition
+    must report the same verdict after the collectives, and nothing may claim a usable index."""
+    import torch
+    from founderblockgraphs_amd import Engine, FbgError
+    rng = np.random.default_rng(77)
+    engines = [Engine() for _ in range(3)]
+    try:
+        for (m, n, kw) in [(12, 300, dict(gap_p=0.05, gap_run=3)), (100, 300, dict(similar=0.999)), (2, 40, {})]:
+            msa = random_msa(rng, m, n, **kw)
+            for e in engines:
+                e.msa_load_host(msa)
+            ok1, ok2, ok3 = _partitioned(engines, n)
+            assert not any(ok2) and not any(ok3), (kw, ok1, ok2, ok3)
+            d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+            with pytest.raises(FbgError):
+                engines[0].scan_f(0, n, d_f.data_ptr())
+            # the fall-back every rank takes
+            engines[0].index_build()
+            torch.cuda.synchronize()
+            engines[0].scan_f(0, n, d_f.data_ptr())
+            engines[0].sync()
+            assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa))
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_partitioned_index_full_size():
+    """C3 shape (1000 x 1,000,000): four key-range partitions give exactly the f of the whole index."""
+    import torch
+    from founderblockgraphs_amd import Engine
+    m, n, P = 1000, 1_000_000, 4
+    d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    engines = [Engine() for _ in range(P)]
+    try:
+        engines[0].msa_synthetic(d.data_ptr(), m, n)
+        for e in engines:
+            e.msa_set_device(d.data_ptr(), m, n)
+        ok1, ok2, ok3 = _partitioned(engines, n)
+        assert all(ok1) and all(ok2) and all(ok3)
+        d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        d_g = torch.zeros(n, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        engines[1].scan_f(0, n, d_f.data_ptr())
+        engines[1].sync()
+        engines[0].index_build()
+        engines[0].scan_f(0, n, d_g.data_ptr())
+        engines[0].sync()
+        assert torch.equal(d_f, d_g)
+    finally:
+        for e in engines:
+            e.close()
