@@ -105,7 +105,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->rec,
                       &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->xbits, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
-                      &ctx->list, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
+                      &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
@@ -157,7 +157,7 @@ int fbg_release_scratch(fbg_ctx *ctx)
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // valsB stays: it is the suffix array
     // keysB stays as well: the rank-order index reads the sorted keys
-    DevBuf *bufs[] = {&ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list,
+    DevBuf *bufs[] = {&ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
@@ -395,14 +395,17 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     // test / debugging API: plain blocking copies
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (text) FBG_HIP_TRY(ctx, hipMemcpy(text, ctx->text.p, N, hipMemcpyDeviceToHost));
-    if (sa) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost));
-    if ((isa || lcp_prev || lcp_next) && ctx->ranked) {
-        // rank-order index: no per-position records exist; derive the three arrays from the sorted keys once
+    if (sa && !ctx->ranked) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost));
+    if ((sa || isa || lcp_prev || lcp_next) && ctx->ranked) {
+        // rank-order index: no per-position records exist; derive the arrays from the sorted keys once
         FBG_TRY(fbg_reserve(ctx, ctx->io_a, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_b, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_c, N * 4));
-        FBG_TRY(fbg_rank_materialize(ctx, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>()));
+        FBG_TRY(fbg_reserve(ctx, ctx->io_d, N * 4));
+        FBG_TRY(fbg_rank_materialize(ctx, ctx->io_d.as<uint32_t>(), ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(),
+                                     ctx->io_c.as<uint32_t>()));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (sa) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->io_d.p, N * 4, hipMemcpyDeviceToHost));
         if (isa) FBG_HIP_TRY(ctx, hipMemcpy(isa, ctx->io_a.p, N * 4, hipMemcpyDeviceToHost));
         if (lcp_prev) FBG_HIP_TRY(ctx, hipMemcpy(lcp_prev, ctx->io_b.p, N * 4, hipMemcpyDeviceToHost));
         if (lcp_next) FBG_HIP_TRY(ctx, hipMemcpy(lcp_next, ctx->io_c.p, N * 4, hipMemcpyDeviceToHost));

@@ -40,6 +40,8 @@ struct fbg_ctx {
     bool gapfree = true;
     bool have_ignore = false;
     uint64_t N = 0;            // text length incl. sentinel
+    unsigned byte_hist[256] = {0}; // symbol histogram of the current text (fbg_key_setup)
+    bool byte_hist_valid = false;
     uint32_t mp = 0;           // rows padded to a multiple of 64 (column-tile pitch)
     DevBuf text;               // N + 64 bytes, zero padded
     DevBuf pos, tot;           // u32[m]
@@ -56,8 +58,9 @@ struct fbg_ctx {
     DevBuf xbits;              // bitmap of the exception columns
     DevBuf exc;                // uint4[n_exc * m]: (rank, lcp_prev, lcp_next) of the rows of the exception columns
     uint32_t n_exc = 0;
-    const uint64_t *rk_keys = nullptr;
+    uint64_t *rk_keys = nullptr; // sorted slots: keys (pairs layout, positions in sa_ptr) or key << rk_pb | position (packed)
     int rk_b = 0, rk_key_bits = 0, rk_K = 0;
+    int rk_packed = 0, rk_pb = 0;
     // partitioned index (partition.hip): this GPU holds the SA slots of key range `part` of `nparts`
     bool part_active = false;
     int part = 0, nparts = 1;
@@ -65,7 +68,7 @@ struct fbg_ctx {
     uint64_t part_T = 0;       // candidates found by phase 1
 
     // scratch
-    DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tmp, small, scalars;
+    DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tie_list, big_groups, tmp, small, scalars;
     DevBuf dp_a, dp_b, dp_c, dp_d, dp_e, dp_f, dp_g, dp_h, io_a, io_b, io_c, io_d;
     DevBuf bt_up, bt_dep;      // binary-lifting tables of the parallel backtrack
 
@@ -93,20 +96,27 @@ void fbg_release(fbg_ctx *ctx, DevBuf &b);
 int fbg_stage_begin(fbg_ctx *ctx, int stage);
 int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);
 
+// Key geometry of the round-0 sort.  compact: separators ('#', sentinel) share code 0 with the smallest symbol and
+// blank the rest of the key (rank_scan.hip undoes the ambiguity with the row arithmetic of gap-free MSAs);
+// packed: one 64-bit word per suffix, key << pb | position, sorted by its key bits only.
+struct KeyGeom {
+    int b = 0, K = 0, key_bits = 0;
+    bool compact = false, packed = false;
+    int pb = 0;
+    const uint8_t *d_code = nullptr;
+};
+
 // ---- stages (each in its own translation unit) ----------------------------------------------
 int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len);  // text_build.hip
 int fbg_suffix_sort(fbg_ctx *ctx);                                            // suffix_sort.hip
 int fbg_neighbour_lcp(fbg_ctx *ctx);                                          // lcp.hip
-int fbg_group_sort(fbg_ctx *ctx, const uint64_t *keys_in, const uint32_t *vals_in, uint64_t *keys_out,
-                   uint32_t *vals_out, uint64_t N, int top_shift, int *ok);   // group_sort.hip
-int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b, int key_bits, int K,
-                      int *done);                                             // rank_scan.hip
+int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);       // rank_scan.hip
 int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out);
-int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
+int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
 #define FBG_STAGE_RANKSCAN FBG_STAGE_TILE
-int fbg_key_setup(fbg_ctx *ctx, int *b, int *K, int *key_bits, const uint8_t **d_code, int *launches);   // suffix_sort.hip
-int fbg_rank_part_classify(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, uint64_t count, int b, int key_bits,
-                           int K, int pre_ok, uint8_t *d_blob, int *ok);      // rank_scan.hip
+int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches);                                // suffix_sort.hip
+int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int pre_ok,
+                           uint8_t *d_blob, int *ok);                         // rank_scan.hip
 int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok);
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);                        // suffix_sort.hip
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,

@@ -2,31 +2,43 @@
 //
 // Coloured ranks that are consecutive integers (fbg.cpp:1633-1641) are, in suffix-array order, simply
 // neighbouring slots whose positions lie in the same MSA column (position mod (n+1)).  So the whole scan of
-// fbg.cpp:1610-1694 can be done on the SORTED (key, position) pairs, without the inverse permutation:
+// fbg.cpp:1610-1694 can be done on the SORTED round-0 keys, without the inverse permutation:
 //
-//   k_rank_scan     per SA slot: its two neighbour LCPs are the numbers of equal leading symbols of its
-//                   round-0 key and the neighbours' keys.  A slot whose neighbours are in other columns is a run
-//                   of length one: g = 1 + max(LCP[r], LCP[r+1]) goes into the column's maximum (table read
-//                   first, atomicMax only when it grows; extensions too small to be a column maximum -- judged
-//                   from a sampled histogram and verified afterwards -- skip the table altogether).
-//                   Slots with a same-column neighbour, slots tying with a neighbour on the whole key, and their
-//                   direct neighbours go to a (short) candidate list instead.
-//   k_tie_groups    tie groups are ordered by comparing the text beyond the K key symbols: final SA order.
+//   k_rank_scan     per SA slot: its two neighbour LCPs are the numbers of equal leading symbols of its key and
+//                   the neighbours' keys.  A slot whose neighbours are in other columns is a run of length one:
+//                   g = 1 + max(LCP[r], LCP[r+1]) goes into the column's maximum (table read first, atomicMax
+//                   only when it grows; extensions too small to be a column maximum -- judged from a sampled
+//                   histogram and verified afterwards -- skip the table altogether).
+//                   Suffixes that tie on the whole key: a small group none of whose members shares a column
+//                   with another member or with the slots next to the group needs no ordering at all -- the
+//                   extension of a member is 1 + its longest match with any other member (k_tie_simple).
+//                   Everything else -- slots with a same-column neighbour, larger or entangled tie groups --
+//                   goes to a (short) candidate list.
+//   k_tie_simple    the small tie groups: all pairs compared beyond the key, straight into the column maxima.
+//   k_tie_groups    candidate tie groups are ordered by text comparison: final SA order.
 //   k_runs          candidates, in final order: every maximal run of same-column neighbouring slots gets
 //                   g = 1 + max(min LCP towards the run head, min LCP towards the run tail) per member
 //                   (fbg.cpp:1644-1678) by one forward and one backward walk.
 //   k_rank_finish   f[x] / v[j] from the column maxima (fbg.cpp:1656-1672 with rank_i(x) = x, tot_i = n).
 //
-// Falls back to the record path (suffix_sort.hip doubling + scan.hip) when more than N/32 slots are
-// candidates (similar rows) or a tie group exceeds 64 members.
+// Keys use the compact coding of suffix_sort.hip: a separator ('#', sentinel) and everything behind it inside a
+// key count as code 0.  A key of a suffix with fewer than K symbols left in its row ("short") is therefore the
+// smallest key with its real symbols: the suffix sorts correctly up to ties, and the number of equal leading
+// symbols of two different keys is their LCP once clamped to the symbols both rows really have left
+// (rem = n - column, row arithmetic).  Tie groups with a short member are ordered by comparing the text from
+// the suffix start.  Slots are either (key, position) pairs or one packed word, key << pb | position.
+//
+// Falls back to the record path (suffix_sort.hip doubling + scan.hip) when a quarter of the slots tie
+// (similar rows), a workgroup's candidate region overflows, or a tie group exceeds 64 members.
 #include <cstring>
 #include <vector>
 #include "fbg_internal.h"
 #include "text_cmp.h"
 #include <rocprim/rocprim.hpp>
 
-// number of equal leading symbols of two keys: (leading equal bits) / b, the division as a multiply-shift
-// (exact for numerators <= 64: inv_b = ceil(2^16 / b))
+#define RS_TG 4    // tie groups up to this size are settled inside the scan
+
+// number of equal leading symbols of two different K-symbol keys (b bits per symbol)
 __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
 {
     const uint64_t d = a ^ c;
@@ -37,14 +49,17 @@ __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, in
 
 struct RankArgs {
     uint64_t magic;            // floor(2^64 / row_len) + 1: p / row_len == umul64hi(p, magic) for p < 2^32
-    const uint64_t *keys;      // sorted round-0 keys
-    uint32_t *vals;            // positions in SA order (final once the tie groups are ordered)
+    uint64_t *keys;            // sorted slots: keys, or packed words key << pb | position
+    uint32_t *vals;            // positions in SA order (pairs layout; final once the tie groups are ordered)
+    uint64_t pmask;            // packed: (1 << pb) - 1
+    int pb;
     const uint8_t *T;
     uint64_t N, n;             // N: number of SA slots in keys[] / vals[]
     uint64_t Ntext;            // text length (position Ntext-1 is the sentinel)
     uint64_t own_lo, own_hi;   // slots this launch owns; the rest are halo copies of the neighbouring partitions
     int first_part, last_part; // partition holds the globally first / last suffix (no neighbour beyond)
     int part_mode;             // >1 partitions: slots next to a partition edge are re-examined once the halos are in
+    int values_only;           // second pass for columns the threshold starved: no lists, no threshold
     uint32_t row_len;          // n + 1
     uint32_t g_min;            // extensions below this cannot be a column maximum (sampled; verified afterwards)
     int b, key_bits, K, reversed;
@@ -52,17 +67,56 @@ struct RankArgs {
     uint32_t *cand;            // SA slots that need the run treatment (see header)
     uint32_t *blk_count;       // k_rank_scan: candidates found by each workgroup (its private region of cand[])
     uint32_t region;           // capacity of one workgroup's region
+    uint32_t *ties;            // heads of the small tie groups, same per-workgroup regions
+    uint32_t *tie_count;
+    uint32_t tie_region;
     uint32_t *pm;              // scratch parallel to cand: prefix minima of the forward walk
-    unsigned long long *counters;   // [0] candidates, [1] fallback flag
+    uint32_t *big;             // tie groups too long for one thread: (head slot, size) pairs, counters[5] of them
+    unsigned long long *counters;   // [1] fallback flag
 };
 
-// column of text position p, or n for '#' / sentinel positions (never a row pointer when there are no gaps)
-__device__ __forceinline__ uint32_t rs_col(const RankArgs &a, uint32_t p)
+struct Slot {
+    uint64_t key;
+    uint32_t pos;
+    uint32_t col;              // MSA column of the position, n for '#' / sentinel (never a row pointer without gaps)
+    uint32_t rem;              // symbols left in the row from this position on (0 for '#' / sentinel)
+};
+
+__device__ __forceinline__ void rs_colrem(const RankArgs &a, uint32_t p, uint32_t &col, uint32_t &rem)
 {
-    if (p == a.Ntext - 1) return (uint32_t)a.n;
+    if (p == a.Ntext - 1) { col = (uint32_t)a.n; rem = 0; return; }
     const uint32_t c = p - (uint32_t)__umul64hi((uint64_t)p, a.magic) * a.row_len;    // p mod (n+1)
-    if (c == a.n) return c;
-    return a.reversed ? (uint32_t)a.n - 1 - c : c;
+    rem = (uint32_t)a.n - c;
+    col = c == a.n ? c : (a.reversed ? (uint32_t)a.n - 1 - c : c);
+}
+
+template <bool PK> __device__ __forceinline__ uint64_t rs_key(const RankArgs &a, uint64_t k)
+{
+    return PK ? a.keys[k] >> a.pb : a.keys[k];
+}
+template <bool PK> __device__ __forceinline__ uint32_t rs_pos(const RankArgs &a, uint64_t k)
+{
+    return PK ? (uint32_t)(a.keys[k] & a.pmask) : a.vals[k];
+}
+template <bool PK> __device__ __forceinline__ void rs_set_pos(const RankArgs &a, uint64_t k, uint32_t p)
+{
+    if (PK) a.keys[k] = (a.keys[k] & ~a.pmask) | p;
+    else a.vals[k] = p;
+}
+template <bool PK> __device__ __forceinline__ Slot rs_slot(const RankArgs &a, uint64_t k)
+{
+    Slot s;
+    const uint64_t w = a.keys[k];
+    s.key = PK ? w >> a.pb : w;
+    s.pos = PK ? (uint32_t)(w & a.pmask) : a.vals[k];
+    rs_colrem(a, s.pos, s.col, s.rem);
+    return s;
+}
+template <bool PK> __device__ __forceinline__ uint32_t rs_col(const RankArgs &a, uint64_t k)
+{
+    uint32_t col, rem;
+    rs_colrem(a, rs_pos<PK>(a, k), col, rem);
+    return col;
 }
 
 __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint32_t g)
@@ -71,69 +125,203 @@ __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint3
     if (a.gmax[col] < g) atomicMax(&a.gmax[col], g);
 }
 
-__device__ __forceinline__ void rank_scan_slot(const RankArgs &a, const uint64_t k)
+// one wave-aggregated append per list: a single counter update per wave, on the workgroup's own counter
+__device__ __forceinline__ void rs_append(bool want, uint32_t *counts, uint32_t *list, uint32_t region, uint32_t value)
 {
-    const bool in = k < a.own_hi;                      // k >= own_lo by construction
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
     const int lane = threadIdx.x & 63;
-    const uint64_t key = in ? a.keys[k] : 0ull;
-    const uint32_t p = in ? a.vals[k] : (uint32_t)(a.Ntext - 1);
-    const uint32_t col = rs_col(a, p);
-    const bool has_prev = k > a.own_lo, has_next = k + 1 < a.own_hi;     // neighbours inside the owned range
-    // keys / columns of the SA neighbours: adjacent lanes, extra loads at the wave's edges
-    uint64_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
-    uint32_t cp = __shfl_up(col, 1, 64), cn = __shfl_down(col, 1, 64);
-    if (lane == 0 && in) { kp = has_prev ? a.keys[k - 1] : ~key; cp = has_prev ? rs_col(a, a.vals[k - 1]) : (uint32_t)a.n; }
-    if (lane == 63 || !has_next) {
-        kn = has_next ? a.keys[k + 1] : ~key;
-        cn = has_next ? rs_col(a, a.vals[k + 1]) : (uint32_t)a.n;
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(&counts[blockIdx.x], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) {
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+        if (slot < region) list[(size_t)blockIdx.x * region + slot] = value;
     }
-    if (!has_prev) { kp = ~key; cp = (uint32_t)a.n; }
-    const bool tie = in && (kp == key || kn == key);
-    // is a neighbour slot a tie?  one ballot; the wave's edge lanes look one key further
-    const unsigned long long tmask = __ballot(tie);
-    bool tie_prev = lane > 0 ? (tmask >> (lane - 1)) & 1ull : false;
-    bool tie_next = lane < 63 ? (tmask >> (lane + 1)) & 1ull : false;
-    if (lane == 0 && in && has_prev) tie_prev = kp == key || (k > a.own_lo + 1 && a.keys[k - 2] == kp);
-    if (lane == 63 && in && has_next) tie_next = kn == key || (k + 2 < a.own_hi && a.keys[k + 2] == kn);
-    if (!in) return;
-    // candidate: ties (order not final yet), neighbours of ties (their neighbour is not final yet), slots with a
-    // same-column neighbour (runs, fbg.cpp:1633-1641), and slots at a partition edge (neighbour not known yet)
-    const bool near_tie = tie_prev || tie_next;
-    const bool run = col != a.n && (cp == col || cn == col);
-    const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);
-    const bool cand = tie || (col != a.n && (near_tie || run || edge));
-    const unsigned long long cmask = __ballot(cand);
-    if (cmask) {                                       // one counter update per wave, on the workgroup's own counter
-        uint32_t base = 0;
-        const int leader = __ffsll((long long)cmask) - 1;
-        if (lane == leader) base = atomicAdd(&a.blk_count[blockIdx.x], (uint32_t)__popcll(cmask));
-        base = __shfl(base, leader, 64);
-        if (cand) {
-            const uint32_t slot = base + (uint32_t)__popcll(cmask & ((1ull << lane) - 1));
-            if (slot < a.region) a.cand[(size_t)blockIdx.x * a.region + slot] = (uint32_t)k;
-            return;
+}
+
+// k_rank_scan stages a chunk of 256 slots (+ RS_HALO either side) in LDS as (key, column): all the looking around
+// that tie groups need happens there.
+#define RS_HALO 8
+#define RS_CHUNK 256
+
+__device__ __forceinline__ uint32_t rs_rem_of(const RankArgs &a, uint32_t col)
+{
+    return col == a.n ? 0u : (a.reversed ? col + 1 : (uint32_t)a.n - col);
+}
+
+// i: LDS index of the slot (slot k = base + i - RS_HALO); valid LDS indices are [lo_i, hi_i)
+__device__ __forceinline__ void rank_scan_slot(const RankArgs &a, const uint64_t *skey, const uint32_t *scol, const int i,
+                                               const int lo_i, const int hi_i, const uint64_t k)
+{
+    const uint32_t n32 = (uint32_t)a.n;
+    const bool in = i < hi_i;
+    const uint64_t key = skey[i];
+    const uint32_t col = scol[i];
+    const bool has_prev = in && i > lo_i, has_next = in && i + 1 < hi_i;   // neighbours inside the owned range
+    const uint64_t kp = skey[i - 1], kn = skey[i + 1];
+    const bool eqp = has_prev && kp == key, eqn = has_next && kn == key;
+    const bool tie = eqp || eqn;
+    bool want_cand = false, want_tie = false;
+    if (tie) {
+        // bounds of the group, looking at most RS_TG slots either way
+        int h = i, t = i;
+        while (h > lo_i && i - h < RS_TG && skey[h - 1] == key) h--;
+        bool big = h > lo_i && skey[h - 1] == key;
+        while (t + 1 < hi_i && t - i < RS_TG && skey[t + 1] == key) t++;
+        big = big || (t + 1 < hi_i && skey[t + 1] == key) || t - h + 1 > RS_TG;
+        bool simple = !big;
+        if (simple && a.part_mode && (k - (uint64_t)(i - h) < a.own_lo + 2 || k + (uint64_t)(t - i) + 2 >= a.own_hi))
+            simple = false;                                                                    // partition edge
+        if (simple) {
+            // every member: K real symbols, columns all different, and different from the slots next to the group
+            uint32_t cols[RS_TG];
+            const int s = t - h + 1;
+#pragma unroll
+            for (int q = 0; q < RS_TG; q++) {
+                cols[q] = 0xffffffffu - (uint32_t)q;
+                if (q < s) {
+                    cols[q] = scol[h + q];
+                    if (rs_rem_of(a, cols[q]) < (uint32_t)a.K) simple = false;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RS_TG; q++)
+#pragma unroll
+                for (int r = q + 1; r < RS_TG; r++)
+                    if (cols[q] == cols[r]) simple = false;
+            if (simple && h > lo_i) {
+                if (h - 1 > lo_i && skey[h - 2] == skey[h - 1]) simple = false;                // tie groups side by side
+                const uint32_t oc = scol[h - 1];
+#pragma unroll
+                for (int q = 0; q < RS_TG; q++)
+                    if (cols[q] == oc) simple = false;
+            }
+            if (simple && t + 1 < hi_i) {
+                if (t + 2 < hi_i && skey[t + 2] == skey[t + 1]) simple = false;
+                const uint32_t oc = scol[t + 1];
+#pragma unroll
+                for (int q = 0; q < RS_TG; q++)
+                    if (cols[q] == oc) simple = false;
+            }
+        }
+        if (simple) want_tie = i == h;
+        else want_cand = true;
+    } else if (in && col != n32) {
+        // not a tie: both LCPs come from the keys, unless a neighbour shares the column (a run)
+        const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);       // neighbour not known yet
+        const uint32_t rem = rs_rem_of(a, col);
+        bool run = (has_prev && scol[i - 1] == col) || (has_next && scol[i + 1] == col);
+        uint32_t mrp = has_prev ? rs_rem_of(a, scol[i - 1]) : 0u, mrn = has_next ? rs_rem_of(a, scol[i + 1]) : 0u;
+        if (has_prev && i - 1 > lo_i && skey[i - 2] == kp) {
+            // the slot before is a tie group whose final order is not known here: any member may end up next to
+            // this slot.  Same column anywhere in it -> run treatment; LCP with it: the member with most symbols left
+            int j = i - 1, cnt = 0;
+            uint32_t mr = 0;
+            for (;;) {
+                const uint32_t cj = scol[j];
+                mr = max(mr, rs_rem_of(a, cj));
+                run = run || cj == col;
+                cnt++;
+                if (j == lo_i || skey[j - 1] != kp) break;
+                if (cnt == RS_TG) { run = true; break; }
+                j--;
+            }
+            mrp = mr;
+        }
+        if (has_next && i + 2 < hi_i && skey[i + 2] == kn) {
+            int j = i + 1, cnt = 0;
+            uint32_t mr = 0;
+            for (;;) {
+                const uint32_t cj = scol[j];
+                mr = max(mr, rs_rem_of(a, cj));
+                run = run || cj == col;
+                cnt++;
+                if (j + 1 >= hi_i || skey[j + 1] != kn) break;
+                if (cnt == RS_TG) { run = true; break; }
+                j++;
+            }
+            mrn = mr;
+        }
+        if (edge || run) want_cand = true;
+        else {
+            const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), mrp) : 0u;
+            const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), mrn) : 0u;
+            const uint32_t g = max(lp, ln) + 1;
+            // near the end of a row few suffixes compete and extensions stay short: no threshold there
+            const uint32_t c_raw = a.reversed ? n32 - 1 - col : col;
+            if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
         }
     }
-    if (col == a.n) return;
-    const uint32_t lp = has_prev ? rs_key_lcp(kp, key, a.b, a.key_bits) : 0u;
-    const uint32_t ln = has_next ? rs_key_lcp(key, kn, a.b, a.key_bits) : 0u;
-    const uint32_t g = max(lp, ln) + 1;
-    // near the end of a row few suffixes compete and extensions stay short: no threshold there
-    const uint32_t c_raw = a.reversed ? (uint32_t)a.n - 1 - col : col;
-    if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
+    if (a.values_only) return;                         // uniform
+    rs_append(want_cand, a.blk_count, a.cand, a.region, (uint32_t)k);
+    rs_append(want_tie, a.tie_count, a.ties, a.tie_region, (uint32_t)k);
 }
 
 // a few thousand workgroups, each walking 256-slot chunks of the SA (a launch of N/256 tiny workgroups spends
 // more time being dispatched than working)
-__global__ __launch_bounds__(256) void k_rank_scan(RankArgs a)
+template <bool PK> __global__ __launch_bounds__(RS_CHUNK) void k_rank_scan(RankArgs a)
 {
-    const uint64_t nchunks = (a.own_hi - a.own_lo + 255) / 256;
-    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) rank_scan_slot(a, a.own_lo + c * 256 + threadIdx.x);
+    __shared__ uint64_t skey[RS_CHUNK + 2 * RS_HALO];
+    __shared__ uint32_t scol[RS_CHUNK + 2 * RS_HALO];
+    const uint64_t nchunks = (a.own_hi - a.own_lo + RS_CHUNK - 1) / RS_CHUNK;
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint64_t base = a.own_lo + c * RS_CHUNK;                 // slot of LDS index RS_HALO
+        const int lo_i = c == 0 ? RS_HALO : 0;                         // LDS index of the first / one past the last owned slot
+        const int hi_i = (int)min((uint64_t)(RS_CHUNK + 2 * RS_HALO), a.own_hi - base + RS_HALO);
+        for (int i = threadIdx.x; i < RS_CHUNK + 2 * RS_HALO; i += RS_CHUNK) {
+            uint64_t key = 0;
+            uint32_t col = (uint32_t)a.n;
+            if (i >= lo_i && i < hi_i) {
+                const Slot s = rs_slot<PK>(a, base + i - RS_HALO);
+                key = s.key; col = s.col;
+            }
+            skey[i] = key; scol[i] = col;
+        }
+        __syncthreads();
+        rank_scan_slot(a, skey, scol, (int)threadIdx.x + RS_HALO, lo_i, hi_i, base + threadIdx.x);
+        __syncthreads();
+    }
+}
+
+// the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
+// shares a column with a neighbour, so each is a run of its own and its extension is 1 + its longest match with
+// any other suffix -- which is another member of the group (they agree on K symbols, nobody else does).
+template <bool PK> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a)
+{
+    const uint32_t have = a.tie_count[blockIdx.x];
+    if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
+    for (uint32_t e = threadIdx.x; e < have; e += blockDim.x) {
+        const uint64_t h = a.ties[(size_t)blockIdx.x * a.tie_region + e];
+        const uint64_t key = rs_key<PK>(a, h);
+        int s = 1;
+        while (s < RS_TG && h + s < a.own_hi && rs_key<PK>(a, h + s) == key) s++;
+        uint32_t pos[RS_TG], best[RS_TG];
+#pragma unroll
+        for (int i = 0; i < RS_TG; i++) { best[i] = 0; pos[i] = i < s ? rs_pos<PK>(a, h + i) : 0u; }
+#pragma unroll
+        for (int i = 0; i < RS_TG; i++)
+#pragma unroll
+            for (int j = i + 1; j < RS_TG; j++)
+                if (j < s) {
+                    const uint32_t x = fbg_extend_match(a.T, (uint64_t)pos[i] + a.K, (uint64_t)pos[j] + a.K, 0);
+                    best[i] = max(best[i], x);
+                    best[j] = max(best[j], x);
+                }
+#pragma unroll
+        for (int i = 0; i < RS_TG; i++)
+            if (i < s) {
+                uint32_t col, rem;
+                rs_colrem(a, pos[i], col, rem);
+                rs_update(a, col, fbg_clamp_lcp(best[i] + (uint32_t)a.K) + 1);
+            }
+    }
 }
 
 // cheap regime test + extension histogram over every 1024th block of 256 SA slots:
 // counters[2] ties, counters[3] slots looked at, hist[g] = non-tie slots with extension min(g, 63)
-__global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__ keys, uint64_t N, int b, int key_bits,
+__global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__ keys, int shift, uint64_t N, int b, int key_bits,
                                                     unsigned long long *__restrict__ counters,
                                                     unsigned int *__restrict__ hist)
 {
@@ -144,8 +332,8 @@ __global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__
     __syncthreads();
     const uint64_t k = (uint64_t)blockIdx.x * 1024 * 256 + threadIdx.x;
     if (k < N) {
-        const uint64_t key = keys[k];
-        const uint64_t kp = k > 0 ? keys[k - 1] : ~key, kn = k + 1 < N ? keys[k + 1] : ~key;
+        const uint64_t key = keys[k] >> shift;
+        const uint64_t kp = k > 0 ? keys[k - 1] >> shift : ~key, kn = k + 1 < N ? keys[k + 1] >> shift : ~key;
         if (kp == key || kn == key) {
             atomicAdd(&sties, 1u);
         } else {
@@ -179,105 +367,180 @@ __global__ void k_cand_compact(const uint32_t *__restrict__ regions, const uint3
     for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) out[o + i] = regions[(size_t)blockIdx.x * region + i];
 }
 
-// second chance for columns the threshold starved: same classification as k_rank_scan, values only
-__global__ __launch_bounds__(256) void k_rank_scan_values(RankArgs a)
-{
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.N) return;
-    const uint64_t key = a.keys[k];
-    const uint64_t kp = k > 0 ? a.keys[k - 1] : ~key, kn = k + 1 < a.N ? a.keys[k + 1] : ~key;
-    if (kp == key || kn == key) return;
-    const uint64_t kpp = k > 1 ? a.keys[k - 2] : ~kp, knn = k + 2 < a.N ? a.keys[k + 2] : ~kn;
-    if ((k > 0 && kpp == kp) || (k + 1 < a.N && knn == kn)) return;
-    const uint32_t col = rs_col(a, a.vals[k]);
-    if (col == a.n) return;
-    const uint32_t cp = k > 0 ? rs_col(a, a.vals[k - 1]) : (uint32_t)a.n;
-    const uint32_t cn = k + 1 < a.N ? rs_col(a, a.vals[k + 1]) : (uint32_t)a.n;
-    if (cp == col || cn == col) return;                // candidates are handled exactly by k_runs
-    const uint32_t lp = k > 0 ? rs_key_lcp(kp, key, a.b, a.key_bits) : 0u;
-    const uint32_t ln = k + 1 < a.N ? rs_key_lcp(key, kn, a.b, a.key_bits) : 0u;
-    rs_update(a, col, max(lp, ln) + 1);
-}
-
-// candidates (sorted): a slot whose key equals its successor's but not its predecessor's heads a tie group
-__global__ void k_tie_groups(RankArgs a, uint64_t T)
+// a slot whose key equals its successor's but not its predecessor's heads a tie group: put the group in text
+// order.  by_list: t indexes the sorted candidates; otherwise every owned slot (fbg_rank_materialize).
+// Groups of more than 64 go to k_tie_big.
+#define RS_BIG_GROUPS 1024
+#define RS_BIG_MEMBERS 8192
+template <bool PK> __global__ void k_tie_groups(RankArgs a, uint64_t T, int by_list)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const uint32_t k0 = a.cand[t];
-    const uint64_t key = a.keys[k0];
-    if (k0 > a.own_lo && a.keys[k0 - 1] == key) return;                    // inside a group
-    if ((uint64_t)k0 + 1 >= a.own_hi || a.keys[k0 + 1] != key) return;     // not a tie at all (ties never cross partitions)
+    const uint64_t k0 = by_list ? (uint64_t)a.cand[t] : a.own_lo + t;
+    const uint64_t key = rs_key<PK>(a, k0);
+    if (k0 > a.own_lo && rs_key<PK>(a, k0 - 1) == key) return;                      // inside a group
+    if (k0 + 1 >= a.own_hi || rs_key<PK>(a, k0 + 1) != key) return;                 // not a tie (ties never cross partitions)
     uint32_t s = 1;
-    while ((uint64_t)k0 + s < a.own_hi && a.keys[k0 + s] == key) s++;
-    if (s > 64) { a.counters[1] = 1; return; }
-    // order the s suffixes by the text beyond their K common symbols (insertion sort, s is tiny)
+    while (k0 + s < a.own_hi && s <= RS_BIG_MEMBERS && rs_key<PK>(a, k0 + s) == key) s++;
+    if (s > 64) {
+        if (s > RS_BIG_MEMBERS) { a.counters[1] = 1; return; }
+        const unsigned long long e = atomicAdd(&a.counters[5], 1ull);
+        if (e >= RS_BIG_GROUPS) { a.counters[1] = 1; return; }
+        a.big[2 * e] = (uint32_t)k0;
+        a.big[2 * e + 1] = s;
+        return;
+    }
+    // order the s suffixes by their text (insertion sort, s is tiny).  The first K symbols agree -- unless a member
+    // has fewer than K symbols left in its row: then the keys agree only up to the separator coding
     uint32_t pos[64];
-    for (uint32_t i = 0; i < s; i++) pos[i] = a.vals[k0 + i];
+    uint32_t from = (uint32_t)a.K;
+    for (uint32_t i = 0; i < s; i++) {
+        pos[i] = rs_pos<PK>(a, k0 + i);
+        uint32_t col, rem;
+        rs_colrem(a, pos[i], col, rem);
+        if (rem < (uint32_t)a.K) from = 0;
+    }
     for (uint32_t i = 1; i < s; i++) {
         const uint32_t cur = pos[i];
         uint32_t j = i;
         while (j > 0) {
             const uint32_t o = pos[j - 1];
-            const uint32_t h = fbg_extend_match(a.T, (uint64_t)o + a.K, (uint64_t)cur + a.K, 0);
-            if (a.T[(uint64_t)o + a.K + h] < a.T[(uint64_t)cur + a.K + h]) break;      // o < cur: in place
+            const uint32_t h = fbg_extend_match(a.T, (uint64_t)o + from, (uint64_t)cur + from, 0);
+            if (a.T[(uint64_t)o + from + h] < a.T[(uint64_t)cur + from + h]) break;      // o < cur: in place
             pos[j] = o;
             j--;
         }
         pos[j] = cur;
     }
-    for (uint32_t i = 0; i < s; i++) a.vals[k0 + i] = pos[i];
+    for (uint32_t i = 0; i < s; i++) rs_set_pos<PK>(a, k0 + i, pos[i]);
 }
 
-// LCP of the suffixes in SA slots k-1 and k (final order)
-__device__ __forceinline__ uint32_t rs_slot_lcp(const RankArgs &a, uint64_t k)
+// Long tie groups exist where many rows end alike: the members of a group share their real symbols and differ in
+// how many they have left (r#, rA#, rAA#, ... and the suffixes with K real symbols), '#' being the smallest
+// symbol.  Text order is therefore: by symbols left (capped at K) first.  Members with the same number left sit in
+// one MSA column: a run whose inner order has no influence on any extension (the LCPs inside exceed those at its
+// two ends, fbg.cpp:1644-1656) -- left as it is unless `exact` (fbg_index_download wants the true suffix array).
+// The members with K real symbols are ordered by their text; more than 64 of those -> fallback flag.
+// One workgroup per group.
+template <bool PK> __global__ __launch_bounds__(256) void k_tie_big(RankArgs a, int exact)
+{
+    __shared__ uint32_t pos[RS_BIG_MEMBERS];
+    __shared__ uint8_t cls[RS_BIG_MEMBERS];
+    __shared__ uint32_t offs[66];
+    __shared__ uint32_t q_start, q_count;
+    if (blockIdx.x >= a.counters[5]) return;
+    const uint64_t k0 = a.big[2 * blockIdx.x];
+    const uint32_t s = a.big[2 * blockIdx.x + 1];
+    if (threadIdx.x < 66) offs[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
+        const uint32_t p = rs_pos<PK>(a, k0 + i);
+        uint32_t col, rem;
+        rs_colrem(a, p, col, rem);
+        const uint32_t c = min(rem, (uint32_t)a.K);
+        pos[i] = p;
+        cls[i] = (uint8_t)c;
+        atomicAdd(&offs[c + 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q_count = offs[a.K + 1];
+        for (int c = 1; c <= a.K + 1; c++) offs[c] += offs[c - 1];      // offs[c] = first slot of class c
+        q_start = offs[a.K];
+    }
+    __syncthreads();
+    if (!exact) {
+        for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
+            const uint32_t dst = atomicAdd(&offs[cls[i]], 1u);
+            rs_set_pos<PK>(a, k0 + dst, pos[i]);
+        }
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t q = q_count;
+            if (q > 64) { a.counters[1] = 1; return; }
+            const uint64_t kq = k0 + q_start;
+            for (uint32_t i = 1; i < q; i++) {                          // insertion sort by the text beyond the key
+                const uint32_t cur = rs_pos<PK>(a, kq + i);
+                uint32_t j = i;
+                while (j > 0) {
+                    const uint32_t o = rs_pos<PK>(a, kq + j - 1);
+                    const uint32_t h = fbg_extend_match(a.T, (uint64_t)o + a.K, (uint64_t)cur + a.K, 0);
+                    if (a.T[(uint64_t)o + a.K + h] < a.T[(uint64_t)cur + a.K + h]) break;
+                    rs_set_pos<PK>(a, kq + j, o);
+                    j--;
+                }
+                rs_set_pos<PK>(a, kq + j, cur);
+            }
+        }
+        return;
+    }
+    // exact: rank of every member among all members by text comparison (distinct suffixes: ranks are a permutation)
+    for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
+        const uint32_t p = pos[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < s; j++) {
+            if (j == i) continue;
+            const uint32_t o = pos[j];
+            const uint32_t h = fbg_extend_match(a.T, (uint64_t)o, (uint64_t)p, 0);
+            rank += a.T[(uint64_t)o + h] < a.T[(uint64_t)p + h] ? 1u : 0u;
+        }
+        rs_set_pos<PK>(a, k0 + rank, p);
+    }
+}
+
+// LCP of the suffixes in SA slots k-1 and k (final order, or a member of an unordered small tie group next to a
+// slot outside it: all its members have K symbols left, the result does not depend on which one it is)
+template <bool PK> __device__ __forceinline__ uint32_t rs_slot_lcp(const RankArgs &a, uint64_t k)
 {
     if (k == (a.first_part ? a.own_lo : 0) || k >= (a.last_part ? a.own_hi : a.N)) return 0;   // no such neighbour
-    const uint64_t x = a.keys[k - 1], y = a.keys[k];
-    if (x != y) return rs_key_lcp(x, y, a.b, a.key_bits);
-    return fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)a.vals[k - 1] + a.K, (uint64_t)a.vals[k] + a.K, 0) + (uint32_t)a.K);
+    const Slot x = rs_slot<PK>(a, k - 1), y = rs_slot<PK>(a, k);
+    if (x.key != y.key) return min(min(rs_key_lcp(x.key, y.key, a.b, a.key_bits), x.rem), y.rem);
+    const uint32_t from = (x.rem < (uint32_t)a.K || y.rem < (uint32_t)a.K) ? 0u : (uint32_t)a.K;
+    return fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)x.pos + from, (uint64_t)y.pos + from, 0) + from);
 }
 
-// test / debugging aid (fbg_index_download): inverse suffix array and neighbour LCPs by text position
-__global__ void k_rank_materialize(RankArgs a, uint32_t *isa, uint32_t *pl, uint32_t *pr)
+// test / debugging aid (fbg_index_download): suffix array, its inverse and the neighbour LCPs by text position
+template <bool PK> __global__ void k_rank_materialize(RankArgs a, uint32_t *sa, uint32_t *isa, uint32_t *pl, uint32_t *pr)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.N) return;
-    const uint32_t p = a.vals[k];
+    const uint32_t p = rs_pos<PK>(a, k);
+    sa[k] = p;
     isa[p] = (uint32_t)k;
-    pl[p] = rs_slot_lcp(a, k);
-    pr[p] = rs_slot_lcp(a, k + 1);
+    pl[p] = rs_slot_lcp<PK>(a, k);
+    pr[p] = rs_slot_lcp<PK>(a, k + 1);
 }
 
 // candidates (sorted, final SA order): one thread per run head walks its run of same-column slots.  With
 // partitions a run may begin or end in a halo (copies of the neighbouring partition's edge slots): it is walked
 // in full, but only owned members update the column maxima -- the neighbour does the same from its side.
-__global__ void k_runs(RankArgs a, uint64_t T)
+template <bool PK> __global__ void k_runs(RankArgs a, uint64_t T)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const uint32_t k0 = a.cand[t];
-    const uint32_t col = rs_col(a, a.vals[k0]);
+    const uint64_t k0 = a.cand[t];
+    const uint32_t col = rs_col<PK>(a, k0);
     if (col == a.n) return;                                            // '#' / sentinel: not a row pointer
-    if (k0 > a.own_lo && rs_col(a, a.vals[k0 - 1]) == col) return;     // an owned predecessor heads this run
+    if (k0 > a.own_lo && rs_col<PK>(a, k0 - 1) == col) return;         // an owned predecessor heads this run
     const uint64_t lo_slot = a.first_part ? a.own_lo : 0, hi_slot = a.last_part ? a.own_hi : a.N;
     uint64_t ks = k0;                                                  // true head: possibly inside the previous halo
-    while (ks > lo_slot && rs_col(a, a.vals[ks - 1]) == col) ks--;
+    while (ks > lo_slot && rs_col<PK>(a, ks - 1) == col) ks--;
     if (ks == 0 && !a.first_part) { a.counters[1] = 1; return; }       // run longer than the halo
     // forward: running minimum of LCP[lb..r]   (owned members of a run are contiguous in cand[])
-    uint32_t run = rs_slot_lcp(a, ks);
+    uint32_t run = rs_slot_lcp<PK>(a, ks);
     uint64_t s = ks;
     for (;;) {
         if (s >= k0 && s < a.own_hi) a.pm[t + (s - k0)] = run;
-        if (s + 1 >= hi_slot || rs_col(a, a.vals[s + 1]) != col) break;
+        if (s + 1 >= hi_slot || rs_col<PK>(a, s + 1) != col) break;
         s++;
-        run = min(run, rs_slot_lcp(a, s));
+        run = min(run, rs_slot_lcp<PK>(a, s));
     }
     if (s + 1 == a.N && !a.last_part) { a.counters[1] = 1; return; }   // ran through the next halo
     // backward: running minimum of LCP[r+1..rb+1], extension, column maximum   (fbg.cpp:1656)
     uint32_t rmin = 0xffffffffu;
     for (;; s--) {
-        rmin = min(rmin, rs_slot_lcp(a, s + 1));
+        rmin = min(rmin, rs_slot_lcp<PK>(a, s + 1));
         if (s >= k0 && s < a.own_hi) rs_update(a, col, max(a.pm[t + (s - k0)], rmin) + 1);
         if (s == ks || s <= k0) break;                                 // members before k0 belong to the neighbour
     }
@@ -321,39 +584,65 @@ template <class F> static int rs_with_tmp(fbg_ctx *ctx, F &&call)
     return FBG_OK;
 }
 
-static void rs_args_init(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, uint32_t *vals, uint64_t slots, int b,
+// kernels exist for both slot layouts
+#define RS_LAUNCH(kernel, packed, grid, block, st, ...)                                        \
+    do {                                                                                       \
+        if (packed) hipLaunchKernelGGL((kernel<true>), grid, block, 0, st, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((kernel<false>), grid, block, 0, st, __VA_ARGS__);             \
+    } while (0)
+
+static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *vals, uint64_t slots, int packed, int pb, int b,
                          int key_bits, int K)
 {
     a.keys = keys; a.vals = vals; a.T = ctx->text.as<uint8_t>();
+    a.pb = packed ? pb : 0; a.pmask = packed ? (1ull << pb) - 1 : 0;
     a.N = slots; a.Ntext = ctx->N; a.n = ctx->n; a.row_len = (uint32_t)(ctx->n + 1);
-    a.own_lo = 0; a.own_hi = slots; a.first_part = a.last_part = 1; a.part_mode = 0;
+    a.own_lo = 0; a.own_hi = slots; a.first_part = a.last_part = 1; a.part_mode = 0; a.values_only = 0;
     a.magic = ~0ull / (ctx->n + 1) + 1;
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>();
     a.cand = nullptr; a.pm = nullptr; a.blk_count = nullptr; a.region = 0;
+    a.ties = nullptr; a.tie_count = nullptr; a.tie_region = 0;
+    a.big = ctx->big_groups.as<uint32_t>();
     a.counters = ctx->scalars.as<unsigned long long>() + 32;
     a.g_min = 0;
 }
 
-// k_rank_scan over the owned slots, then the candidates: compacted, sorted, tie groups put in final order.
-// On return a.cand / a.pm name the sorted list and its scratch; *T = 0xffffffffffffffff when a workgroup's
+static void rs_remember(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g)
+{
+    ctx->rk_keys = keys; ctx->sa_ptr = vals;
+    ctx->rk_packed = g.packed ? 1 : 0; ctx->rk_pb = g.pb;
+    ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
+}
+
+// k_rank_scan over the owned slots, the small tie groups, then the candidates: compacted, sorted, tie groups put
+// in final order.  On return a.cand / a.pm name the sorted list and its scratch; *T = ~0 when a workgroup's
 // candidate region overflowed (similar rows: the caller takes another path).
-static int rs_classify(fbg_ctx *ctx, RankArgs &a, uint64_t *T_out, int *launches)
+static int rs_classify(fbg_ctx *ctx, RankArgs &a, int packed, uint64_t *T_out, int *launches)
 {
     hipStream_t st = ctx->stream;
     const uint64_t own = a.own_hi - a.own_lo;
     const unsigned rs_blocks = fbg_blocks(own, 256, 256 * 32);
     const uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
+    const uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
     FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rs_blocks * region * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)rs_blocks * tie_region * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
+    a.big = ctx->big_groups.as<uint32_t>();
     FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (size_t)(rs_blocks + 1) * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)(rs_blocks + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_f, (size_t)(rs_blocks + 1) * 4));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->dp_c.p, 0, (size_t)(rs_blocks + 1) * 4, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->dp_f.p, 0, (size_t)(rs_blocks + 1) * 4, st));
     a.cand = ctx->list.as<uint32_t>();
     a.blk_count = ctx->dp_c.as<uint32_t>(); a.region = region;
+    a.ties = ctx->tie_list.as<uint32_t>();
+    a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    hipLaunchKernelGGL(k_rank_scan, dim3(rs_blocks), dim3(256), 0, st, a);
+    RS_LAUNCH(k_rank_scan, packed, dim3(rs_blocks), dim3(256), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
-    (*launches)++;
+    RS_LAUNCH(k_tie_simple, packed, dim3(rs_blocks), dim3(256), st, a);
+    *launches += 2;
     // candidate counts per workgroup -> offsets; total and the largest count come back to the host
     uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
     FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
@@ -384,21 +673,22 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, uint64_t *T_out, int *launches
         }));
         a.cand = sorted;
         a.pm = ctx->dp_b.as<uint32_t>();
-        hipLaunchKernelGGL(k_tie_groups, dim3(fbg_blocks(T, 64)), dim3(64), 0, st, a, T);
-        *launches += 2;
+        RS_LAUNCH(k_tie_groups, packed, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
+        RS_LAUNCH(k_tie_big, packed, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
+        *launches += 3;
     }
     return FBG_OK;
 }
 
-// Called by fbg_suffix_sort right after the round-0 sort.  *done = 1 when the rank-order scan covered the
-// whole input (ctx->ranked set, suffix array final in vals); 0 = continue with the record path.
-int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b, int key_bits, int K, int *done)
+// Called by fbg_suffix_sort right after the round-0 sort of the compact keys.  *done = 1 when the rank-order scan
+// covered the whole input (ctx->ranked set); 0 = continue with the record path.
+int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &geom, int *done)
 {
     *done = 0;
     ctx->ranked = false;
     ctx->part_active = false;
-    if (!ctx->gapfree || ctx->have_ignore || getenv("FBG_NO_RANKED")) return FBG_OK;
     const uint64_t N = ctx->N, n = ctx->n, m = ctx->m;
+    const int packed = geom.packed ? 1 : 0;
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
@@ -406,7 +696,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
     FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
     RankArgs a;
-    rs_args_init(ctx, a, keys, vals, N, b, key_bits, K);
+    rs_args_init(ctx, a, keys, vals, N, packed, geom.pb, geom.b, geom.key_bits, geom.K);
     int launches = 0;
     if (N > (1u << 22)) {
         // sample: (a) similar rows tie almost everywhere -> do not even try the rank-order scan;
@@ -414,14 +704,15 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
         //             a column maximum: skipping them removes almost all table reads (verified below)
         unsigned int *d_hist = reinterpret_cast<unsigned int *>(cnt + 8);
         FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(N, 1024 * 256)), dim3(256), 0, st, keys, N, b, key_bits, cnt, d_hist);
+        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(N, 1024 * 256)), dim3(256), 0, st, keys, a.pb, N, geom.b, geom.key_bits,
+                           cnt, d_hist);
         launches++;
         unsigned long long hs[4];
         unsigned int hh[64];
         FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipMemcpyAsync(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (hs[2] * 16 > hs[3]) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+        if (hs[2] * 4 > hs[3]) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
         if (!getenv("FBG_RANK_NO_THRESHOLD")) {
             const double need = 32.0 / (double)m * (double)hs[3];     // sampled slots that must lie at or above g_min
             unsigned long long above = 0;
@@ -432,36 +723,36 @@ int fbg_rank_scan_try(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, int b,
         }
     }
     uint64_t T = 0;
-    FBG_TRY(rs_classify(ctx, a, &T, &launches));
+    FBG_TRY(rs_classify(ctx, a, packed, &T, &launches));
     if (T == ~0ull) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
     if (T > 0) {
-        hipLaunchKernelGGL(k_runs, dim3(fbg_blocks(T, 64)), dim3(64), 0, st, a, T);
+        RS_LAUNCH(k_runs, packed, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);
         launches++;
     }
     unsigned long long h[5];
-    if (T > 0 || a.g_min > 1) {
-        // a large tie group -> record path; a column without a value lost all its rows to the threshold -> redo
-        if (a.g_min > 1)
-            hipLaunchKernelGGL(k_count_unfilled, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.gmax, n, cnt);
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    // a large tie group / an overflowing tie region -> record path; a column without a value lost all its rows
+    // to the threshold -> redo without it
+    if (a.g_min > 1)
+        hipLaunchKernelGGL(k_count_unfilled, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.gmax, n, cnt);
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    launches++;
+    if (h[1] != 0) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+    if (a.g_min > 1 && h[4] != 0) {
+        a.g_min = 0;
+        a.values_only = 1;
+        RS_LAUNCH(k_rank_scan, packed, dim3(fbg_blocks(N, 256, 256 * 32)), dim3(256), st, a);
         launches++;
-        if (h[1] != 0) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
-        if (a.g_min > 1 && h[4] != 0) {
-            a.g_min = 0;
-            hipLaunchKernelGGL(k_rank_scan_values, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a);
-            launches++;
-        }
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
     ctx->n_exc = 0;
     ctx->ranked = true;
-    ctx->rk_b = b; ctx->rk_key_bits = key_bits; ctx->rk_K = K; ctx->rk_keys = keys;
+    rs_remember(ctx, keys, vals, geom);
     *done = 1;
     return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
 }
 
-// ---- partitioned index (partition.hip): this GPU holds the SA slots of one key range ----------------------
+// ---- partitioned index (suffix_sort.hip, fbg_part_sort): this GPU holds the SA slots of one key range -------
 // keys / vals: FBG_PART_HALO + count + FBG_PART_HALO slots; the middle part is sorted, the halos are filled in
 // by fbg_rank_part_runs once the neighbouring partitions have published their edge slots.
 __global__ void k_halo_export(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t own_lo,
@@ -473,7 +764,7 @@ __global__ void k_halo_export(const uint64_t *__restrict__ keys, const uint32_t 
     const uint32_t t = threadIdx.x;                    // 2 * FBG_PART_HALO threads: head slots, then tail slots
     if (ok) {
         const uint64_t k = t < FBG_PART_HALO ? own_lo + t : own_hi - 2 * FBG_PART_HALO + t;
-        bk[t] = keys[k]; bv[t] = vals[k];
+        bk[t] = keys[k]; bv[t] = vals ? vals[k] : 0u;
     } else { bk[t] = 0; bv[t] = 0; }
     if (t == 0) { tail[0] = ok; tail[1] = own_hi - own_lo; }
 }
@@ -485,18 +776,19 @@ __global__ void k_halo_import(const uint8_t *__restrict__ blobs, int part, int n
     if (part > 0) {                                    // tail of the previous partition -> slots [0, H)
         const uint8_t *bl = blobs + (size_t)(part - 1) * FBG_PART_HALO_BYTES;
         keys[t] = reinterpret_cast<const uint64_t *>(bl)[FBG_PART_HALO + t];
-        vals[t] = reinterpret_cast<const uint32_t *>(bl + 2 * FBG_PART_HALO * 8)[FBG_PART_HALO + t];
+        if (vals) vals[t] = reinterpret_cast<const uint32_t *>(bl + 2 * FBG_PART_HALO * 8)[FBG_PART_HALO + t];
     }
     if (part + 1 < nparts) {                           // head of the next partition -> slots [own_hi, own_hi + H)
         const uint8_t *bl = blobs + (size_t)(part + 1) * FBG_PART_HALO_BYTES;
         keys[own_hi + t] = reinterpret_cast<const uint64_t *>(bl)[t];
-        vals[own_hi + t] = reinterpret_cast<const uint32_t *>(bl + 2 * FBG_PART_HALO * 8)[t];
+        if (vals) vals[own_hi + t] = reinterpret_cast<const uint32_t *>(bl + 2 * FBG_PART_HALO * 8)[t];
     }
 }
 
 static void rs_part_args(fbg_ctx *ctx, RankArgs &a)
 {
-    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->part_count + 2 * FBG_PART_HALO, ctx->rk_b, ctx->rk_key_bits, ctx->rk_K);
+    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->part_count + 2 * FBG_PART_HALO, ctx->rk_packed, ctx->rk_pb, ctx->rk_b,
+                 ctx->rk_key_bits, ctx->rk_K);
     a.own_lo = FBG_PART_HALO; a.own_hi = FBG_PART_HALO + ctx->part_count;
     a.first_part = ctx->part == 0; a.last_part = ctx->part + 1 == ctx->nparts;
     a.part_mode = ctx->nparts > 1;
@@ -504,8 +796,8 @@ static void rs_part_args(fbg_ctx *ctx, RankArgs &a)
 
 // Phase 1: classify the owned slots, order the tie groups, publish the edge slots (d_blob, FBG_PART_HALO_BYTES).
 // *ok = 0: this partition cannot be handled in rank order (the flag travels in the blob; every rank sees it).
-int fbg_rank_part_classify(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, uint64_t count, int b, int key_bits, int K,
-                           int pre_ok, uint8_t *d_blob, int *ok)
+int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &geom, int pre_ok,
+                           uint8_t *d_blob, int *ok)
 {
     const uint64_t n = ctx->n;
     hipStream_t st = ctx->stream;
@@ -514,7 +806,8 @@ int fbg_rank_part_classify(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, u
     ctx->ranked = false;
     ctx->part_count = count;
     ctx->part_T = 0;
-    ctx->rk_b = b; ctx->rk_key_bits = key_bits; ctx->rk_K = K; ctx->rk_keys = keys; ctx->sa_ptr = vals;
+    rs_remember(ctx, keys, vals, geom);
+    const int packed = geom.packed ? 1 : 0;
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
     FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
@@ -525,26 +818,24 @@ int fbg_rank_part_classify(fbg_ctx *ctx, const uint64_t *keys, uint32_t *vals, u
     if (good && count > (1u << 22)) {                  // similar rows tie almost everywhere: not for this path
         unsigned int *d_hist = reinterpret_cast<unsigned int *>(cnt + 8);
         FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(count, 1024 * 256)), dim3(256), 0, st, keys + a.own_lo, count, b,
-                           key_bits, cnt, d_hist);
+        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(count, 1024 * 256)), dim3(256), 0, st, keys + a.own_lo, a.pb, count,
+                           geom.b, geom.key_bits, cnt, d_hist);
         launches++;
         unsigned long long hs[4];
         FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (hs[2] * 16 > hs[3]) good = 0;
+        if (hs[2] * 4 > hs[3]) good = 0;
     }
     if (good) {
         uint64_t T = 0;
-        FBG_TRY(rs_classify(ctx, a, &T, &launches));
+        FBG_TRY(rs_classify(ctx, a, packed, &T, &launches));
         if (T == ~0ull) good = 0;
         else {
             ctx->part_T = T;
-            if (T > 0) {                               // tie groups longer than 64 raise counters[1]
-                unsigned long long h[2];
-                FBG_HIP_TRY(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
-                FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-                if (h[1] != 0) good = 0;
-            }
+            unsigned long long h[2];                   // tie groups longer than 64 / tie regions too small raise [1]
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (h[1] != 0) good = 0;
         }
     }
     hipLaunchKernelGGL(k_halo_export, dim3(1), dim3(2 * FBG_PART_HALO), 0, st, keys, vals, a.own_lo, a.own_hi, (uint64_t)good, d_blob);
@@ -576,10 +867,10 @@ int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, i
         rs_part_args(ctx, a);
         a.cand = ctx->dp_a.as<uint32_t>(); a.pm = ctx->dp_b.as<uint32_t>();
         hipLaunchKernelGGL(k_halo_import, dim3(1), dim3(FBG_PART_HALO), 0, st, d_blobs, ctx->part, ctx->nparts, a.own_lo,
-                           a.own_hi, const_cast<uint64_t *>(a.keys), a.vals);
+                           a.own_hi, a.keys, a.vals);
         launches++;
         if (ctx->part_T > 0) {
-            hipLaunchKernelGGL(k_runs, dim3(fbg_blocks(ctx->part_T, 64)), dim3(64), 0, st, a, ctx->part_T);
+            RS_LAUNCH(k_runs, ctx->rk_packed, dim3(fbg_blocks(ctx->part_T, 64)), dim3(64), st, a, ctx->part_T);
             launches++;
             unsigned long long h[2];
             FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -605,12 +896,18 @@ int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disabl
     return FBG_OK;
 }
 
-// isa / lcp_prev / lcp_next by text position for fbg_index_download when the index is in rank order
-int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr)
+// sa / isa / lcp_prev / lcp_next by text position for fbg_index_download when the index is in rank order.
+// The small tie groups the scan never had to order are ordered here first.
+int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr)
 {
     RankArgs a;
-    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->N, ctx->rk_b, ctx->rk_key_bits, ctx->rk_K);
-    hipLaunchKernelGGL(k_rank_materialize, dim3(fbg_blocks(ctx->N, 256)), dim3(256), 0, ctx->stream, a, d_isa, d_pl, d_pr);
+    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->N, ctx->rk_packed, ctx->rk_pb, ctx->rk_b, ctx->rk_key_bits, ctx->rk_K);
+    FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
+    a.big = ctx->big_groups.as<uint32_t>();
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 5, 0, sizeof(unsigned long long), ctx->stream));
+    RS_LAUNCH(k_tie_groups, ctx->rk_packed, dim3(fbg_blocks(ctx->N, 256)), dim3(256), ctx->stream, a, ctx->N, 0);
+    RS_LAUNCH(k_tie_big, ctx->rk_packed, dim3(RS_BIG_GROUPS), dim3(256), ctx->stream, a, 1);
+    RS_LAUNCH(k_rank_materialize, ctx->rk_packed, dim3(fbg_blocks(ctx->N, 256)), dim3(256), ctx->stream, a, d_sa, d_isa, d_pl, d_pr);
     FBG_HIP_TRY(ctx, hipGetLastError());
     return FBG_OK;
 }

@@ -49,39 +49,153 @@ __global__ void k_byte_hist(const uint8_t *__restrict__ T, uint64_t N, unsigned 
 // key[p] = first K symbol codes of suffix p, most significant first, zero beyond the text.
 // Each thread owns PK_ITEMS consecutive positions: the first key is packed symbol by symbol, the following
 // ones roll (drop the leading symbol, append one), so the cost per position is one LDS byte read.
+//
+// COMPACT (rank-order scan only): the code table flags separators ('#', the sentinel) with FBG_SEP; a separator
+// and everything after it inside a key count as code 0, which it shares with the smallest symbol.  Such a key is
+// the smallest one with its leading symbols, i.e. the suffix lands where it belongs up to ties, and the scan
+// knows from the row arithmetic how many symbols of a key are real (rank_scan.hip).  Positions beyond the text
+// are separators too.  PACKED: one word per suffix, key << pb | position.  FILTER: keep keys in [lo, hi) only,
+// compacted in no particular order (partitioned index).
 #define PK_ITEMS 8
-__global__ __launch_bounds__(SS_THREADS) void k_pack_keys(const uint8_t *__restrict__ T, uint64_t N,
-                                                          const uint8_t *__restrict__ code, int b, int K,
-                                                          uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+#define FBG_SEP 0x80
+struct PackArgs {
+    const uint8_t *T;
+    uint64_t N;
+    const uint8_t *code;
+    int b, K, pb;
+    uint64_t *keys;            // PACKED: items
+    uint32_t *vals;
+    uint64_t lo, hi, cap;      // FILTER
+    int nohi;
+    unsigned long long *counter;
+};
+
+template <bool COMPACT, bool PACKED, bool FILTER>
+__global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
 {
     constexpr int TILE = SS_THREADS * PK_ITEMS;
     __shared__ uint8_t tile[TILE + 64];      // symbol codes of the block's positions (+K lookahead)
     __shared__ uint8_t cd[256];
-    cd[threadIdx.x] = code[threadIdx.x];
+    __shared__ uint64_t skeys[TILE];         // keys leave through LDS so that the global stores are coalesced
+    const int b = a.b, K = a.K;
+    cd[threadIdx.x] = a.code[threadIdx.x];
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
     for (int k = threadIdx.x; k < TILE + 64; k += SS_THREADS) {
         const uint64_t p = base + k;
-        tile[k] = p < N ? cd[T[p]] : 0;
+        tile[k] = p < a.N ? cd[a.T[p]] : (COMPACT ? FBG_SEP : 0);
     }
     __syncthreads();
     const int t0 = threadIdx.x * PK_ITEMS;
     const uint64_t mask = (K * b) >= 64 ? ~0ull : ((1ull << (K * b)) - 1);
-    __shared__ uint64_t skeys[TILE];         // keys leave through LDS so that the global stores are coalesced
     uint64_t key = 0;
-    for (int k = 0; k < K; k++) key = (key << b) | tile[t0 + k];
+    uint32_t seen = 0;
+    for (int k = 0; k < K; k++) { const uint32_t c = tile[t0 + k]; seen |= c; key = (key << b) | c; }
 #pragma unroll
     for (int i = 0; i < PK_ITEMS; i++) {
         skeys[t0 + i] = key;
-        key = ((key << b) | tile[t0 + K + i]) & mask;
+        const uint32_t c = tile[t0 + K + i];
+        seen |= c;
+        key = ((key << b) | c) & mask;
+    }
+    if (COMPACT && (seen & FBG_SEP)) {       // a separator in reach (K + 8 symbols of a row end): symbol by symbol
+        for (int i = 0; i < PK_ITEMS; i++) {
+            uint64_t kk = 0;
+            bool dead = false;
+            for (int k = 0; k < K; k++) {
+                const uint32_t c = tile[t0 + i + k];
+                dead = dead || (c & FBG_SEP);
+                kk = (kk << b) | (dead ? 0u : c);
+            }
+            skeys[t0 + i] = kk;
+        }
     }
     __syncthreads();
+    if (!FILTER) {
+#pragma unroll
+        for (int i = 0; i < PK_ITEMS; i++) {
+            const int j = threadIdx.x + i * SS_THREADS;
+            const uint64_t p = base + j;
+            if (p < a.N) {
+                if (PACKED) a.keys[p] = (skeys[j] << a.pb) | p;
+                else { a.keys[p] = skeys[j]; a.vals[p] = (uint32_t)p; }
+            }
+        }
+        return;
+    }
+    __shared__ uint32_t wsum[SS_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long keep[PK_ITEMS];
+    uint32_t wtot = 0;
 #pragma unroll
     for (int i = 0; i < PK_ITEMS; i++) {
         const int j = threadIdx.x + i * SS_THREADS;
-        const uint64_t p = base + j;
-        if (p < N) { keys[p] = skeys[j]; vals[p] = (uint32_t)p; }
+        const uint64_t kj = skeys[j];
+        keep[i] = __ballot(base + j < a.N && kj >= a.lo && (a.nohi || kj < a.hi));
+        wtot += (uint32_t)__popcll(keep[i]);
     }
+    if (lane == 0) wsum[w] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int q = 0; q < SS_THREADS / 64; q++) tot += wsum[q];
+        s_base = tot ? atomicAdd(a.counter, (unsigned long long)tot) : 0ull;     // one counter update per workgroup
+    }
+    __syncthreads();
+    uint64_t off = s_base;
+    for (int q = 0; q < w; q++) off += wsum[q];
+#pragma unroll
+    for (int i = 0; i < PK_ITEMS; i++) {
+        const int j = threadIdx.x + i * SS_THREADS;
+        if ((keep[i] >> lane) & 1ull) {
+            const uint64_t o = off + (uint64_t)__popcll(keep[i] & ((1ull << lane) - 1));
+            if (o < a.cap) {
+                if (PACKED) a.keys[o] = (skeys[j] << a.pb) | (base + j);
+                else { a.keys[o] = skeys[j]; a.vals[o] = (uint32_t)(base + j); }
+            }
+        }
+        off += (uint64_t)__popcll(keep[i]);
+    }
+}
+
+static void launch_pack(fbg_ctx *ctx, const KeyGeom &g, bool filter, PackArgs &a)
+{
+    const dim3 grid(fbg_blocks(a.N, SS_THREADS * PK_ITEMS)), block(SS_THREADS);
+    hipStream_t st = ctx->stream;
+#define FBG_PACK(C, P, F) hipLaunchKernelGGL((k_pack<C, P, F>), grid, block, 0, st, a)
+    if (g.compact) {
+        if (g.packed) { if (filter) FBG_PACK(true, true, true); else FBG_PACK(true, true, false); }
+        else          { if (filter) FBG_PACK(true, false, true); else FBG_PACK(true, false, false); }
+    } else {
+        if (filter) FBG_PACK(false, false, true); else FBG_PACK(false, false, false);
+    }
+#undef FBG_PACK
+}
+
+// keys of every stride-th position (same definition as k_pack): splitters and the regime pre-test
+__global__ void k_sample_keys(const uint8_t *__restrict__ T, uint64_t N, const uint8_t *__restrict__ code, int b, int K,
+                              int compact, uint64_t stride, uint64_t S, uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const uint64_t p = i * stride;
+    uint64_t key = 0;
+    bool dead = false;
+    for (int k = 0; k < K; k++) {
+        const uint32_t c = p + k < N ? code[T[p + k]] : (compact ? FBG_SEP : 0);
+        dead = dead || (compact && (c & FBG_SEP));
+        key = (key << b) | (dead ? 0u : c);
+    }
+    out[i] = key;
+}
+
+__global__ void k_count_equal_neighbours(const uint64_t *__restrict__ keys, uint64_t S, unsigned long long *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool eq = i + 1 < S && keys[i] == keys[i + 1];
+    const unsigned long long m = __ballot(eq);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
 // grp[r] = r if key[r] starts a group, else 0  (max-scan turns it into the group head index)
@@ -267,23 +381,41 @@ template <class F> static int with_tmp(fbg_ctx *ctx, F &&call)
 }
 
 // Alphabet compaction (order preserving) and the key geometry: b bits per symbol, K symbols per key.
-int fbg_key_setup(fbg_ctx *ctx, int *b_out, int *K_out, int *key_bits_out, const uint8_t **d_code_out, int *launches)
+// compact = true asks for the separator-free coding of the rank-order scan; g->compact tells whether it applies.
+int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches)
 {
     const uint64_t N = ctx->N;
     hipStream_t st = ctx->stream;
     const uint8_t *T = ctx->text.as<uint8_t>();
     unsigned *d_hist = ctx->small.as<unsigned>() + 256;   // small: bytes [0,256) ignore table, [1024,2048) histogram, [2048,2304) code table
     uint8_t *d_code = ctx->small.as<uint8_t>() + 2048;
-    FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
-    hipLaunchKernelGGL(k_byte_hist, dim3(fbg_blocks(N, 256 * 64, 4096)), dim3(256), 0, st, T, N, d_hist);
-    unsigned hist[256];
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    uint8_t code[256];
-    int sigma = 0;
-    for (int c = 0; c < 256; c++) { code[c] = (uint8_t)sigma; if (hist[c]) sigma++; }
+    unsigned *hist = ctx->byte_hist;
+    if (!ctx->byte_hist_valid) {
+        FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
+        hipLaunchKernelGGL(k_byte_hist, dim3(fbg_blocks(N, 256 * 64, 4096)), dim3(256), 0, st, T, N, d_hist);
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        ctx->byte_hist_valid = true;
+        *launches += 1;
+    }
     if (hist[0] != 1)
         return fbg_fail(ctx, FBG_ERR_INVALID, "the MSA contains a NUL byte; the text needs a unique 0 sentinel");
+    // the compact coding needs '#' to be smaller than every symbol of the rows, and room for the separator flag
+    int below = 0, real = 0;
+    for (int c = 1; c < 256; c++)
+        if (hist[c] && c != '#') { real++; if (c < '#') below++; }
+    compact = compact && below == 0 && real >= 1 && real < FBG_SEP;
+    uint8_t code[256];
+    int sigma = 0;
+    if (compact) {
+        for (int c = 0; c < 256; c++) {
+            if (c == 0 || c == '#') { code[c] = FBG_SEP; continue; }
+            code[c] = (uint8_t)sigma;
+            if (hist[c]) sigma++;
+        }
+    } else {
+        for (int c = 0; c < 256; c++) { code[c] = (uint8_t)sigma; if (hist[c]) sigma++; }
+    }
     int b = 1;
     while ((1 << b) < sigma) b++;
     // symbols per key: enough that only a few percent of the suffixes tie on the whole key (those are ordered by
@@ -291,7 +423,7 @@ int fbg_key_setup(fbg_ctx *ctx, int *b_out, int *K_out, int *key_bits_out, const
     // of the text tells how many symbols that takes: ties ~ N * 2^(-H*K)  =>  K >= (log2 N + 5) / H.
     double H = 0;
     for (int c = 1; c < 256; c++)
-        if (hist[c]) { const double q = (double)hist[c] / (double)N; H -= q * log2(q); }
+        if (hist[c] && !(compact && c == '#')) { const double q = (double)hist[c] / (double)N; H -= q * log2(q); }
     if (H < 0.05) H = 0.05;
     int K = (int)ceil((log2((double)N) + 5.0) / H);
     if (getenv("FBG_FULL_KEYS") || K > 64 / b) K = 64 / b;
@@ -300,10 +432,71 @@ int fbg_key_setup(fbg_ctx *ctx, int *b_out, int *K_out, int *key_bits_out, const
         const int Kfill = (9 * passes) / b;                  // symbols that fit the same number of passes
         K = Kfill < 64 / b ? Kfill : 64 / b;
     }
+    g->compact = compact; g->packed = false; g->pb = 0;
+    if (compact && !getenv("FBG_NO_PACKED")) {
+        // one 64-bit word per suffix if the position leaves room for enough symbols (ties up to ~10% are fine:
+        // small tie groups are settled inside the scan)
+        int pb = 1;
+        while ((1ull << pb) < N) pb++;
+        const int Kroom = (64 - pb) / b;
+        const int Kmin = (int)ceil((log2((double)N) + 3.2) / H);
+        if (Kroom >= Kmin) { g->packed = true; g->pb = pb; if (K > Kroom) K = Kroom; }
+    }
+    g->b = b; g->K = K; g->key_bits = K * b; g->d_code = d_code;
     FBG_HIP_TRY(ctx, hipMemcpyAsync(d_code, code, 256, hipMemcpyHostToDevice, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // code[] lives on this stack frame
-    *b_out = b; *K_out = K; *key_bits_out = K * b; *d_code_out = d_code;
-    *launches += 2;
+    *launches += 1;
+    return FBG_OK;
+}
+
+// sorted (by key) slots of the first `count` entries of the A buffers -> B buffers (+ offset)
+static int sort_slots(fbg_ctx *ctx, const KeyGeom &g, uint64_t count, uint64_t out_offset)
+{
+    hipStream_t st = ctx->stream;
+    uint64_t *ka = ctx->keysA.as<uint64_t>(), *kb = ctx->keysB.as<uint64_t>() + out_offset;
+    if (g.packed) {
+        // rocPRIM 7.2's merge-sort path (inputs below a few million words) mis-sorts a bit range that starts above
+        // bit 0 and ends at bit 64 (scripts/micro/sortcheck.hip); whole words sort correctly and cost nothing there
+        unsigned lo = (unsigned)g.pb;
+        const unsigned hi = (unsigned)(g.pb + g.key_bits);
+        if (hi == 64 && count < (1u << 23)) lo = 0;
+        return with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::radix_sort_keys<fbg_sort_config>(tmp, bytes, ka, kb, (size_t)count, lo, hi, st);
+        });
+    }
+    uint32_t *va = ctx->valsA.as<uint32_t>(), *vb = ctx->valsB.as<uint32_t>() + out_offset;
+    return with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, ka, kb, va, vb, (size_t)count, 0u, (unsigned)g.key_bits, st);
+    });
+}
+
+// Rows that resemble each other tie on almost every key: the rank-order scan is not for them.  Cheap look before
+// the sort: twins among the keys of a sample (the exact test follows after the sort, rank_scan.hip).
+static int sample_says_similar(fbg_ctx *ctx, const KeyGeom &g, bool *similar, int *launches)
+{
+    const uint64_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    *similar = false;
+    if (N < (1u << 22)) return FBG_OK;
+    const uint64_t S = 1u << 20, stride = N / S;
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_g, S * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_h, S * 8));
+    uint64_t *smp = ctx->dp_g.as<uint64_t>(), *srt = ctx->dp_h.as<uint64_t>();
+    unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, st));
+    hipLaunchKernelGGL(k_sample_keys, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, ctx->text.as<uint8_t>(), N, g.d_code, g.b, g.K,
+                       g.compact ? 1 : 0, stride, S, smp);
+    FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::radix_sort_keys(tmp, bytes, smp, srt, (size_t)S, 0u, (unsigned)g.key_bits, st);
+    }));
+    hipLaunchKernelGGL(k_count_equal_neighbours, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, srt, S, d_count);
+    unsigned long long twins = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&twins, d_count, 8, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 3;
+    // a suffix with one twin somewhere shows up as a sample twin with probability S/N: estimated tie fraction
+    const double est = (double)twins * (double)N / ((double)S * (double)S);
+    *similar = est > 0.5;
     return FBG_OK;
 }
 
@@ -314,12 +507,41 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SUFFIX_SORT));
     int launches = 0;
     const uint8_t *T = ctx->text.as<uint8_t>();
-    int b = 0, K = 0, key_bits = 0;
-    const uint8_t *d_code = nullptr;
-    FBG_TRY(fbg_key_setup(ctx, &b, &K, &key_bits, &d_code, &launches));
     ctx->part_active = false;
+    ctx->ranked = false;
+    KeyGeom g;
+
+    // ---- gap-free MSAs: compact keys, sort, and the whole extension scan in rank order (rank_scan.hip) -------
+    if (ctx->gapfree && !ctx->have_ignore && !getenv("FBG_NO_RANKED")) {
+        FBG_TRY(fbg_key_setup(ctx, true, &g, &launches));
+        bool similar = false;
+        FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
+        if (!similar) {
+            FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
+            FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
+            if (!g.packed) {
+                FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
+                FBG_TRY(fbg_reserve(ctx, ctx->valsB, N * 4));
+            }
+            PackArgs pa;
+            pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = g.b; pa.K = g.K; pa.pb = g.pb;
+            pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
+            pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
+            launch_pack(ctx, g, false, pa);
+            launches++;
+            FBG_TRY(sort_slots(ctx, g, N, 0));
+            int done = 0;
+            FBG_TRY(fbg_rank_scan_try(ctx, ctx->keysB.as<uint64_t>(), g.packed ? nullptr : ctx->valsB.as<uint32_t>(), g, &done));
+            if (done) {
+                FBG_HIP_TRY(ctx, hipGetLastError());
+                return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
+            }
+        }
+    }
 
     // ---- round 0: sort all suffixes by their first K symbols -------------------------------
+    FBG_TRY(fbg_key_setup(ctx, false, &g, &launches));
+    const int b = g.b, K = g.K, key_bits = g.key_bits;
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
@@ -337,49 +559,14 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     ct.row_len = (uint32_t)(ctx->n + 1);
     ct.n = (uint32_t)ctx->n;
     ct.last = (uint32_t)(N - 1);
-
-    hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code, b, K,
-                       keysA, valsA);
-    launches += 1;
-    // hybrid sort: radix passes on the leading ~log2(N)-3 key bits only, then every small group of pairs sharing
-    // those bits is finished locally in one pass (group_sort.hip); all bits by radix if a group is too long
-    int top_bits = 9;
-    while (top_bits < key_bits && (1ull << top_bits) < N / 8) top_bits += 9;
-    bool hybrid = top_bits < key_bits && N > (1u << 20) && getenv("FBG_HYBRID_SORT");   // off by default: see DESIGN.md
-    if (hybrid) {
-        const unsigned lo = (unsigned)(key_bits - top_bits);
-        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, lo, (unsigned)key_bits, st);
-        }));
-        int ok = 0;
-        FBG_TRY(fbg_group_sort(ctx, keysB, valsB, keysA, valsA, N, (int)lo, &ok));
-        launches += 1;
-        if (ok) {
-            // the sorted pairs are in the A buffers: make "B" name them, as the rest of the pipeline expects
-            std::swap(ctx->keysA, ctx->keysB);
-            std::swap(ctx->valsA, ctx->valsB);
-            keysA = ctx->keysA.as<uint64_t>(); keysB = ctx->keysB.as<uint64_t>();
-            valsA = ctx->valsA.as<uint32_t>(); valsB = ctx->valsB.as<uint32_t>();
-            sa = valsB;
-            ctx->sa_ptr = sa;
-        } else {
-            hybrid = false;   // skewed keys: start over with all bits
-            hipLaunchKernelGGL(k_pack_keys, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code,
-                               b, K, keysA, valsA);
-        }
-    }
-    if (!hybrid) {
-        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, keysA, keysB, valsA, valsB, (size_t)N, 0u, (unsigned)key_bits, st);
-        }));
-    }
-    {   // gap-free MSAs: the whole extension scan can be done right here, in rank order (rank_scan.hip)
-        int done = 0;
-        FBG_TRY(fbg_rank_scan_try(ctx, keysB, valsB, b, key_bits, K, &done));
-        if (done) {
-            FBG_HIP_TRY(ctx, hipGetLastError());
-            return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
-        }
+    {
+        PackArgs pa;
+        pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = b; pa.K = K; pa.pb = 0;
+        pa.keys = keysA; pa.vals = valsA;
+        pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
+        launch_pack(ctx, g, false, pa);
+        launches++;
+        FBG_TRY(sort_slots(ctx, g, N, 0));
     }
     FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->flags, N));
@@ -474,82 +661,9 @@ int fbg_suffix_sort(fbg_ctx *ctx)
 
 // ---- partitioned index: this GPU sorts only the suffixes whose key lies in its range ------------------------
 // Every rank of a multi-GPU job holds the whole text (MSAs are small next to their index: 1 byte per symbol
-// against 24 bytes of sort state), computes the same splitters from the same key sample, and then packs,
+// against 16-24 bytes of sort state), computes the same splitters from the same key sample, and then packs,
 // sorts and scans only its own key range: sort state and sort time divide by the number of GPUs.  The ranks
 // exchange nothing but FBG_PART_HALO edge slots each and the per-column maxima (rank_scan.hip, distributed.py).
-__global__ void k_sample_keys(const uint8_t *__restrict__ T, uint64_t N, const uint8_t *__restrict__ code, int b, int K,
-                              uint64_t stride, uint64_t S, uint64_t *__restrict__ out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S) return;
-    const uint64_t p = i * stride;
-    uint64_t key = 0;
-    for (int k = 0; k < K; k++) key = (key << b) | (p + k < N ? code[T[p + k]] : 0);
-    out[i] = key;
-}
-
-// k_pack_keys, keeping only keys in [lo, hi) (hi ignored when nohi): compacted, in no particular order
-__global__ __launch_bounds__(SS_THREADS) void k_pack_filter(const uint8_t *__restrict__ T, uint64_t N,
-                                                            const uint8_t *__restrict__ code, int b, int K, uint64_t lo,
-                                                            uint64_t hi, int nohi, uint64_t cap,
-                                                            unsigned long long *__restrict__ counter,
-                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    constexpr int TILE = SS_THREADS * PK_ITEMS;
-    __shared__ uint8_t tile[TILE + 64];
-    __shared__ uint8_t cd[256];
-    __shared__ uint64_t skeys[TILE];
-    __shared__ uint32_t wsum[SS_THREADS / 64];
-    __shared__ unsigned long long s_base;
-    cd[threadIdx.x] = code[threadIdx.x];
-    __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    for (int k = threadIdx.x; k < TILE + 64; k += SS_THREADS) {
-        const uint64_t p = base + k;
-        tile[k] = p < N ? cd[T[p]] : 0;
-    }
-    __syncthreads();
-    const int t0 = threadIdx.x * PK_ITEMS;
-    const uint64_t mask = (K * b) >= 64 ? ~0ull : ((1ull << (K * b)) - 1);
-    uint64_t key = 0;
-    for (int k = 0; k < K; k++) key = (key << b) | tile[t0 + k];
-#pragma unroll
-    for (int i = 0; i < PK_ITEMS; i++) {
-        skeys[t0 + i] = key;
-        key = ((key << b) | tile[t0 + K + i]) & mask;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned long long keep[PK_ITEMS];
-    uint32_t wtot = 0;
-#pragma unroll
-    for (int i = 0; i < PK_ITEMS; i++) {
-        const int j = threadIdx.x + i * SS_THREADS;
-        const uint64_t kj = skeys[j];
-        keep[i] = __ballot(base + j < N && kj >= lo && (nohi || kj < hi));
-        wtot += (uint32_t)__popcll(keep[i]);
-    }
-    if (lane == 0) wsum[w] = wtot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int q = 0; q < SS_THREADS / 64; q++) tot += wsum[q];
-        s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;     // one counter update per workgroup
-    }
-    __syncthreads();
-    uint64_t off = s_base;
-    for (int q = 0; q < w; q++) off += wsum[q];
-#pragma unroll
-    for (int i = 0; i < PK_ITEMS; i++) {
-        const int j = threadIdx.x + i * SS_THREADS;
-        if ((keep[i] >> lane) & 1ull) {
-            const uint64_t o = off + (uint64_t)__popcll(keep[i] & ((1ull << lane) - 1));
-            if (o < cap) { keys[o] = skeys[j]; vals[o] = (uint32_t)(base + j); }
-        }
-        off += (uint64_t)__popcll(keep[i]);
-    }
-}
-
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
 {
     const uint64_t N = ctx->N;
@@ -557,11 +671,11 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SUFFIX_SORT));
     int launches = 0;
     const uint8_t *T = ctx->text.as<uint8_t>();
-    int b = 0, K = 0, key_bits = 0;
-    const uint8_t *d_code = nullptr;
-    FBG_TRY(fbg_key_setup(ctx, &b, &K, &key_bits, &d_code, &launches));
-    ctx->part = part; ctx->nparts = nparts; ctx->part_active = true;
+    KeyGeom g;
     int pre_ok = ctx->gapfree && !ctx->have_ignore && !getenv("FBG_NO_RANKED");
+    FBG_TRY(fbg_key_setup(ctx, pre_ok != 0, &g, &launches));
+    pre_ok = pre_ok && g.compact;
+    ctx->part = part; ctx->nparts = nparts; ctx->part_active = true;
     uint64_t count = 0;
     // splitters: quantiles of a sorted key sample -- the same on every rank, ties never straddle a boundary
     uint64_t S = N / 64;
@@ -573,9 +687,9 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
         FBG_TRY(fbg_reserve(ctx, ctx->dp_g, S * 8));
         FBG_TRY(fbg_reserve(ctx, ctx->dp_h, S * 8));
         uint64_t *smp = ctx->dp_g.as<uint64_t>(), *smp_sorted = ctx->dp_h.as<uint64_t>();
-        hipLaunchKernelGGL(k_sample_keys, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, T, N, d_code, b, K, stride, S, smp);
+        hipLaunchKernelGGL(k_sample_keys, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, T, N, g.d_code, g.b, g.K, 1, stride, S, smp);
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_keys(tmp, bytes, smp, smp_sorted, (size_t)S, 0u, (unsigned)key_bits, st);
+            return rocprim::radix_sort_keys(tmp, bytes, smp, smp_sorted, (size_t)S, 0u, (unsigned)g.key_bits, st);
         }));
         launches += 2;
         if (part > 0)
@@ -584,19 +698,19 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
             FBG_HIP_TRY(ctx, hipMemcpyAsync(&hi, smp_sorted + (uint64_t)(part + 1) * S / nparts, 8, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    const int nohi = part + 1 >= nparts;
-    uint64_t *keys_out = nullptr;
-    uint32_t *vals_out = nullptr;
     if (pre_ok) {
         unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
         uint64_t cap = N / nparts + N / 8 + 65536;
         if (cap > N) cap = N;
         for (int attempt = 0; attempt < 2; attempt++) {
             FBG_TRY(fbg_reserve(ctx, ctx->keysA, cap * 8));
-            FBG_TRY(fbg_reserve(ctx, ctx->valsA, cap * 4));
+            if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsA, cap * 4));
             FBG_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 8, st));
-            hipLaunchKernelGGL(k_pack_filter, dim3(fbg_blocks(N, SS_THREADS * PK_ITEMS)), dim3(SS_THREADS), 0, st, T, N, d_code,
-                               b, K, lo, hi, nohi, cap, d_count, ctx->keysA.as<uint64_t>(), ctx->valsA.as<uint32_t>());
+            PackArgs pa;
+            pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = g.b; pa.K = g.K; pa.pb = g.pb;
+            pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
+            pa.lo = lo; pa.hi = hi; pa.cap = cap; pa.nohi = part + 1 >= nparts; pa.counter = d_count;
+            launch_pack(ctx, g, true, pa);
             launches++;
             unsigned long long hc = 0;
             FBG_HIP_TRY(ctx, hipMemcpyAsync(&hc, d_count, 8, hipMemcpyDeviceToHost, st));
@@ -608,17 +722,10 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     }
     const uint64_t slots = count + 2 * FBG_PART_HALO;
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, slots * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->valsB, slots * 4));
-    keys_out = ctx->keysB.as<uint64_t>();
-    vals_out = ctx->valsB.as<uint32_t>();
-    if (pre_ok && count > 0) {
-        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, ctx->keysA.as<uint64_t>(), keys_out + FBG_PART_HALO,
-                                                              ctx->valsA.as<uint32_t>(), vals_out + FBG_PART_HALO,
-                                                              (size_t)count, 0u, (unsigned)key_bits, st);
-        }));
-    }
+    if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsB, slots * 4));
+    if (pre_ok && count > 0) FBG_TRY(sort_slots(ctx, g, count, FBG_PART_HALO));
     FBG_HIP_TRY(ctx, hipGetLastError());
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches));
-    return fbg_rank_part_classify(ctx, keys_out, vals_out, count, b, key_bits, K, pre_ok, d_blob, ok);
+    return fbg_rank_part_classify(ctx, ctx->keysB.as<uint64_t>(), g.packed ? nullptr : ctx->valsB.as<uint32_t>(), count, g,
+                                  pre_ok, d_blob, ok);
 }

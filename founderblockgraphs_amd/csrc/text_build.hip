@@ -182,6 +182,7 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_TEXT));
     int launches = 0;
+    ctx->byte_hist_valid = false;
     FBG_TRY(fbg_reserve(ctx, ctx->pos, m * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->tot, m * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->scalars, 256 * sizeof(unsigned long long)));

@@ -125,17 +125,23 @@ def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=Fal
     blob = torch.empty(PART_HALO_BYTES, dtype=torch.uint8, device=device)
     blobs = torch.empty(world * PART_HALO_BYTES, dtype=torch.uint8, device=device)
     gmax = torch.empty(n + 1, dtype=torch.int32, device=device)
-    torch.cuda.current_stream().synchronize()
+
+    def fence():       # torch's stream and the engine's may differ: order their work explicitly
+        if torch.device(device).type == "cuda":
+            torch.cuda.current_stream().synchronize()
+        engine.sync()
+
+    fence()
     engine.part_index_build(rank, world, blob.data_ptr(), reversed)   # verdict travels inside the blob
-    engine.sync()
+    fence()
     if world > 1:
         dist.all_gather_into_tensor(blobs, blob, group=group)
     else:
         blobs.copy_(blob)
-    torch.cuda.current_stream().synchronize()
+    fence()
     engine.part_scan(blobs.data_ptr(), gmax.data_ptr())               # verdict travels in gmax[n]
-    engine.sync()
+    fence()
     if world > 1:
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-    torch.cuda.current_stream().synchronize()
+    fence()
     return engine.part_finish(gmax.data_ptr())

@@ -94,3 +94,101 @@ def _worker_pairs(rank, world, port, out_dir):
 def test_two_rank_row_group_pairs(tmp_path):
     """The capacity plan used when m*(n+1)+1 >= 2^32: pairs of row groups, element-wise max of f."""
     mp.spawn(_worker_pairs, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+class _OraclePartEngine:
+    """CPU stand-in for the fbg_part_* calls of libfbg_hip.so, built on the oracle's index arrays: partition r
+    owns the suffix-array slots [N*r/W, N*(r+1)/W) and contributes the extensions g of exactly those suffixes
+    (fbg.cpp:1633-1657 for gap-free rows).  Same calling convention: raw addresses of caller-owned buffers."""
+
+    def __init__(self, msa, fail=False):
+        from oracle import pyoracle as O
+        self.msa, self.fail = msa, fail
+        self.m, self.n = msa.shape
+        _, self.SA, self.ISA, lcp = O.msa_index(msa)
+        self.LCP = np.concatenate([lcp.astype(np.int64), [0]])
+        self.gmax = None
+
+    @staticmethod
+    def _view(ptr, nbytes, dtype):
+        import ctypes
+        return np.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=dtype)
+
+    def sync(self):
+        pass
+
+    def part_index_build(self, part, nparts, blob_ptr, reversed=False):
+        from founderblockgraphs_amd._lib import PART_HALO, PART_HALO_BYTES
+        assert not reversed
+        self.part, self.nparts = part, nparts
+        blob = self._view(blob_ptr, PART_HALO_BYTES, np.uint8)
+        blob[:] = 0
+        tail = self._view(blob_ptr + 2 * PART_HALO * 12, 16, np.uint64)
+        tail[0] = 0 if self.fail else 1
+        return not self.fail
+
+    def part_scan(self, blobs_ptr, gmax_ptr):
+        from founderblockgraphs_amd._lib import PART_HALO, PART_HALO_BYTES
+        oks = [int(self._view(blobs_ptr + p * PART_HALO_BYTES + 2 * PART_HALO * 12, 16, np.uint64)[0])
+               for p in range(self.nparts)]
+        g = self._view(gmax_ptr, 4 * (self.n + 1), np.int32)
+        g[:] = 0
+        if not all(oks):
+            g[self.n] = 1
+            return False
+        N = len(self.SA)
+        lo, hi = N * self.part // self.nparts, N * (self.part + 1) // self.nparts
+        for x in range(self.n):
+            r = np.sort(self.ISA[np.arange(self.m) * (self.n + 1) + x].astype(np.int64))
+            k = 0
+            while k < self.m:
+                e = k
+                while e + 1 < self.m and r[e + 1] == r[e] + 1:
+                    e += 1
+                lb, rb = r[k], r[e]
+                for q in range(lb, rb + 1):
+                    if lo <= q < hi:
+                        ext = 1 + max(self.LCP[lb:q + 1].min(), self.LCP[q + 1:rb + 2].min())
+                        g[x] = max(g[x], ext)
+                k = e + 1
+        return True
+
+    def part_finish(self, gmax_ptr):
+        g = self._view(gmax_ptr, 4 * (self.n + 1), np.int32)
+        if g[self.n] != 0:
+            return False
+        self.gmax = g[:self.n].astype(np.int64)
+        return True
+
+    def f(self):
+        """k_rank_finish: fbg.cpp:1618-1666 with rank_i(x) = x, tot_i = n (gap-free rows)."""
+        n, x = self.n, np.arange(self.n)
+        fi = np.where(x + self.gmax > n, n - 1, x + self.gmax - 1)
+        f = np.maximum(x, fi)
+        f[0] = 0
+        return f
+
+
+def _worker_part(rank, world, port, fail_rank, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from founderblockgraphs_amd import distributed as D
+    from oracle import pyoracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    msa = random_msa(np.random.default_rng(11), 9, 160, similar=0.8)
+    eng = _OraclePartEngine(msa, fail=(rank == fail_rank))
+    ok = D.partitioned_index(eng, msa.shape[1], device="cpu")
+    assert ok == (fail_rank < 0)                     # one failing partition: every rank declines
+    if ok:
+        assert np.array_equal(eng.f().astype(np.uint64), O.compute_f(msa))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 0, 1])
+def test_two_rank_partitioned_index(fail_rank, tmp_path):
+    """Key-range partitioned index: halo all-gather + all-reduce(max) of the column maxima, verdict included."""
+    mp.spawn(_worker_part, args=(2, _free_port(), fail_rank, str(tmp_path)), nprocs=2, join=True)

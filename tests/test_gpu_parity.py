@@ -353,9 +353,9 @@ def test_nonelastic_dp_random_v(engine, max_len):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(similar=0.97), dict(gap_p=0.01, gap_run=8)], ids=["iid", "similar", "gaps"])
-def test_hybrid_sort_regime(engine, kw):
-    """Texts above 2^20 symbols take the hybrid sort (radix on the leading bits + local group sort), similar rows
-    make it fall back to the full radix sort: index arrays and f must equal the oracle's either way."""
+def test_large_text_index_arrays(engine, kw):
+    """Texts above 2^20 symbols (packed compact keys for the iid rows, record path for the other two): index
+    arrays and f must equal the oracle's."""
     rng = np.random.default_rng(77)
     msa = random_msa(rng, 48, 24000, **kw)
     T, SA, ISA, LCP = O.msa_index(msa)
@@ -377,6 +377,8 @@ ALT_PATHS = [
     {"FBG_NO_RANKED": "1", "FBG_LCP_TEXT": "1"},     # ... with Kasai text comparison instead of key-derived LCPs
     {"FBG_FULL_KEYS": "1"},                          # 64-bit keys instead of entropy-sized ones
     {"FBG_RANK_NO_THRESHOLD": "1"},                  # rank-order scan without the sampled threshold
+    {"FBG_NO_PACKED": "1"},                          # rank-order scan on (key, position) pairs instead of packed words
+    {"FBG_NO_PACKED": "1", "FBG_FULL_KEYS": "1"},
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
     {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
@@ -401,6 +403,7 @@ def test_alternative_paths_stay_bit_identical(engine, env):
             gb, gmml, gbt = engine.minmax_dp(g, full=True)
             assert np.array_equal(gmml, mml) and np.array_equal(gbt, bt) and np.array_equal(gb, b)
             if ord("-") not in msa:
+                assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))       # no ignore chars: rank-order scan
                 v = O.segment_v(msa)
                 gv = engine.repeatfree_v(msa)
                 assert np.array_equal(gv, v)
@@ -530,3 +533,48 @@ def test_partitioned_index_full_size():
     finally:
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}], ids=["packed", "pairs", "nothreshold"])
+def test_rank_scan_sampled_regime_matches_oracle(engine, env):
+    """Texts above 2^22 symbols use the sampled threshold and regime test of the rank-order scan: f and v must
+    still be the oracle's, for iid rows and for rows with shared stretches (ties, runs, short suffixes)."""
+    import os
+    rng = np.random.default_rng(99)
+    a = random_msa(rng, 150, 30000)
+    b = random_msa(rng, 150, 30000, similar=0.6)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for msa in (a, b):
+            assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))
+            assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("alphabet", ["A", "AC", "ACGT", "ACGTN"])
+def test_rank_scan_short_rows_and_heavy_ties(engine, alphabet):
+    """Rows shorter than a key, tiny alphabets, repeated rows: every suffix is 'short' or tied.  Index arrays and
+    f / v against the oracle (exercises the separator coding, tie ordering from the suffix start, runs)."""
+    rng = np.random.default_rng(len(alphabet))
+    for (m, n, kw) in [(3, 1, {}), (4, 2, {}), (6, 5, {}), (9, 13, {}), (12, 40, {}), (5, 200, dict(similar=0.9)),
+                       (40, 30, dict(similar=0.7)), (70, 64, {}), (8, 700, dict(similar=0.98))]:
+        msa = random_msa(rng, m, n, alphabet=alphabet, **kw)
+        T, SA, ISA, LCP = O.msa_index(msa)
+        engine.msa_load_host(msa)
+        engine.index_build()
+        gT, gSA, gISA, gPL, gPR = engine.index_download()
+        assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64)), (alphabet, m, n)
+        lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
+        assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA])
+        assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1])
+        assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa)), (alphabet, m, n)
+        exp = O.compute_f(msa, disable_tricks=True)
+        if exp[0] != n:                                  # otherwise the engine reports "no valid segmentation"
+            assert np.array_equal(engine.elastic_f(msa, disable_efg_tricks=True), exp)
+        assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa)), (alphabet, m, n)
