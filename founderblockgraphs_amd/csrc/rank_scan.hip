@@ -144,26 +144,26 @@ __device__ __forceinline__ void rs_append(bool want, uint32_t *counts, uint32_t 
 // k_rank_scan stages a chunk of 256 slots (+ RS_HALO either side) in LDS as (key, column): all the looking around
 // that tie groups need happens there.
 #define RS_HALO 8
-#define RS_CHUNK 256
+#define RS_ITEMS 4
+#define RS_THREADS 256
+#define RS_CHUNK (RS_THREADS * RS_ITEMS)
 
 __device__ __forceinline__ uint32_t rs_rem_of(const RankArgs &a, uint32_t col)
 {
     return col == a.n ? 0u : (a.reversed ? col + 1 : (uint32_t)a.n - col);
 }
 
-// i: LDS index of the slot (slot k = base + i - RS_HALO); valid LDS indices are [lo_i, hi_i)
-__device__ __forceinline__ void rank_scan_slot(const RankArgs &a, const uint64_t *skey, const uint32_t *scol, const int i,
-                                               const int lo_i, const int hi_i, const uint64_t k)
+// Slots that tie with a neighbour on the whole key, and slots next to such a group, need to look around.
+// i: LDS index of the slot (slot k = base + i - RS_HALO); valid LDS indices are [lo_i, hi_i).
+__device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t *skey, const uint32_t *scol, const int i,
+                                               const int lo_i, const int hi_i, const uint64_t k, bool &want_cand, bool &want_tie)
 {
     const uint32_t n32 = (uint32_t)a.n;
-    const bool in = i < hi_i;
     const uint64_t key = skey[i];
     const uint32_t col = scol[i];
-    const bool has_prev = in && i > lo_i, has_next = in && i + 1 < hi_i;   // neighbours inside the owned range
+    const bool has_prev = i > lo_i, has_next = i + 1 < hi_i;               // neighbours inside the owned range
     const uint64_t kp = skey[i - 1], kn = skey[i + 1];
-    const bool eqp = has_prev && kp == key, eqn = has_next && kn == key;
-    const bool tie = eqp || eqn;
-    bool want_cand = false, want_tie = false;
+    const bool tie = (has_prev && kp == key) || (has_next && kn == key);
     if (tie) {
         // bounds of the group, looking at most RS_TG slots either way
         int h = i, t = i;
@@ -208,79 +208,159 @@ __device__ __forceinline__ void rank_scan_slot(const RankArgs &a, const uint64_t
         }
         if (simple) want_tie = i == h;
         else want_cand = true;
-    } else if (in && col != n32) {
-        // not a tie: both LCPs come from the keys, unless a neighbour shares the column (a run)
-        const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);       // neighbour not known yet
-        const uint32_t rem = rs_rem_of(a, col);
-        bool run = (has_prev && scol[i - 1] == col) || (has_next && scol[i + 1] == col);
-        uint32_t mrp = has_prev ? rs_rem_of(a, scol[i - 1]) : 0u, mrn = has_next ? rs_rem_of(a, scol[i + 1]) : 0u;
-        if (has_prev && i - 1 > lo_i && skey[i - 2] == kp) {
-            // the slot before is a tie group whose final order is not known here: any member may end up next to
-            // this slot.  Same column anywhere in it -> run treatment; LCP with it: the member with most symbols left
-            int j = i - 1, cnt = 0;
-            uint32_t mr = 0;
-            for (;;) {
-                const uint32_t cj = scol[j];
-                mr = max(mr, rs_rem_of(a, cj));
-                run = run || cj == col;
-                cnt++;
-                if (j == lo_i || skey[j - 1] != kp) break;
-                if (cnt == RS_TG) { run = true; break; }
-                j--;
-            }
-            mrp = mr;
-        }
-        if (has_next && i + 2 < hi_i && skey[i + 2] == kn) {
-            int j = i + 1, cnt = 0;
-            uint32_t mr = 0;
-            for (;;) {
-                const uint32_t cj = scol[j];
-                mr = max(mr, rs_rem_of(a, cj));
-                run = run || cj == col;
-                cnt++;
-                if (j + 1 >= hi_i || skey[j + 1] != kn) break;
-                if (cnt == RS_TG) { run = true; break; }
-                j++;
-            }
-            mrn = mr;
-        }
-        if (edge || run) want_cand = true;
-        else {
-            const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), mrp) : 0u;
-            const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), mrn) : 0u;
-            const uint32_t g = max(lp, ln) + 1;
-            // near the end of a row few suffixes compete and extensions stay short: no threshold there
-            const uint32_t c_raw = a.reversed ? n32 - 1 - col : col;
-            if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
-        }
+        return;
     }
-    if (a.values_only) return;                         // uniform
-    rs_append(want_cand, a.blk_count, a.cand, a.region, (uint32_t)k);
-    rs_append(want_tie, a.tie_count, a.ties, a.tie_region, (uint32_t)k);
+    if (col == n32) return;
+    // not a tie itself, but next to a tie group whose final order is not known here: any member may end up next to
+    // this slot.  Same column anywhere in it -> run treatment; LCP with it: the member with most symbols left
+    const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);           // neighbour not known yet
+    const uint32_t rem = rs_rem_of(a, col);
+    bool run = (has_prev && scol[i - 1] == col) || (has_next && scol[i + 1] == col);
+    uint32_t mrp = has_prev ? rs_rem_of(a, scol[i - 1]) : 0u, mrn = has_next ? rs_rem_of(a, scol[i + 1]) : 0u;
+    if (has_prev && i - 1 > lo_i && skey[i - 2] == kp) {
+        int j = i - 1, cnt = 0;
+        uint32_t mr = 0;
+        for (;;) {
+            const uint32_t cj = scol[j];
+            mr = max(mr, rs_rem_of(a, cj));
+            run = run || cj == col;
+            cnt++;
+            if (j == lo_i || skey[j - 1] != kp) break;
+            if (cnt == RS_TG) { run = true; break; }
+            j--;
+        }
+        mrp = mr;
+    }
+    if (has_next && i + 2 < hi_i && skey[i + 2] == kn) {
+        int j = i + 1, cnt = 0;
+        uint32_t mr = 0;
+        for (;;) {
+            const uint32_t cj = scol[j];
+            mr = max(mr, rs_rem_of(a, cj));
+            run = run || cj == col;
+            cnt++;
+            if (j + 1 >= hi_i || skey[j + 1] != kn) break;
+            if (cnt == RS_TG) { run = true; break; }
+            j++;
+        }
+        mrn = mr;
+    }
+    if (edge || run) { want_cand = true; return; }
+    const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), mrp) : 0u;
+    const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), mrn) : 0u;
+    const uint32_t g = max(lp, ln) + 1;
+    const uint32_t c_raw = a.reversed ? n32 - 1 - col : col;
+    if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
 }
 
-// a few thousand workgroups, each walking 256-slot chunks of the SA (a launch of N/256 tiny workgroups spends
-// more time being dispatched than working)
-template <bool PK> __global__ __launch_bounds__(RS_CHUNK) void k_rank_scan(RankArgs a)
+// A few thousand workgroups, each walking chunks of RS_CHUNK slots of the SA.  Per chunk: (1) keys and columns
+// into LDS -- the global loads of the NEXT chunk are issued right away, so their latency hides behind this chunk's
+// work; (2) every slot that neither ties nor sits next to a tie group is finished on the spot, the others queue
+// up; (3) the queue is worked off by as many lanes as it has entries, instead of a few lanes in every wave.
+template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
 {
     __shared__ uint64_t skey[RS_CHUNK + 2 * RS_HALO];
     __shared__ uint32_t scol[RS_CHUNK + 2 * RS_HALO];
+    __shared__ uint16_t sq[RS_CHUNK];
+    __shared__ uint32_t sqn;
+    const uint32_t n32 = (uint32_t)a.n;
+    const int lane = threadIdx.x & 63;
     const uint64_t nchunks = (a.own_hi - a.own_lo + RS_CHUNK - 1) / RS_CHUNK;
+    // registers for one chunk: LDS entries e = tid + RS_THREADS * r, r = 0..RS_ITEMS (the last one: the 2*RS_HALO extra)
+    uint64_t w[RS_ITEMS + 1];
+    uint32_t v[RS_ITEMS + 1];
+    auto fetch = [&](uint64_t c) {
+        const uint64_t base = a.own_lo + c * RS_CHUNK;
+        const int lo_i = c == 0 ? RS_HALO : 0;
+        const int hi_i = (int)min((uint64_t)(RS_CHUNK + 2 * RS_HALO), a.own_hi - base + RS_HALO);
+#pragma unroll
+        for (int r = 0; r <= RS_ITEMS; r++) {
+            const int e = (int)threadIdx.x + RS_THREADS * r;
+            w[r] = 0; v[r] = 0;
+            if (e >= lo_i && e < hi_i && (r < RS_ITEMS || threadIdx.x < 2 * RS_HALO)) {
+                w[r] = a.keys[base + e - RS_HALO];
+                if (!PK) v[r] = a.vals[base + e - RS_HALO];
+            }
+        }
+    };
+    if (blockIdx.x < nchunks) fetch(blockIdx.x);
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint64_t base = a.own_lo + c * RS_CHUNK;                 // slot of LDS index RS_HALO
         const int lo_i = c == 0 ? RS_HALO : 0;                         // LDS index of the first / one past the last owned slot
         const int hi_i = (int)min((uint64_t)(RS_CHUNK + 2 * RS_HALO), a.own_hi - base + RS_HALO);
-        for (int i = threadIdx.x; i < RS_CHUNK + 2 * RS_HALO; i += RS_CHUNK) {
-            uint64_t key = 0;
-            uint32_t col = (uint32_t)a.n;
-            if (i >= lo_i && i < hi_i) {
-                const Slot s = rs_slot<PK>(a, base + i - RS_HALO);
-                key = s.key; col = s.col;
+        if (threadIdx.x == 0) sqn = 0;
+#pragma unroll
+        for (int r = 0; r <= RS_ITEMS; r++) {
+            const int e = (int)threadIdx.x + RS_THREADS * r;
+            if (r < RS_ITEMS || threadIdx.x < 2 * RS_HALO) {
+                uint64_t key = 0;
+                uint32_t col = n32, rem;
+                if (e >= lo_i && e < hi_i) {
+                    key = PK ? w[r] >> a.pb : w[r];
+                    rs_colrem(a, PK ? (uint32_t)(w[r] & a.pmask) : v[r], col, rem);
+                }
+                skey[e] = key; scol[e] = col;
             }
-            skey[i] = key; scol[i] = col;
         }
         __syncthreads();
-        rank_scan_slot(a, skey, scol, (int)threadIdx.x + RS_HALO, lo_i, hi_i, base + threadIdx.x);
+        if (c + gridDim.x < nchunks) fetch(c + gridDim.x);
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const int i = (int)threadIdx.x + RS_THREADS * r + RS_HALO;
+            const uint64_t k = base + (uint64_t)(i - RS_HALO);
+            const bool in = i < hi_i;
+            const uint64_t key = skey[i], kp = skey[i - 1], kn = skey[i + 1];
+            const uint32_t col = scol[i];
+            const bool has_prev = in && i > lo_i, has_next = in && i + 1 < hi_i;
+            const bool tie = (has_prev && kp == key) || (has_next && kn == key);
+            const bool near = (has_prev && i - 1 > lo_i && skey[i - 2] == kp) || (has_next && i + 2 < hi_i && skey[i + 2] == kn);
+            const bool slow = tie || (in && near && col != n32);
+            bool want_cand = false;
+            if (in && !slow && col != n32) {
+                // both LCPs come from the keys, unless a neighbour shares the column (a run)
+                const uint32_t cp = scol[i - 1], cn = scol[i + 1];
+                const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);
+                if (edge || (has_prev && cp == col) || (has_next && cn == col)) want_cand = true;
+                else {
+                    const uint32_t rem = rs_rem_of(a, col);
+                    const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), rs_rem_of(a, cp)) : 0u;
+                    const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), rs_rem_of(a, cn)) : 0u;
+                    const uint32_t g = max(lp, ln) + 1;
+                    // near the end of a row few suffixes compete and extensions stay short: no threshold there
+                    const uint32_t c_raw = a.reversed ? n32 - 1 - col : col;
+                    if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
+                }
+            }
+            const unsigned long long smask = __ballot(slow);
+            if (smask) {
+                uint32_t qb = 0;
+                const int leader = __ffsll((long long)smask) - 1;
+                if (lane == leader) qb = atomicAdd(&sqn, (uint32_t)__popcll(smask));
+                qb = __shfl(qb, leader, 64);
+                if (slow) sq[qb + (uint32_t)__popcll(smask & ((1ull << lane) - 1))] = (uint16_t)i;
+            }
+            if (!a.values_only) rs_append(want_cand, a.blk_count, a.cand, a.region, (uint32_t)k);
+        }
+        __syncthreads();
+        {
+            const uint32_t qn = sqn;
+            for (uint32_t q0 = 0; q0 < qn; q0 += RS_THREADS) {
+                if (q0 + (threadIdx.x & ~63u) >= qn) break;            // wave-uniform
+                const uint32_t q = q0 + threadIdx.x;
+                bool want_cand = false, want_tie = false;
+                uint64_t k = 0;
+                if (q < qn) {
+                    const int i = sq[q];
+                    k = base + (uint64_t)(i - RS_HALO);
+                    const bool is_tie = (i > lo_i && skey[i - 1] == skey[i]) || (i + 1 < hi_i && skey[i + 1] == skey[i]);
+                    if (!(a.values_only && is_tie)) rank_scan_slow(a, skey, scol, i, lo_i, hi_i, k, want_cand, want_tie);
+                }
+                if (!a.values_only) {
+                    rs_append(want_cand, a.blk_count, a.cand, a.region, (uint32_t)k);
+                    rs_append(want_tie, a.tie_count, a.ties, a.tie_region, (uint32_t)k);
+                }
+            }
+        }
         __syncthreads();
     }
 }
@@ -622,7 +702,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int packed, uint64_t *T_out, i
 {
     hipStream_t st = ctx->stream;
     const uint64_t own = a.own_hi - a.own_lo;
-    const unsigned rs_blocks = fbg_blocks(own, 256, 256 * 32);
+    const unsigned rs_blocks = fbg_blocks(own, RS_CHUNK, 256 * 16);
     const uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
     const uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
     FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rs_blocks * region * 4));
@@ -639,7 +719,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int packed, uint64_t *T_out, i
     a.ties = ctx->tie_list.as<uint32_t>();
     a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    RS_LAUNCH(k_rank_scan, packed, dim3(rs_blocks), dim3(256), st, a);
+    RS_LAUNCH(k_rank_scan, packed, dim3(rs_blocks), dim3(RS_THREADS), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     RS_LAUNCH(k_tie_simple, packed, dim3(rs_blocks), dim3(256), st, a);
     *launches += 2;
@@ -741,7 +821,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     if (a.g_min > 1 && h[4] != 0) {
         a.g_min = 0;
         a.values_only = 1;
-        RS_LAUNCH(k_rank_scan, packed, dim3(fbg_blocks(N, 256, 256 * 32)), dim3(256), st, a);
+        RS_LAUNCH(k_rank_scan, packed, dim3(fbg_blocks(N, RS_CHUNK, 256 * 16)), dim3(RS_THREADS), st, a);
         launches++;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
