@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, in
 }
 
 struct RankArgs {
-    uint64_t magic;            // floor(2^64 / row_len) + 1: p / row_len == umul64hi(p, magic) for p < 2^32
+    uint32_t magic32;          // floor(2^32 / row_len): umulhi(p, magic32) is p / row_len or one less
     uint64_t *keys;            // sorted slots: keys, or packed words key << pb | position
     uint32_t *vals;            // positions in SA order (pairs layout; final once the tie groups are ordered)
     uint64_t pmask;            // packed: (1 << pb) - 1
@@ -59,6 +59,7 @@ struct RankArgs {
     uint64_t own_lo, own_hi;   // slots this launch owns; the rest are halo copies of the neighbouring partitions
     int first_part, last_part; // partition holds the globally first / last suffix (no neighbour beyond)
     int part_mode;             // >1 partitions: slots next to a partition edge are re-examined once the halos are in
+    int dbg;                   // timing experiments only (FBG_RS_DBG)
     int values_only;           // second pass for columns the threshold starved: no lists, no threshold
     uint32_t row_len;          // n + 1
     uint32_t g_min;            // extensions below this cannot be a column maximum (sampled; verified afterwards)
@@ -82,12 +83,22 @@ struct Slot {
     uint32_t rem;              // symbols left in the row from this position on (0 for '#' / sentinel)
 };
 
+// symbols left in the row of text position p (0 for '#' / sentinel); p < 2^32
+__device__ __forceinline__ uint32_t rs_rem(const RankArgs &a, uint32_t p)
+{
+    uint32_t c = p - __umulhi(p, a.magic32) * a.row_len;               // p mod (n+1), possibly one row_len too much
+    if (c >= a.row_len) c -= a.row_len;
+    return p == (uint32_t)(a.Ntext - 1) ? 0u : (uint32_t)a.n - c;
+}
+// MSA column of a row pointer with `rem` symbols left; n for '#' / sentinel (never a row pointer without gaps)
+__device__ __forceinline__ uint32_t rs_col_of_rem(const RankArgs &a, uint32_t rem)
+{
+    return rem == 0 ? (uint32_t)a.n : (a.reversed ? rem - 1 : (uint32_t)a.n - rem);
+}
 __device__ __forceinline__ void rs_colrem(const RankArgs &a, uint32_t p, uint32_t &col, uint32_t &rem)
 {
-    if (p == a.Ntext - 1) { col = (uint32_t)a.n; rem = 0; return; }
-    const uint32_t c = p - (uint32_t)__umul64hi((uint64_t)p, a.magic) * a.row_len;    // p mod (n+1)
-    rem = (uint32_t)a.n - c;
-    col = c == a.n ? c : (a.reversed ? (uint32_t)a.n - 1 - c : c);
+    rem = rs_rem(a, p);
+    col = rs_col_of_rem(a, rem);
 }
 
 template <bool PK> __device__ __forceinline__ uint64_t rs_key(const RankArgs &a, uint64_t k)
@@ -125,15 +136,16 @@ __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint3
     if (a.gmax[col] < g) atomicMax(&a.gmax[col], g);
 }
 
-// one wave-aggregated append per list: a single counter update per wave, on the workgroup's own counter
-__device__ __forceinline__ void rs_append(bool want, uint32_t *counts, uint32_t *list, uint32_t region, uint32_t value)
+// one wave-aggregated append per list: a single update per wave of the workgroup's counter (LDS; it goes to
+// global memory once, when the workgroup is done)
+__device__ __forceinline__ void rs_append(bool want, uint32_t *counter, uint32_t *list, uint32_t region, uint32_t value)
 {
     const unsigned long long mask = __ballot(want);
     if (!mask) return;
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
     const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) base = atomicAdd(&counts[blockIdx.x], (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader, 64);
     if (want) {
         const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
@@ -148,19 +160,13 @@ __device__ __forceinline__ void rs_append(bool want, uint32_t *counts, uint32_t 
 #define RS_THREADS 256
 #define RS_CHUNK (RS_THREADS * RS_ITEMS)
 
-__device__ __forceinline__ uint32_t rs_rem_of(const RankArgs &a, uint32_t col)
-{
-    return col == a.n ? 0u : (a.reversed ? col + 1 : (uint32_t)a.n - col);
-}
-
 // Slots that tie with a neighbour on the whole key, and slots next to such a group, need to look around.
 // i: LDS index of the slot (slot k = base + i - RS_HALO); valid LDS indices are [lo_i, hi_i).
-__device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t *skey, const uint32_t *scol, const int i,
+__device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t *skey, const uint32_t *srem, const int i,
                                                const int lo_i, const int hi_i, const uint64_t k, bool &want_cand, bool &want_tie)
 {
-    const uint32_t n32 = (uint32_t)a.n;
     const uint64_t key = skey[i];
-    const uint32_t col = scol[i];
+    const uint32_t rem = srem[i];
     const bool has_prev = i > lo_i, has_next = i + 1 < hi_i;               // neighbours inside the owned range
     const uint64_t kp = skey[i - 1], kn = skey[i + 1];
     const bool tie = (has_prev && kp == key) || (has_next && kn == key);
@@ -182,8 +188,8 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
             for (int q = 0; q < RS_TG; q++) {
                 cols[q] = 0xffffffffu - (uint32_t)q;
                 if (q < s) {
-                    cols[q] = scol[h + q];
-                    if (rs_rem_of(a, cols[q]) < (uint32_t)a.K) simple = false;
+                    cols[q] = srem[h + q];
+                    if (cols[q] < (uint32_t)a.K) simple = false;
                 }
             }
 #pragma unroll
@@ -193,14 +199,14 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
                     if (cols[q] == cols[r]) simple = false;
             if (simple && h > lo_i) {
                 if (h - 1 > lo_i && skey[h - 2] == skey[h - 1]) simple = false;                // tie groups side by side
-                const uint32_t oc = scol[h - 1];
+                const uint32_t oc = srem[h - 1];
 #pragma unroll
                 for (int q = 0; q < RS_TG; q++)
                     if (cols[q] == oc) simple = false;
             }
             if (simple && t + 1 < hi_i) {
                 if (t + 2 < hi_i && skey[t + 2] == skey[t + 1]) simple = false;
-                const uint32_t oc = scol[t + 1];
+                const uint32_t oc = srem[t + 1];
 #pragma unroll
                 for (int q = 0; q < RS_TG; q++)
                     if (cols[q] == oc) simple = false;
@@ -210,20 +216,19 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
         else want_cand = true;
         return;
     }
-    if (col == n32) return;
+    if (rem == 0) return;
     // not a tie itself, but next to a tie group whose final order is not known here: any member may end up next to
     // this slot.  Same column anywhere in it -> run treatment; LCP with it: the member with most symbols left
     const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);           // neighbour not known yet
-    const uint32_t rem = rs_rem_of(a, col);
-    bool run = (has_prev && scol[i - 1] == col) || (has_next && scol[i + 1] == col);
-    uint32_t mrp = has_prev ? rs_rem_of(a, scol[i - 1]) : 0u, mrn = has_next ? rs_rem_of(a, scol[i + 1]) : 0u;
+    bool run = (has_prev && srem[i - 1] == rem) || (has_next && srem[i + 1] == rem);
+    uint32_t mrp = has_prev ? srem[i - 1] : 0u, mrn = has_next ? srem[i + 1] : 0u;
     if (has_prev && i - 1 > lo_i && skey[i - 2] == kp) {
         int j = i - 1, cnt = 0;
         uint32_t mr = 0;
         for (;;) {
-            const uint32_t cj = scol[j];
-            mr = max(mr, rs_rem_of(a, cj));
-            run = run || cj == col;
+            const uint32_t rj = srem[j];
+            mr = max(mr, rj);
+            run = run || rj == rem;
             cnt++;
             if (j == lo_i || skey[j - 1] != kp) break;
             if (cnt == RS_TG) { run = true; break; }
@@ -235,9 +240,9 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
         int j = i + 1, cnt = 0;
         uint32_t mr = 0;
         for (;;) {
-            const uint32_t cj = scol[j];
-            mr = max(mr, rs_rem_of(a, cj));
-            run = run || cj == col;
+            const uint32_t rj = srem[j];
+            mr = max(mr, rj);
+            run = run || rj == rem;
             cnt++;
             if (j + 1 >= hi_i || skey[j + 1] != kn) break;
             if (cnt == RS_TG) { run = true; break; }
@@ -249,87 +254,147 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
     const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), mrp) : 0u;
     const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), mrn) : 0u;
     const uint32_t g = max(lp, ln) + 1;
-    const uint32_t c_raw = a.reversed ? n32 - 1 - col : col;
-    if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
+    if (g >= a.g_min || rem <= 64) rs_update(a, rs_col_of_rem(a, rem), g);
 }
 
-// A few thousand workgroups, each walking chunks of RS_CHUNK slots of the SA.  Per chunk: (1) keys and columns
-// into LDS -- the global loads of the NEXT chunk are issued right away, so their latency hides behind this chunk's
-// work; (2) every slot that neither ties nor sits next to a tie group is finished on the spot, the others queue
-// up; (3) the queue is worked off by as many lanes as it has entries, instead of a few lanes in every wave.
+// A few thousand workgroups, each walking chunks of RS_CHUNK slots of the SA; a thread owns RS_ITEMS consecutive
+// slots.  Per chunk: (1) keys and columns into LDS -- the global loads of the NEXT chunk are issued right away, so
+// their latency hides behind this chunk's work; (2) every slot that neither ties nor sits next to a tie group is
+// finished on the spot from registers (its neighbours are the thread's own slots or the adjacent lanes'), the
+// others queue up; (3) the queue is worked off, out of LDS, by as many lanes as it has entries instead of a few
+// lanes in every wave.
 template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
 {
     __shared__ uint64_t skey[RS_CHUNK + 2 * RS_HALO];
-    __shared__ uint32_t scol[RS_CHUNK + 2 * RS_HALO];
+    __shared__ uint32_t srem[RS_CHUNK + 2 * RS_HALO];   // symbols left in the row: names the column as well
     __shared__ uint16_t sq[RS_CHUNK];
-    __shared__ uint32_t sqn;
-    const uint32_t n32 = (uint32_t)a.n;
+    __shared__ uint32_t sqn, s_cand_n, s_tie_n;
     const int lane = threadIdx.x & 63;
     const uint64_t nchunks = (a.own_hi - a.own_lo + RS_CHUNK - 1) / RS_CHUNK;
-    // registers for one chunk: LDS entries e = tid + RS_THREADS * r, r = 0..RS_ITEMS (the last one: the 2*RS_HALO extra)
+    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
+    // registers for one chunk: the thread's RS_ITEMS slots, plus one of the 2 * RS_HALO extra entries (threads 0..15)
     uint64_t w[RS_ITEMS + 1];
     uint32_t v[RS_ITEMS + 1];
+    const int my_i = RS_HALO + RS_ITEMS * (int)threadIdx.x;            // LDS index of the thread's first slot
+    const int halo_i = (int)threadIdx.x < RS_HALO ? (int)threadIdx.x : RS_CHUNK + (int)threadIdx.x;   // threads < 2 * RS_HALO
     auto fetch = [&](uint64_t c) {
-        const uint64_t base = a.own_lo + c * RS_CHUNK;
+        const uint64_t base = a.own_lo + c * RS_CHUNK;                 // slot of LDS index RS_HALO
         const int lo_i = c == 0 ? RS_HALO : 0;
         const int hi_i = (int)min((uint64_t)(RS_CHUNK + 2 * RS_HALO), a.own_hi - base + RS_HALO);
 #pragma unroll
-        for (int r = 0; r <= RS_ITEMS; r++) {
-            const int e = (int)threadIdx.x + RS_THREADS * r;
+        for (int r = 0; r < RS_ITEMS; r++) {
             w[r] = 0; v[r] = 0;
-            if (e >= lo_i && e < hi_i && (r < RS_ITEMS || threadIdx.x < 2 * RS_HALO)) {
-                w[r] = a.keys[base + e - RS_HALO];
-                if (!PK) v[r] = a.vals[base + e - RS_HALO];
+            if (my_i + r < hi_i) {
+                w[r] = a.keys[base + (uint64_t)(my_i + r - RS_HALO)];
+                if (!PK) v[r] = a.vals[base + (uint64_t)(my_i + r - RS_HALO)];
             }
+        }
+        w[RS_ITEMS] = 0; v[RS_ITEMS] = 0;
+        if (threadIdx.x < 2 * RS_HALO && halo_i >= lo_i && halo_i < hi_i) {
+            w[RS_ITEMS] = a.keys[base + halo_i - RS_HALO];
+            if (!PK) v[RS_ITEMS] = a.vals[base + halo_i - RS_HALO];
         }
     };
     if (blockIdx.x < nchunks) fetch(blockIdx.x);
     for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint64_t base = a.own_lo + c * RS_CHUNK;                 // slot of LDS index RS_HALO
+        const uint64_t base = a.own_lo + c * RS_CHUNK;
         const int lo_i = c == 0 ? RS_HALO : 0;                         // LDS index of the first / one past the last owned slot
         const int hi_i = (int)min((uint64_t)(RS_CHUNK + 2 * RS_HALO), a.own_hi - base + RS_HALO);
         if (threadIdx.x == 0) sqn = 0;
+        uint64_t kk[RS_ITEMS + 6];                                     // keys of slots my_i - 3 .. my_i + RS_ITEMS + 2
+        uint32_t cc[RS_ITEMS + 4];                                     // columns of slots my_i - 2 .. my_i + RS_ITEMS + 1
 #pragma unroll
-        for (int r = 0; r <= RS_ITEMS; r++) {
-            const int e = (int)threadIdx.x + RS_THREADS * r;
-            if (r < RS_ITEMS || threadIdx.x < 2 * RS_HALO) {
-                uint64_t key = 0;
-                uint32_t col = n32, rem;
-                if (e >= lo_i && e < hi_i) {
-                    key = PK ? w[r] >> a.pb : w[r];
-                    rs_colrem(a, PK ? (uint32_t)(w[r] & a.pmask) : v[r], col, rem);
-                }
-                skey[e] = key; scol[e] = col;
+        for (int r = 0; r < RS_ITEMS; r++) {
+            uint64_t key = 0;
+            uint32_t rem = 0;
+            if (my_i + r < hi_i) {
+                key = PK ? w[r] >> a.pb : w[r];
+                rem = rs_rem(a, PK ? (uint32_t)(w[r] & a.pmask) : v[r]);
             }
+            kk[r + 3] = key; cc[r + 2] = rem;
+            skey[my_i + r] = key; srem[my_i + r] = rem;
+        }
+        if (threadIdx.x < 2 * RS_HALO) {
+            uint64_t key = 0;
+            uint32_t rem = 0;
+            if (halo_i >= lo_i && halo_i < hi_i) {
+                key = PK ? w[RS_ITEMS] >> a.pb : w[RS_ITEMS];
+                rem = rs_rem(a, PK ? (uint32_t)(w[RS_ITEMS] & a.pmask) : v[RS_ITEMS]);
+            }
+            skey[halo_i] = key; srem[halo_i] = rem;
         }
         __syncthreads();
         if (c + gridDim.x < nchunks) fetch(c + gridDim.x);
+        // the neighbours beyond the thread's own slots: adjacent lanes, LDS at the wave's edges
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            kk[j] = __shfl_up(kk[RS_ITEMS + j], 1, 64);                // lane - 1's last three slots
+            kk[RS_ITEMS + 3 + j] = __shfl_down(kk[3 + j], 1, 64);      // lane + 1's first three
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            cc[j] = __shfl_up(cc[RS_ITEMS + j], 1, 64);
+            cc[RS_ITEMS + 2 + j] = __shfl_down(cc[2 + j], 1, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) kk[j] = skey[my_i - 3 + j];
+            cc[0] = srem[my_i - 2]; cc[1] = srem[my_i - 1];
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) kk[RS_ITEMS + 3 + j] = skey[my_i + RS_ITEMS + j];
+            cc[RS_ITEMS + 2] = srem[my_i + RS_ITEMS]; cc[RS_ITEMS + 3] = srem[my_i + RS_ITEMS + 1];
+        }
+        uint32_t upd_g[RS_ITEMS], upd_c[RS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) { upd_g[r] = 0; upd_c[r] = 0; }
+        uint32_t lcp[RS_ITEMS + 1];                                    // key LCP of slots my_i + r - 1 and my_i + r (K for equal keys)
+#pragma unroll
+        for (int r = 0; r <= RS_ITEMS; r++) lcp[r] = rs_key_lcp(kk[r + 2], kk[r + 3], a.b, a.key_bits);
+        if (!(a.dbg & 4))
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) {
-            const int i = (int)threadIdx.x + RS_THREADS * r + RS_HALO;
+            // slot i with keys K[-3..3] = kk[r .. r+6] and columns C[-2..2] = cc[r .. r+4]
+            const int i = my_i + r;
             const uint64_t k = base + (uint64_t)(i - RS_HALO);
             const bool in = i < hi_i;
-            const uint64_t key = skey[i], kp = skey[i - 1], kn = skey[i + 1];
-            const uint32_t col = scol[i];
-            const bool has_prev = in && i > lo_i, has_next = in && i + 1 < hi_i;
-            const bool tie = (has_prev && kp == key) || (has_next && kn == key);
-            const bool near = (has_prev && i - 1 > lo_i && skey[i - 2] == kp) || (has_next && i + 2 < hi_i && skey[i + 2] == kn);
-            const bool slow = tie || (in && near && col != n32);
-            bool want_cand = false;
-            if (in && !slow && col != n32) {
-                // both LCPs come from the keys, unless a neighbour shares the column (a run)
-                const uint32_t cp = scol[i - 1], cn = scol[i + 1];
-                const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);
-                if (edge || (has_prev && cp == col) || (has_next && cn == col)) want_cand = true;
-                else {
-                    const uint32_t rem = rs_rem_of(a, col);
-                    const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), rs_rem_of(a, cp)) : 0u;
-                    const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), rs_rem_of(a, cn)) : 0u;
-                    const uint32_t g = max(lp, ln) + 1;
-                    // near the end of a row few suffixes compete and extensions stay short: no threshold there
-                    const uint32_t c_raw = a.reversed ? n32 - 1 - col : col;
-                    if (g >= a.g_min || c_raw + 64 >= a.n) rs_update(a, col, g);
-                }
+            const bool window = i - 3 >= lo_i && i + 3 < hi_i;         // all of it inside the owned range
+            const uint64_t key = kk[r + 3];
+            const uint32_t rem = cc[r + 2];
+            const bool eqp = kk[r + 2] == key, eqn = kk[r + 4] == key;
+            bool slow = in && !window;                                 // range ends: the general code sorts it out
+            bool want_cand = false, want_cand2 = false, want_tie = false;
+            if (window) {
+                const bool prev_tie = kk[r + 1] == kk[r + 2], next_tie = kk[r + 5] == kk[r + 4];    // the neighbour ties with ITS neighbour
+                if (!eqp && !eqn) {
+                    if (rem != 0) {
+                        // both LCPs come from the keys, unless a neighbour shares the column (a run).  A neighbour that
+                        // is half of a tied pair: either half may end up next to this slot
+                        if ((prev_tie && kk[r] == kk[r + 1]) || (next_tie && kk[r + 6] == kk[r + 5])) slow = true;   // longer groups
+                        else {
+                            bool run = cc[r + 1] == rem || cc[r + 3] == rem;
+                            uint32_t mrp = cc[r + 1], mrn = cc[r + 3];
+                            if (prev_tie) { run = run || cc[r] == rem; mrp = max(mrp, cc[r]); }
+                            if (next_tie) { run = run || cc[r + 4] == rem; mrn = max(mrn, cc[r + 4]); }
+                            if (run) want_cand = true;
+                            else {
+                                const uint32_t g = max(min(lcp[r], min(rem, mrp)), min(lcp[r + 1], min(rem, mrn))) + 1;
+                                // near the end of a row few suffixes compete and extensions stay short: no threshold there
+                                if (g >= a.g_min || rem <= 64) { upd_g[r] = g; upd_c[r] = rs_col_of_rem(a, rem); }
+                            }
+                        }
+                    }
+                } else if (!eqp && kk[r + 5] != key && i + 4 < hi_i) {
+                    // head of a tied pair (slots i, i + 1): settled here.  Simple = both with K real symbols, the two
+                    // columns and those of the slots before and after all different, no tie group right next to it
+                    const uint32_t r1 = cc[r + 3], rb = cc[r + 1], ra = cc[r + 4];
+                    const bool simple = rem >= (uint32_t)a.K && r1 >= (uint32_t)a.K && rem != r1 &&
+                                        !prev_tie && rb != rem && rb != r1 &&
+                                        kk[r + 6] != kk[r + 5] && ra != rem && ra != r1;
+                    if (simple) want_tie = true;
+                    else { want_cand = true; want_cand2 = true; }
+                } else if (!(eqp && !eqn && kk[r + 1] != key && i - 4 >= lo_i)) slow = true;    // not the tail of a pair settled by its head
             }
             const unsigned long long smask = __ballot(slow);
             if (smask) {
@@ -339,11 +404,20 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
                 qb = __shfl(qb, leader, 64);
                 if (slow) sq[qb + (uint32_t)__popcll(smask & ((1ull << lane) - 1))] = (uint16_t)i;
             }
-            if (!a.values_only) rs_append(want_cand, a.blk_count, a.cand, a.region, (uint32_t)k);
+            if (!a.values_only) {
+                rs_append(want_cand, &s_cand_n, a.cand, a.region, (uint32_t)k);
+                rs_append(want_cand2, &s_cand_n, a.cand, a.region, (uint32_t)k + 1);
+                rs_append(want_tie, &s_tie_n, a.ties, a.tie_region, (uint32_t)k);
+            }
         }
+        // column maxima: the table reads of the thread's slots go out together (g = 0: nothing to do) and are
+        // looked at after the queue has been worked off
+        uint32_t cur[RS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) cur[r] = (upd_g[r] && !(a.dbg & 2)) ? a.gmax[upd_c[r]] : 0xffffffffu;
         __syncthreads();
         {
-            const uint32_t qn = sqn;
+            const uint32_t qn = (a.dbg & 1) ? 0u : sqn;
             for (uint32_t q0 = 0; q0 < qn; q0 += RS_THREADS) {
                 if (q0 + (threadIdx.x & ~63u) >= qn) break;            // wave-uniform
                 const uint32_t q = q0 + threadIdx.x;
@@ -353,16 +427,20 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
                     const int i = sq[q];
                     k = base + (uint64_t)(i - RS_HALO);
                     const bool is_tie = (i > lo_i && skey[i - 1] == skey[i]) || (i + 1 < hi_i && skey[i + 1] == skey[i]);
-                    if (!(a.values_only && is_tie)) rank_scan_slow(a, skey, scol, i, lo_i, hi_i, k, want_cand, want_tie);
+                    if (!(a.values_only && is_tie)) rank_scan_slow(a, skey, srem, i, lo_i, hi_i, k, want_cand, want_tie);
                 }
                 if (!a.values_only) {
-                    rs_append(want_cand, a.blk_count, a.cand, a.region, (uint32_t)k);
-                    rs_append(want_tie, a.tie_count, a.ties, a.tie_region, (uint32_t)k);
+                    rs_append(want_cand, &s_cand_n, a.cand, a.region, (uint32_t)k);
+                    rs_append(want_tie, &s_tie_n, a.ties, a.tie_region, (uint32_t)k);
                 }
             }
         }
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++)
+            if (cur[r] < upd_g[r]) atomicMax(&a.gmax[upd_c[r]], upd_g[r]);
         __syncthreads();
     }
+    if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
 }
 
 // the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
@@ -678,7 +756,7 @@ static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *va
     a.pb = packed ? pb : 0; a.pmask = packed ? (1ull << pb) - 1 : 0;
     a.N = slots; a.Ntext = ctx->N; a.n = ctx->n; a.row_len = (uint32_t)(ctx->n + 1);
     a.own_lo = 0; a.own_hi = slots; a.first_part = a.last_part = 1; a.part_mode = 0; a.values_only = 0;
-    a.magic = ~0ull / (ctx->n + 1) + 1;
+    a.magic32 = (uint32_t)((1ull << 32) / (ctx->n + 1));
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>();
     a.cand = nullptr; a.pm = nullptr; a.blk_count = nullptr; a.region = 0;
@@ -686,6 +764,7 @@ static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *va
     a.big = ctx->big_groups.as<uint32_t>();
     a.counters = ctx->scalars.as<unsigned long long>() + 32;
     a.g_min = 0;
+    a.dbg = getenv("FBG_RS_DBG") ? atoi(getenv("FBG_RS_DBG")) : 0;
 }
 
 static void rs_remember(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g)
