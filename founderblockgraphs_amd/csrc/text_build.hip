@@ -46,33 +46,62 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total,
     return base + inc - v;
 }
 
-// tot[i] = number of non-gap cells of row i; scalars[0] += gaps, scalars[1] += ignore cells
+// tot[i] += number of non-gap cells of segment blockIdx.x of row blockIdx.y; scalars[0] += gaps,
+// scalars[1] += ignore cells; hist[c] += cells holding byte c (the symbol histogram of the text follows from it:
+// fbg_build_text).  The histogram is kept per workgroup in LDS; equal bytes within a wave are counted with one
+// ballot and one update (DNA: 4-5 rounds per 64 bytes instead of 64 colliding atomics).
+#define RC_SEG 65536
+#define RC_UNROLL 8
 __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restrict__ msa, uint64_t n,
                                                           const uint8_t *__restrict__ is_ignore,
                                                           uint32_t *__restrict__ tot,
-                                                          unsigned long long *__restrict__ scalars)
+                                                          unsigned long long *__restrict__ scalars,
+                                                          unsigned *__restrict__ hist)
 {
     __shared__ uint32_t red[2][TB_THREADS / 64];
-    const uint64_t i = blockIdx.x;
+    __shared__ uint32_t sh[256];
+    const uint64_t i = blockIdx.y;
     const uint8_t *row = msa + i * n;
+    const uint64_t x_lo = (uint64_t)blockIdx.x * RC_SEG, x_hi = min(n, x_lo + RC_SEG);
+    const int lane = threadIdx.x & 63;
+    sh[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t nongap = 0, ign = 0;
-    for (uint64_t x = threadIdx.x; x < n; x += TB_THREADS) {
-        uint8_t c = row[x];
-        nongap += c != '-';
-        if (is_ignore) ign += is_ignore[c];
+    for (uint64_t x = x_lo + threadIdx.x; x < x_lo + RC_SEG; x += (uint64_t)TB_THREADS * RC_UNROLL) {   // uniform trip count
+        uint32_t c[RC_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RC_UNROLL; u++) {
+            const uint64_t xx = x + (uint64_t)u * TB_THREADS;
+            c[u] = xx < x_hi ? (uint32_t)row[xx] : 0x100u;             // 0x100: past the end
+        }
+#pragma unroll
+        for (int u = 0; u < RC_UNROLL; u++) {
+            const bool valid = c[u] < 0x100u;
+            nongap += valid && c[u] != '-';
+            if (is_ignore && valid) ign += is_ignore[c[u]];
+            unsigned long long rest = __ballot(valid);
+            while (rest) {
+                const int l = __ffsll((long long)rest) - 1;
+                const uint32_t v = __shfl(c[u], l, 64);
+                const unsigned long long same = __ballot(c[u] == v);
+                if (lane == l) atomicAdd(&sh[v], (uint32_t)__popcll(same));
+                rest &= ~same;
+            }
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         nongap += __shfl_down(nongap, d, 64);
         ign += __shfl_down(ign, d, 64);
     }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nongap; red[1][threadIdx.x >> 6] = ign; }
+    if (lane == 0) { red[0][threadIdx.x >> 6] = nongap; red[1][threadIdx.x >> 6] = ign; }
     __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
     if (threadIdx.x == 0) {
         uint32_t a = 0, b = 0;
         for (int k = 0; k < TB_THREADS / 64; k++) { a += red[0][k]; b += red[1][k]; }
-        tot[i] = a;
-        atomicAdd(&scalars[0], (unsigned long long)(n - a));
-        atomicAdd(&scalars[1], (unsigned long long)b);
+        atomicAdd(&tot[i], a);
+        atomicAdd(&scalars[0], (unsigned long long)((x_hi > x_lo ? x_hi - x_lo : 0) - a));
+        if (b) atomicAdd(&scalars[1], (unsigned long long)b);
     }
 }
 
@@ -200,14 +229,23 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // table[] is on this stack frame
     }
     unsigned long long *sc = ctx->scalars.as<unsigned long long>();
-    hipLaunchKernelGGL(k_row_count, dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,
-                       ctx->tot.as<uint32_t>(), sc);
+    unsigned *d_hist = ctx->small.as<unsigned>() + 256;            // small: bytes [1024, 2048)
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->tot.p, 0, m * 4, st));
+    hipLaunchKernelGGL(k_row_count, dim3((unsigned)((n + RC_SEG - 1) / RC_SEG), (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
+                       n, d_is_ignore, ctx->tot.as<uint32_t>(), sc, d_hist);
     hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(64), 0, st, ctx->tot.as<uint32_t>(), m,
                        ctx->pos.as<uint32_t>(), sc);
     launches += 2;
     unsigned long long h[3];
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->byte_hist, d_hist, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    // symbol histogram of the text: the cells without the gaps, a '#' per row, the sentinel
+    ctx->byte_hist['-'] = 0;
+    ctx->byte_hist['#'] += (unsigned)m;
+    ctx->byte_hist[0] += 1;
+    ctx->byte_hist_valid = true;
     ctx->gapfree = h[0] == 0;
     ctx->N = h[2];
     if (ctx->N >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit ranks", h[2]);
