@@ -67,26 +67,48 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
     sh[threadIdx.x] = 0;
     __syncthreads();
     uint32_t nongap = 0, ign = 0;
-    for (uint64_t x = x_lo + threadIdx.x; x < x_lo + RC_SEG; x += (uint64_t)TB_THREADS * RC_UNROLL) {   // uniform trip count
-        uint32_t c[RC_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RC_UNROLL; u++) {
-            const uint64_t xx = x + (uint64_t)u * TB_THREADS;
-            c[u] = xx < x_hi ? (uint32_t)row[xx] : 0x100u;             // 0x100: past the end
+    auto count = [&](uint32_t c, bool valid) {                         // one byte per lane
+        nongap += valid && c != '-';
+        if (is_ignore && valid) ign += is_ignore[c];
+        unsigned long long rest = __ballot(valid);
+        while (rest) {
+            const int l = __ffsll((long long)rest) - 1;
+            const uint32_t v = __shfl(c, l, 64);
+            const unsigned long long same = __ballot(valid && c == v);
+            if (lane == l) atomicAdd(&sh[v], (uint32_t)__popcll(same));
+            rest &= ~same;
         }
+    };
+    if ((((uintptr_t)row + x_lo) & 3) == 0) {
+        // 4 bytes per lane and load (rows of MSAs whose width is a multiple of 4 all start aligned)
+        const uint32_t *words = reinterpret_cast<const uint32_t *>(row + x_lo);
+        const uint64_t nbytes = x_hi > x_lo ? x_hi - x_lo : 0, nwords = nbytes / 4;
+        for (uint64_t q = threadIdx.x; q < RC_SEG / 4; q += (uint64_t)TB_THREADS * RC_UNROLL) {     // uniform trip count
+            uint32_t wv[RC_UNROLL];
 #pragma unroll
-        for (int u = 0; u < RC_UNROLL; u++) {
-            const bool valid = c[u] < 0x100u;
-            nongap += valid && c[u] != '-';
-            if (is_ignore && valid) ign += is_ignore[c[u]];
-            unsigned long long rest = __ballot(valid);
-            while (rest) {
-                const int l = __ffsll((long long)rest) - 1;
-                const uint32_t v = __shfl(c[u], l, 64);
-                const unsigned long long same = __ballot(c[u] == v);
-                if (lane == l) atomicAdd(&sh[v], (uint32_t)__popcll(same));
-                rest &= ~same;
+            for (int u = 0; u < RC_UNROLL; u++) {
+                const uint64_t qq = q + (uint64_t)u * TB_THREADS;
+                wv[u] = qq < nwords ? words[qq] : 0u;
             }
+#pragma unroll
+            for (int u = 0; u < RC_UNROLL; u++) {
+                const bool valid = q + (uint64_t)u * TB_THREADS < nwords;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) count((wv[u] >> (8 * bb)) & 0xffu, valid);
+            }
+        }
+        const uint64_t tail = x_lo + nwords * 4 + threadIdx.x;         // up to three bytes left (first wave only)
+        if (threadIdx.x < 64) count(tail < x_hi ? (uint32_t)row[tail] : 0u, tail < x_hi);
+    } else {
+        for (uint64_t x = x_lo + threadIdx.x; x < x_lo + RC_SEG; x += (uint64_t)TB_THREADS * RC_UNROLL) {   // uniform trip count
+            uint32_t c[RC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RC_UNROLL; u++) {
+                const uint64_t xx = x + (uint64_t)u * TB_THREADS;
+                c[u] = xx < x_hi ? (uint32_t)row[xx] : 0x100u;         // 0x100: past the end
+            }
+#pragma unroll
+            for (int u = 0; u < RC_UNROLL; u++) count(c[u] & 0xffu, c[u] < 0x100u);
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -157,6 +179,42 @@ __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__rest
     if (threadIdx.x == 0) {
         T[p0 + tot[i]] = '#';
         if (GAPPED) colT[p0 + tot[i]] = (uint32_t)n;
+    }
+}
+
+// Gap-free rows, left to right: the text is the MSA with a '#' after every row.  Row i moves from msa + i*n to
+// T + i*(n+1): source and destination are aligned differently in every row, so each destination word is put
+// together from the two aligned source words that hold its bytes (v_alignbyte); all global accesses are 4 bytes
+// wide and coalesced.  blockIdx.y = row, blockIdx.x = segment of CR_SEG destination bytes.
+#define CR_SEG 32768
+__global__ __launch_bounds__(TB_THREADS) void k_copy_rows(const uint8_t *__restrict__ msa, uint64_t n, uint64_t m,
+                                                          uint8_t *__restrict__ T)
+{
+    const uint64_t i = blockIdx.y;
+    const uint8_t *src = msa + i * n;
+    uint8_t *dst = T + i * (n + 1);
+    const uint64_t x_lo = (uint64_t)blockIdx.x * CR_SEG, x_hi = min(n, x_lo + CR_SEG);
+    if (x_lo >= x_hi) return;
+    // destination words fully inside [x_lo, x_hi): from the first aligned address on
+    const uint64_t head = (4 - ((uintptr_t)(dst + x_lo) & 3)) & 3;      // bytes before the first aligned word
+    const uint64_t xa = min(x_hi, x_lo + head);
+    const uint64_t nwords = (x_hi - xa) / 4;
+    const uint64_t xt = xa + nwords * 4;                               // tail bytes [xt, x_hi)
+    if (threadIdx.x < 8) {
+        const uint64_t x = threadIdx.x < 4 ? x_lo + threadIdx.x : xt + (threadIdx.x - 4);
+        const uint64_t end = threadIdx.x < 4 ? xa : x_hi;
+        if (x < end) dst[x] = src[x];
+    }
+    if (threadIdx.x == 8 && x_hi == n) dst[n] = '#';
+    const uintptr_t sa = (uintptr_t)(src + xa);
+    const uint32_t *sw = reinterpret_cast<const uint32_t *>(sa & ~(uintptr_t)3);
+    const uint32_t shift = (uint32_t)(sa & 3);
+    const uint32_t *last = reinterpret_cast<const uint32_t *>(((uintptr_t)(msa + m * n) - 1) & ~(uintptr_t)3);   // last readable word
+    uint32_t *dw = reinterpret_cast<uint32_t *>(dst + xa);
+    for (uint64_t j = threadIdx.x; j < nwords; j += TB_THREADS) {
+        const uint32_t lo = sw[j];
+        const uint32_t hi = (shift && sw + j + 1 <= last) ? sw[j + 1] : 0u;
+        dw[j] = __builtin_amdgcn_alignbyte(hi, lo, shift);
     }
 }
 
@@ -270,8 +328,8 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
         hipLaunchKernelGGL((k_write_text<false, true>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
                            pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr);
     } else {
-        hipLaunchKernelGGL((k_write_text<false, false>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
-                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + CR_SEG - 1) / CR_SEG), (unsigned)m), dim3(TB_THREADS), 0, st,
+                           ctx->d_msa, n, m, T);
     }
     launches++;
     if (!ctx->gapfree) {   // the sentinel has no column: same marker as '#'
