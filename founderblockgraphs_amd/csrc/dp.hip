@@ -718,7 +718,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                 uint8_t *Wt = ctx->tmp.as<uint8_t>();
                 const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
                 const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
-                const uint32_t Fg = 4;                                   // blocks per group of the chain
+                const uint32_t Fg = 16;                                  // blocks per group of the chain (a chain step costs ~0.5 us)
                 const uint32_t ngroups = (nblocks + Fg - 1) / Fg;
                 uint8_t *Sg = reinterpret_cast<uint8_t *>(cur);          // (n+2)*4 bytes >= ngroups * WN: free on this path
 #define FBG_DP_PIPE(RR)                                                                                                   \

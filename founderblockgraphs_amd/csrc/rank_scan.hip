@@ -59,7 +59,6 @@ struct RankArgs {
     uint64_t own_lo, own_hi;   // slots this launch owns; the rest are halo copies of the neighbouring partitions
     int first_part, last_part; // partition holds the globally first / last suffix (no neighbour beyond)
     int part_mode;             // >1 partitions: slots next to a partition edge are re-examined once the halos are in
-    int dbg;                   // timing experiments only (FBG_RS_DBG)
     int values_only;           // second pass for columns the threshold starved: no lists, no threshold
     uint32_t row_len;          // n + 1
     uint32_t g_min;            // extensions below this cannot be a column maximum (sampled; verified afterwards)
@@ -352,7 +351,6 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
         uint32_t lcp[RS_ITEMS + 1];                                    // key LCP of slots my_i + r - 1 and my_i + r (K for equal keys)
 #pragma unroll
         for (int r = 0; r <= RS_ITEMS; r++) lcp[r] = rs_key_lcp(kk[r + 2], kk[r + 3], a.b, a.key_bits);
-        if (!(a.dbg & 4))
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) {
             // slot i with keys K[-3..3] = kk[r .. r+6] and columns C[-2..2] = cc[r .. r+4]
@@ -414,10 +412,10 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
         // looked at after the queue has been worked off
         uint32_t cur[RS_ITEMS];
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++) cur[r] = (upd_g[r] && !(a.dbg & 2)) ? a.gmax[upd_c[r]] : 0xffffffffu;
+        for (int r = 0; r < RS_ITEMS; r++) cur[r] = upd_g[r] ? a.gmax[upd_c[r]] : 0xffffffffu;
         __syncthreads();
         {
-            const uint32_t qn = (a.dbg & 1) ? 0u : sqn;
+            const uint32_t qn = sqn;
             for (uint32_t q0 = 0; q0 < qn; q0 += RS_THREADS) {
                 if (q0 + (threadIdx.x & ~63u) >= qn) break;            // wave-uniform
                 const uint32_t q = q0 + threadIdx.x;
@@ -764,7 +762,6 @@ static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *va
     a.big = ctx->big_groups.as<uint32_t>();
     a.counters = ctx->scalars.as<unsigned long long>() + 32;
     a.g_min = 0;
-    a.dbg = getenv("FBG_RS_DBG") ? atoi(getenv("FBG_RS_DBG")) : 0;
 }
 
 static void rs_remember(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g)
