@@ -2,19 +2,22 @@
 """bench.py -- MSA columns segmented per second on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one synthetic MSA already resident in HBM:
-    index build (text, suffix sort, neighbour LCPs, column tiles)  -> load_cst        fbg.cpp:361-436
-    per-column extension scan                                       -> compute_f       fbg.cpp:1579-1695
-    [N>1: one RCCL all-gather of the f slices]
-    bucket pass + min-max-length sweep + backtrack (rank 0)         -> fbg.cpp:1940-2039
+    index build: text, key sort, extension scan in rank order      -> load_cst + compute_f   fbg.cpp:361-436, 1579-1695
+    f[] from the per-column maxima                                  -> fbg.cpp:1656-1681
+    [N>1: an all-gather of 1.5 KB per rank and one all-reduce(max) of n+1 words, see below]
+    min-max-length sweep + backtrack (rank 0)                       -> fbg.cpp:1940-2039
 Workload at N=1: BASELINE config C3, synthetic 1000 rows x 1,000,000 columns, iid ACGT
 (SURVEY.md 8d generator), --elastic.  N>1: weak scaling, 1,000,000 columns per GPU.  While the text
-fits 32-bit ranks (N<=4) every rank builds the (replicated) index and scans its own column range
-(SURVEY.md 8e); beyond that (N=8, text 8e9) the exact row-group-pair plan of
-founderblockgraphs_amd/distributed.py is used (one all-reduce(max) instead of the all-gather).
+fits 32-bit positions (N<=4) every rank holds the whole text but sorts and scans only its own key
+range of the suffixes (key-range partitioned index, founderblockgraphs_amd/distributed.py); if a rank
+finds its input unsuitable all ranks fall back to the replicated index with column shards
+(--replicated-index forces it).  Beyond that (N=8, text 8e9) the exact row-group-pair
+plan is used (one all-reduce(max) of f).
 
-Prints ONE JSON line on rank 0.  `roofline` prices the scan kernel (k_scan_stream): algorithmic
-bytes = (13*m + 8) per column over its HIP-event duration.  `cpu_baseline` times
-the CPU restatement (oracle/, kind "port") on a bounded column prefix of the same MSA.
+Prints ONE JSON line on rank 0.  `roofline` prices the extension-scan kernel (k_rank_scan; k_scan_stream
+when the MSA has gaps): algorithmic bytes = (13*m + 8) per column over its HIP-event
+duration.  `cpu_baseline` times the CPU restatement (oracle/, kind "port") on a bounded column prefix
+of the same MSA.
 """
 import argparse
 import json
@@ -71,9 +74,9 @@ def cpu_baseline(m, n_total, sample_cols):
 
 
 def measured_traffic(m, n, kernel):
-    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected and
-    corrected as MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled);
-    None when no pass exists for this workload / kernel."""
+    """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected as
+    MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units; the gfx950 FETCH_SIZE doubling applies to
+    16-B-per-lane streams only, see the note in the JSON); None when no pass exists for this workload / kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_kernels.json")) as fh:
             d = json.load(fh)
@@ -223,7 +226,7 @@ def main():
                          "traffic": measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
                          if world == 1 else None,
                          "traffic_source": "profiles/r01_pmc_scan_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                           "passes; the x2 FETCH_SIZE correction is calibrated for 16-B loads only: upper bound here)",
+                                           "passes; 8-B-per-lane loads: raw FETCH_SIZE, which equals one read of every slot)",
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "device_bytes": eng.device_bytes(),

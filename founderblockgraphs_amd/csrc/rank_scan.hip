@@ -450,28 +450,38 @@ template <bool PK> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs 
     if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
     for (uint32_t e = threadIdx.x; e < have; e += blockDim.x) {
         const uint64_t h = a.ties[(size_t)blockIdx.x * a.tie_region + e];
-        const uint64_t key = rs_key<PK>(a, h);
-        int s = 1;
-        while (s < RS_TG && h + s < a.own_hi && rs_key<PK>(a, h + s) == key) s++;
+        // the RS_TG slots from the head on, all loads at once; the group ends where the key changes
+        uint64_t key[RS_TG];
         uint32_t pos[RS_TG], best[RS_TG];
 #pragma unroll
-        for (int i = 0; i < RS_TG; i++) { best[i] = 0; pos[i] = i < s ? rs_pos<PK>(a, h + i) : 0u; }
+        for (int i = 0; i < RS_TG; i++) {
+            const bool ok = h + i < a.own_hi;
+            const uint64_t w = ok ? a.keys[h + i] : 0ull;
+            key[i] = PK ? w >> a.pb : w;
+            pos[i] = PK ? (uint32_t)(w & a.pmask) : (ok ? a.vals[h + i] : 0u);
+            if (!ok) key[i] = ~key[0];
+            best[i] = 0;
+        }
+        int s = 1;
+#pragma unroll
+        for (int i = 1; i < RS_TG; i++)
+            if (s == i && key[i] == key[0]) s = i + 1;
+        // most groups are pairs whose texts part within 8 bytes: that comparison first, the rest by the general code
+        const uint64_t x01 = fbg_load8(a.T, (uint64_t)pos[0] + a.K) ^ fbg_load8(a.T, (uint64_t)pos[1] + a.K);
 #pragma unroll
         for (int i = 0; i < RS_TG; i++)
 #pragma unroll
             for (int j = i + 1; j < RS_TG; j++)
                 if (j < s) {
-                    const uint32_t x = fbg_extend_match(a.T, (uint64_t)pos[i] + a.K, (uint64_t)pos[j] + a.K, 0);
+                    uint32_t x;
+                    if (i == 0 && j == 1 && x01 != 0) x = (uint32_t)(__ffsll((unsigned long long)x01) - 1) / 8;
+                    else x = fbg_extend_match(a.T, (uint64_t)pos[i] + a.K, (uint64_t)pos[j] + a.K, 0);
                     best[i] = max(best[i], x);
                     best[j] = max(best[j], x);
                 }
 #pragma unroll
         for (int i = 0; i < RS_TG; i++)
-            if (i < s) {
-                uint32_t col, rem;
-                rs_colrem(a, pos[i], col, rem);
-                rs_update(a, col, fbg_clamp_lcp(best[i] + (uint32_t)a.K) + 1);
-            }
+            if (i < s) rs_update(a, rs_col_of_rem(a, rs_rem(a, pos[i])), fbg_clamp_lcp(best[i] + (uint32_t)a.K) + 1);
     }
 }
 
