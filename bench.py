@@ -131,53 +131,74 @@ def main():
     d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     state = {}
-    replicated = m * (n + 1) + 1 < (1 << 32) - 1 and not args.force_row_pairs
-    if replicated:
-        # column shards of one (replicated) index: SURVEY.md 8e, compute_f_range's partition
-        x0, x1 = D.shard_range(n, rank, world)
-        d_msa = torch.empty(m * n, dtype=torch.uint8, device="cuda")
-        eng.msa_synthetic(d_msa.data_ptr(), m, n, SEED)
-        scan_cols, scan_rows, mode = x1 - x0, m, "column shards, replicated index"
+    fits32 = m * (n + 1) + 1 < (1 << 32) - 1
+    want_partition = world > 1 and not args.replicated_index and not args.force_row_pairs
+    x0, x1 = D.shard_range(n, rank, world)
+    bufs = {}
 
-        def step():
-            eng.msa_set_device(d_msa.data_ptr(), m, n)
-            if world > 1 and not args.replicated_index and D.partitioned_index(eng, n, rank, world):
-                # each rank sorted and scanned one key range of the suffixes; the column maxima are global now
-                state["mode"] = "key-range partitioned index, all-reduce(max) of the column maxima"
-                if rank == 0:
-                    d_f.zero_()
-                    eng.scan_f(0, n, d_f.data_ptr())
-                    state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
-                return
+    def whole_msa():
+        if "whole" not in bufs:
+            bufs["whole"] = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+            eng.msa_synthetic(bufs["whole"].data_ptr(), m, n, SEED)
+        return bufs["whole"]
+
+    def step_partitioned():
+        """Each rank sorts and scans one key range of the suffixes (any text length); False = declined by some rank."""
+        d_msa = whole_msa()
+        eng.msa_set_device(d_msa.data_ptr(), m, n)
+        if not D.partitioned_index(eng, n, rank, world):
+            return False
+        if rank == 0:
+            d_f.zero_()
+            eng.scan_f(0, n, d_f.data_ptr())
+            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        return True
+
+    def step_replicated():
+        """Column shards of one (replicated) index: SURVEY.md 8e, compute_f_range's partition."""
+        d_msa = whole_msa()
+        eng.msa_set_device(d_msa.data_ptr(), m, n)
+        eng.index_build()
+        d_f.zero_()
+        eng.scan_f(x0, x1, d_f.data_ptr())
+        f_full = D.all_gather_columns(d_f[x0:x1], n, rank, world)   # the one exchange of the path
+        if rank == 0:
+            state["blocks"] = eng.minmax_dp_device(f_full.data_ptr(), n, d_b.data_ptr())
+
+    def step_row_pairs():
+        """Text too long for 32-bit positions on one GPU: exact row-group-pair plan, one all-reduce(max) of f."""
+        if "plan" not in bufs:
+            bufs.pop("whole", None)
+            G, groups, plan = (D.plan_row_pairs(m, n, world, limit=args.force_row_pairs * (n + 1) + 1)
+                               if args.force_row_pairs else D.plan_row_pairs(m, n, world))
+            rows_pair = max((groups[a][1] - groups[a][0]) + (groups[b][1] - groups[b][0]) for a, b in D.group_pairs(G))
+            bufs["plan"] = (G, groups, plan[rank], rows_pair, torch.empty(rows_pair * n, dtype=torch.uint8, device="cuda"))
+        G, groups, mine, rows_pair, d_msa = bufs["plan"]
+        d_f.zero_()
+        for a, b in mine:
+            off = 0
+            for g in (a, b):
+                r0, r1 = groups[g]
+                eng.msa_synthetic(d_msa.data_ptr() + off * n, r1 - r0, n, SEED + r0 * n)
+                off += r1 - r0
+            eng.msa_set_device(d_msa.data_ptr(), off, n)
             eng.index_build()
-            d_f.zero_()
-            eng.scan_f(x0, x1, d_f.data_ptr())
-            f_full = D.all_gather_columns(d_f[x0:x1], n, rank, world)   # the one exchange of the path
-            if rank == 0:
-                state["blocks"] = eng.minmax_dp_device(f_full.data_ptr(), n, d_b.data_ptr())
-    else:
-        # text too long for 32-bit ranks: exact row-group-pair plan, one all-reduce(max) of f
-        G, groups, plan = (D.plan_row_pairs(m, n, world, limit=args.force_row_pairs * (n + 1) + 1)
-                           if args.force_row_pairs else D.plan_row_pairs(m, n, world))
-        mine = plan[rank]
-        rows_pair = max((groups[a][1] - groups[a][0]) + (groups[b][1] - groups[b][0]) for a, b in D.group_pairs(G))
-        d_msa = torch.empty(rows_pair * n, dtype=torch.uint8, device="cuda")
-        scan_cols, scan_rows, mode = n, rows_pair, f"row-group pairs (G={G}, {len(D.group_pairs(G))} pairs), all-reduce(max)"
+            eng.scan_f(0, n, d_f.data_ptr())
+        D.all_reduce_max(d_f)
+        if rank == 0:
+            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
 
-        def step():
-            d_f.zero_()
-            for a, b in mine:
-                off = 0
-                for g in (a, b):
-                    r0, r1 = groups[g]
-                    eng.msa_synthetic(d_msa.data_ptr() + off * n, r1 - r0, n, SEED + r0 * n)
-                    off += r1 - r0
-                eng.msa_set_device(d_msa.data_ptr(), off, n)
-                eng.index_build()
-                eng.scan_f(0, n, d_f.data_ptr())
-            D.all_reduce_max(d_f)
-            if rank == 0:
-                state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+    state["path"] = "partitioned" if want_partition else ("replicated" if fits32 and not args.force_row_pairs else "row_pairs")
+
+    def step():
+        if state["path"] == "partitioned":
+            if step_partitioned():
+                return
+            state["path"] = "replicated" if fits32 else "row_pairs"     # every rank sees the same verdict
+        if state["path"] == "replicated":
+            step_replicated()
+        else:
+            step_row_pairs()
 
     def fence():
         torch.cuda.synchronize()
@@ -210,7 +231,14 @@ def main():
         # k_scan_stream (text order) otherwise; one launch per step either way
         ranked = stage_acc.get("rank_kernel", [0.0, 0])[1] > 0
         scan_ms = (stage_acc["rank_kernel"][0] if ranked else stage_acc["scan"][0]) / max(1, args.steps)
-        mode_used = state.get("mode", mode)
+        if state["path"] == "partitioned":
+            scan_cols, scan_rows, mode_used = x1 - x0, m, "key-range partitioned index, all-reduce(max) of the column maxima"
+        elif state["path"] == "replicated":
+            scan_cols, scan_rows, mode_used = x1 - x0, m, "column shards, replicated index"
+        else:
+            G, _, _, rows_pair, _ = bufs["plan"]
+            scan_cols, scan_rows = n, rows_pair
+            mode_used = f"row-group pairs (G={G}, {len(D.group_pairs(G))} pairs), all-reduce(max)"
         scan_bytes = (13 * scan_rows + 8) * scan_cols
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {

@@ -178,9 +178,10 @@ static int check_dims(fbg_ctx *ctx, uint64_t m, uint64_t n)
                                           (unsigned long long)m, (unsigned long long)n);
     if (m > FBG_MAX_ROWS)
         return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "m=%llu exceeds FBG_MAX_ROWS=%d", (unsigned long long)m, FBG_MAX_ROWS);
-    if (n >= (1ull << 32) || m * (n + 1) + 1 >= (1ull << 32))
-        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length m*(n+1)+1 = %llu needs more than 32-bit ranks",
-                        (unsigned long long)(m * (n + 1) + 1));
+    // whether a text beyond 32-bit positions can be indexed depends on the path taken: fbg_build_text decides
+    if (n >= (1ull << 31) || m * (n + 1) + 1 >= (1ull << 40))
+        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "MSA of %llu x %llu cells is beyond this engine (n < 2^31, text < 2^40)",
+                        (unsigned long long)m, (unsigned long long)n);
     return FBG_OK;
 }
 
@@ -229,7 +230,10 @@ int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void 
     ctx->index_valid = false;
     ctx->ranked = false;
     ctx->reversed = reversed ? 1 : 0;
-    FBG_TRY(fbg_build_text(ctx, nullptr, 0));
+    ctx->allow_wide = true;                        // the partitions together may hold a text of 2^32 symbols and more
+    const int rc = fbg_build_text(ctx, nullptr, 0);
+    ctx->allow_wide = false;
+    FBG_TRY(rc);
     return fbg_part_sort(ctx, part, nparts, static_cast<uint8_t *>(d_blob), ok);
 }
 
@@ -391,6 +395,7 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     if (!ctx) return FBG_ERR_INVALID;
     if (!ctx->index_valid) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: no index");
     if (ctx->part_active) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: the index is partitioned over several GPUs");
+    if (ctx->N >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_index_download: 32-bit arrays");
     size_t N = ctx->N;
     // test / debugging API: plain blocking copies
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -40,8 +40,8 @@ struct fbg_ctx {
     bool gapfree = true;
     bool have_ignore = false;
     uint64_t N = 0;            // text length incl. sentinel
-    unsigned byte_hist[256] = {0}; // symbol histogram of the current text (fbg_key_setup)
-    bool byte_hist_valid = false;
+    uint64_t byte_hist[256] = {0}; // symbol histogram of the current text (fbg_build_text; read by fbg_key_setup)
+    bool allow_wide = false;       // the caller can work with text positions beyond 32 bits (partitioned index only)
     uint32_t mp = 0;           // rows padded to a multiple of 64 (column-tile pitch)
     DevBuf text;               // N + 64 bytes, zero padded
     DevBuf pos, tot;           // u32[m]
@@ -60,7 +60,7 @@ struct fbg_ctx {
     uint32_t n_exc = 0;
     uint64_t *rk_keys = nullptr; // sorted slots: keys (pairs layout, positions in sa_ptr) or key << rk_pb | position (packed)
     int rk_b = 0, rk_key_bits = 0, rk_K = 0;
-    int rk_packed = 0, rk_pb = 0;
+    int rk_layout = 0, rk_pb = 0;   // FBG_SLOTS_*
     // partitioned index (partition.hip): this GPU holds the SA slots of key range `part` of `nparts`
     bool part_active = false;
     int part = 0, nparts = 1;
@@ -96,12 +96,16 @@ void fbg_release(fbg_ctx *ctx, DevBuf &b);
 int fbg_stage_begin(fbg_ctx *ctx, int stage);
 int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);
 
+#define FBG_SLOTS_PAIRS 0    // keys[k] = key, vals[k] = position (32 bits)
+#define FBG_SLOTS_PACKED 1   // keys[k] = key << pb | position
+#define FBG_SLOTS_WIDE 2     // keys[k] = key << pb | position >> 32, vals[k] = low 32 bits of the position
 // Key geometry of the round-0 sort.  compact: separators ('#', sentinel) share code 0 with the smallest symbol and
 // blank the rest of the key (rank_scan.hip undoes the ambiguity with the row arithmetic of gap-free MSAs);
 // packed: one 64-bit word per suffix, key << pb | position, sorted by its key bits only.
 struct KeyGeom {
     int b = 0, K = 0, key_bits = 0;
     bool compact = false, packed = false;
+    bool wide = false;            // (key word, low position word) pairs, key << pb | position >> 32: texts of 2^32 symbols and more
     int pb = 0;
     const uint8_t *d_code = nullptr;
 };

@@ -49,9 +49,10 @@ __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, in
 
 struct RankArgs {
     uint32_t magic32;          // floor(2^32 / row_len): umulhi(p, magic32) is p / row_len or one less
+    uint64_t magic64;          // floor(2^64 / row_len) + 1: umul64hi(p, magic64) is p / row_len (wide positions)
     uint64_t *keys;            // sorted slots: keys, or packed words key << pb | position
     uint32_t *vals;            // positions in SA order (pairs layout; final once the tie groups are ordered)
-    uint64_t pmask;            // packed: (1 << pb) - 1
+    uint64_t pmask;            // packed / wide: (1 << pb) - 1, the position bits of the key word
     int pb;
     const uint8_t *T;
     uint64_t N, n;             // N: number of SA slots in keys[] / vals[]
@@ -77,56 +78,61 @@ struct RankArgs {
 
 struct Slot {
     uint64_t key;
-    uint32_t pos;
+    uint64_t pos;
     uint32_t col;              // MSA column of the position, n for '#' / sentinel (never a row pointer without gaps)
     uint32_t rem;              // symbols left in the row from this position on (0 for '#' / sentinel)
 };
 
-// symbols left in the row of text position p (0 for '#' / sentinel); p < 2^32
-__device__ __forceinline__ uint32_t rs_rem(const RankArgs &a, uint32_t p)
-{
-    uint32_t c = p - __umulhi(p, a.magic32) * a.row_len;               // p mod (n+1), possibly one row_len too much
-    if (c >= a.row_len) c -= a.row_len;
-    return p == (uint32_t)(a.Ntext - 1) ? 0u : (uint32_t)a.n - c;
-}
 // MSA column of a row pointer with `rem` symbols left; n for '#' / sentinel (never a row pointer without gaps)
 __device__ __forceinline__ uint32_t rs_col_of_rem(const RankArgs &a, uint32_t rem)
 {
     return rem == 0 ? (uint32_t)a.n : (a.reversed ? rem - 1 : (uint32_t)a.n - rem);
 }
-__device__ __forceinline__ void rs_colrem(const RankArgs &a, uint32_t p, uint32_t &col, uint32_t &rem)
+// slot layouts (FBG_SLOTS_*): the key is always word >> pb (pb = 0 for plain pairs)
+template <int L> struct PosT { typedef uint32_t type; };
+template <> struct PosT<FBG_SLOTS_WIDE> { typedef uint64_t type; };
+template <int L> __device__ __forceinline__ uint64_t rs_key(const RankArgs &a, uint64_t k) { return a.keys[k] >> a.pb; }
+template <int L> __device__ __forceinline__ uint64_t rs_pos_of(const RankArgs &a, uint64_t w, uint32_t v)
 {
-    rem = rs_rem(a, p);
-    col = rs_col_of_rem(a, rem);
+    if (L == FBG_SLOTS_PACKED) return w & a.pmask;
+    if (L == FBG_SLOTS_WIDE) return ((w & a.pmask) << 32) | v;
+    return v;
 }
-
-template <bool PK> __device__ __forceinline__ uint64_t rs_key(const RankArgs &a, uint64_t k)
+template <int L> __device__ __forceinline__ uint64_t rs_pos(const RankArgs &a, uint64_t k)
 {
-    return PK ? a.keys[k] >> a.pb : a.keys[k];
+    return rs_pos_of<L>(a, L == FBG_SLOTS_PAIRS ? 0ull : a.keys[k], L == FBG_SLOTS_PACKED ? 0u : a.vals[k]);
 }
-template <bool PK> __device__ __forceinline__ uint32_t rs_pos(const RankArgs &a, uint64_t k)
+template <int L> __device__ __forceinline__ void rs_set_pos(const RankArgs &a, uint64_t k, uint64_t p)
 {
-    return PK ? (uint32_t)(a.keys[k] & a.pmask) : a.vals[k];
+    if (L == FBG_SLOTS_PACKED) a.keys[k] = (a.keys[k] & ~a.pmask) | p;
+    else if (L == FBG_SLOTS_WIDE) { a.keys[k] = (a.keys[k] & ~a.pmask) | (p >> 32); a.vals[k] = (uint32_t)p; }
+    else a.vals[k] = (uint32_t)p;
 }
-template <bool PK> __device__ __forceinline__ void rs_set_pos(const RankArgs &a, uint64_t k, uint32_t p)
+// symbols left in the row of text position p (0 for '#' / sentinel)
+template <int L> __device__ __forceinline__ uint32_t rs_rem(const RankArgs &a, uint64_t p)
 {
-    if (PK) a.keys[k] = (a.keys[k] & ~a.pmask) | p;
-    else a.vals[k] = p;
+    if (L == FBG_SLOTS_WIDE) {
+        const uint64_t c = p - __umul64hi(p, a.magic64) * a.row_len;   // exact while p * row_len < 2^64
+        return p == a.Ntext - 1 ? 0u : (uint32_t)(a.n - c);
+    }
+    const uint32_t p32 = (uint32_t)p;
+    uint32_t c = p32 - __umulhi(p32, a.magic32) * a.row_len;           // p mod (n+1), possibly one row_len too much
+    if (c >= a.row_len) c -= a.row_len;
+    return p32 == (uint32_t)(a.Ntext - 1) ? 0u : (uint32_t)a.n - c;
 }
-template <bool PK> __device__ __forceinline__ Slot rs_slot(const RankArgs &a, uint64_t k)
+template <int L> __device__ __forceinline__ Slot rs_slot(const RankArgs &a, uint64_t k)
 {
     Slot s;
     const uint64_t w = a.keys[k];
-    s.key = PK ? w >> a.pb : w;
-    s.pos = PK ? (uint32_t)(w & a.pmask) : a.vals[k];
-    rs_colrem(a, s.pos, s.col, s.rem);
+    s.key = w >> a.pb;
+    s.pos = rs_pos_of<L>(a, w, L == FBG_SLOTS_PACKED ? 0u : a.vals[k]);
+    s.rem = rs_rem<L>(a, s.pos);
+    s.col = rs_col_of_rem(a, s.rem);
     return s;
 }
-template <bool PK> __device__ __forceinline__ uint32_t rs_col(const RankArgs &a, uint64_t k)
+template <int L> __device__ __forceinline__ uint32_t rs_col(const RankArgs &a, uint64_t k)
 {
-    uint32_t col, rem;
-    rs_colrem(a, rs_pos<PK>(a, k), col, rem);
-    return col;
+    return rs_col_of_rem(a, rs_rem<L>(a, rs_pos<L>(a, k)));
 }
 
 __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint32_t g)
@@ -262,7 +268,7 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
 // finished on the spot from registers (its neighbours are the thread's own slots or the adjacent lanes'), the
 // others queue up; (3) the queue is worked off, out of LDS, by as many lanes as it has entries instead of a few
 // lanes in every wave.
-template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
+template <int L> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
 {
     __shared__ uint64_t skey[RS_CHUNK + 2 * RS_HALO];
     __shared__ uint32_t srem[RS_CHUNK + 2 * RS_HALO];   // symbols left in the row: names the column as well
@@ -285,13 +291,13 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
             w[r] = 0; v[r] = 0;
             if (my_i + r < hi_i) {
                 w[r] = a.keys[base + (uint64_t)(my_i + r - RS_HALO)];
-                if (!PK) v[r] = a.vals[base + (uint64_t)(my_i + r - RS_HALO)];
+                if (L != FBG_SLOTS_PACKED) v[r] = a.vals[base + (uint64_t)(my_i + r - RS_HALO)];
             }
         }
         w[RS_ITEMS] = 0; v[RS_ITEMS] = 0;
         if (threadIdx.x < 2 * RS_HALO && halo_i >= lo_i && halo_i < hi_i) {
             w[RS_ITEMS] = a.keys[base + halo_i - RS_HALO];
-            if (!PK) v[RS_ITEMS] = a.vals[base + halo_i - RS_HALO];
+            if (L != FBG_SLOTS_PACKED) v[RS_ITEMS] = a.vals[base + halo_i - RS_HALO];
         }
     };
     if (blockIdx.x < nchunks) fetch(blockIdx.x);
@@ -307,8 +313,8 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
             uint64_t key = 0;
             uint32_t rem = 0;
             if (my_i + r < hi_i) {
-                key = PK ? w[r] >> a.pb : w[r];
-                rem = rs_rem(a, PK ? (uint32_t)(w[r] & a.pmask) : v[r]);
+                key = w[r] >> a.pb;
+                rem = rs_rem<L>(a, rs_pos_of<L>(a, w[r], v[r]));
             }
             kk[r + 3] = key; cc[r + 2] = rem;
             skey[my_i + r] = key; srem[my_i + r] = rem;
@@ -317,8 +323,8 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
             uint64_t key = 0;
             uint32_t rem = 0;
             if (halo_i >= lo_i && halo_i < hi_i) {
-                key = PK ? w[RS_ITEMS] >> a.pb : w[RS_ITEMS];
-                rem = rs_rem(a, PK ? (uint32_t)(w[RS_ITEMS] & a.pmask) : v[RS_ITEMS]);
+                key = w[RS_ITEMS] >> a.pb;
+                rem = rs_rem<L>(a, rs_pos_of<L>(a, w[RS_ITEMS], v[RS_ITEMS]));
             }
             skey[halo_i] = key; srem[halo_i] = rem;
         }
@@ -444,21 +450,21 @@ template <bool PK> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(Ran
 // the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
 // shares a column with a neighbour, so each is a run of its own and its extension is 1 + its longest match with
 // any other suffix -- which is another member of the group (they agree on K symbols, nobody else does).
-template <bool PK> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a)
+template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a)
 {
     const uint32_t have = a.tie_count[blockIdx.x];
     if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
     for (uint32_t e = threadIdx.x; e < have; e += blockDim.x) {
         const uint64_t h = a.ties[(size_t)blockIdx.x * a.tie_region + e];
         // the RS_TG slots from the head on, all loads at once; the group ends where the key changes
-        uint64_t key[RS_TG];
-        uint32_t pos[RS_TG], best[RS_TG];
+        uint64_t key[RS_TG], pos[RS_TG];
+        uint32_t best[RS_TG];
 #pragma unroll
         for (int i = 0; i < RS_TG; i++) {
             const bool ok = h + i < a.own_hi;
             const uint64_t w = ok ? a.keys[h + i] : 0ull;
-            key[i] = PK ? w >> a.pb : w;
-            pos[i] = PK ? (uint32_t)(w & a.pmask) : (ok ? a.vals[h + i] : 0u);
+            key[i] = w >> a.pb;
+            pos[i] = rs_pos_of<L>(a, w, (ok && L != FBG_SLOTS_PACKED) ? a.vals[h + i] : 0u);
             if (!ok) key[i] = ~key[0];
             best[i] = 0;
         }
@@ -467,7 +473,7 @@ template <bool PK> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs 
         for (int i = 1; i < RS_TG; i++)
             if (s == i && key[i] == key[0]) s = i + 1;
         // most groups are pairs whose texts part within 8 bytes: that comparison first, the rest by the general code
-        const uint64_t x01 = fbg_load8(a.T, (uint64_t)pos[0] + a.K) ^ fbg_load8(a.T, (uint64_t)pos[1] + a.K);
+        const uint64_t x01 = fbg_load8(a.T, pos[0] + a.K) ^ fbg_load8(a.T, pos[1] + a.K);
 #pragma unroll
         for (int i = 0; i < RS_TG; i++)
 #pragma unroll
@@ -475,13 +481,13 @@ template <bool PK> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs 
                 if (j < s) {
                     uint32_t x;
                     if (i == 0 && j == 1 && x01 != 0) x = (uint32_t)(__ffsll((unsigned long long)x01) - 1) / 8;
-                    else x = fbg_extend_match(a.T, (uint64_t)pos[i] + a.K, (uint64_t)pos[j] + a.K, 0);
+                    else x = fbg_extend_match(a.T, pos[i] + a.K, pos[j] + a.K, 0);
                     best[i] = max(best[i], x);
                     best[j] = max(best[j], x);
                 }
 #pragma unroll
         for (int i = 0; i < RS_TG; i++)
-            if (i < s) rs_update(a, rs_col_of_rem(a, rs_rem(a, pos[i])), fbg_clamp_lcp(best[i] + (uint32_t)a.K) + 1);
+            if (i < s) rs_update(a, rs_col_of_rem(a, rs_rem<L>(a, pos[i])), fbg_clamp_lcp(best[i] + (uint32_t)a.K) + 1);
     }
 }
 
@@ -538,16 +544,16 @@ __global__ void k_cand_compact(const uint32_t *__restrict__ regions, const uint3
 // Groups of more than 64 go to k_tie_big.
 #define RS_BIG_GROUPS 1024
 #define RS_BIG_MEMBERS 8192
-template <bool PK> __global__ void k_tie_groups(RankArgs a, uint64_t T, int by_list)
+template <int L> __global__ void k_tie_groups(RankArgs a, uint64_t T, int by_list)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const uint64_t k0 = by_list ? (uint64_t)a.cand[t] : a.own_lo + t;
-    const uint64_t key = rs_key<PK>(a, k0);
-    if (k0 > a.own_lo && rs_key<PK>(a, k0 - 1) == key) return;                      // inside a group
-    if (k0 + 1 >= a.own_hi || rs_key<PK>(a, k0 + 1) != key) return;                 // not a tie (ties never cross partitions)
+    const uint64_t key = rs_key<L>(a, k0);
+    if (k0 > a.own_lo && rs_key<L>(a, k0 - 1) == key) return;                      // inside a group
+    if (k0 + 1 >= a.own_hi || rs_key<L>(a, k0 + 1) != key) return;                 // not a tie (ties never cross partitions)
     uint32_t s = 1;
-    while (k0 + s < a.own_hi && s <= RS_BIG_MEMBERS && rs_key<PK>(a, k0 + s) == key) s++;
+    while (k0 + s < a.own_hi && s <= RS_BIG_MEMBERS && rs_key<L>(a, k0 + s) == key) s++;
     if (s > 64) {
         if (s > RS_BIG_MEMBERS) { a.counters[1] = 1; return; }
         const unsigned long long e = atomicAdd(&a.counters[5], 1ull);
@@ -558,19 +564,18 @@ template <bool PK> __global__ void k_tie_groups(RankArgs a, uint64_t T, int by_l
     }
     // order the s suffixes by their text (insertion sort, s is tiny).  The first K symbols agree -- unless a member
     // has fewer than K symbols left in its row: then the keys agree only up to the separator coding
-    uint32_t pos[64];
+    typedef typename PosT<L>::type pos_t;
+    pos_t pos[64];
     uint32_t from = (uint32_t)a.K;
     for (uint32_t i = 0; i < s; i++) {
-        pos[i] = rs_pos<PK>(a, k0 + i);
-        uint32_t col, rem;
-        rs_colrem(a, pos[i], col, rem);
-        if (rem < (uint32_t)a.K) from = 0;
+        pos[i] = (pos_t)rs_pos<L>(a, k0 + i);
+        if (rs_rem<L>(a, pos[i]) < (uint32_t)a.K) from = 0;
     }
     for (uint32_t i = 1; i < s; i++) {
-        const uint32_t cur = pos[i];
+        const pos_t cur = pos[i];
         uint32_t j = i;
         while (j > 0) {
-            const uint32_t o = pos[j - 1];
+            const pos_t o = pos[j - 1];
             const uint32_t h = fbg_extend_match(a.T, (uint64_t)o + from, (uint64_t)cur + from, 0);
             if (a.T[(uint64_t)o + from + h] < a.T[(uint64_t)cur + from + h]) break;      // o < cur: in place
             pos[j] = o;
@@ -578,7 +583,7 @@ template <bool PK> __global__ void k_tie_groups(RankArgs a, uint64_t T, int by_l
         }
         pos[j] = cur;
     }
-    for (uint32_t i = 0; i < s; i++) rs_set_pos<PK>(a, k0 + i, pos[i]);
+    for (uint32_t i = 0; i < s; i++) rs_set_pos<L>(a, k0 + i, pos[i]);
 }
 
 // Long tie groups exist where many rows end alike: the members of a group share their real symbols and differ in
@@ -588,23 +593,26 @@ template <bool PK> __global__ void k_tie_groups(RankArgs a, uint64_t T, int by_l
 // two ends, fbg.cpp:1644-1656) -- left as it is unless `exact` (fbg_index_download wants the true suffix array).
 // The members with K real symbols are ordered by their text; more than 64 of those -> fallback flag.
 // One workgroup per group.
-template <bool PK> __global__ __launch_bounds__(256) void k_tie_big(RankArgs a, int exact)
+template <int L> __global__ __launch_bounds__(256) void k_tie_big(RankArgs a, int exact)
 {
-    __shared__ uint32_t pos[RS_BIG_MEMBERS];
+    __shared__ uint32_t pos_lo[RS_BIG_MEMBERS];
+    __shared__ uint8_t pos_hi[L == FBG_SLOTS_WIDE ? RS_BIG_MEMBERS : 1];     // positions beyond 32 bits: their top byte
     __shared__ uint8_t cls[RS_BIG_MEMBERS];
     __shared__ uint32_t offs[66];
     __shared__ uint32_t q_start, q_count;
     if (blockIdx.x >= a.counters[5]) return;
     const uint64_t k0 = a.big[2 * blockIdx.x];
     const uint32_t s = a.big[2 * blockIdx.x + 1];
+    auto member = [&](uint32_t i) -> uint64_t {
+        return L == FBG_SLOTS_WIDE ? ((uint64_t)pos_hi[L == FBG_SLOTS_WIDE ? i : 0] << 32) | pos_lo[i] : (uint64_t)pos_lo[i];
+    };
     if (threadIdx.x < 66) offs[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
-        const uint32_t p = rs_pos<PK>(a, k0 + i);
-        uint32_t col, rem;
-        rs_colrem(a, p, col, rem);
-        const uint32_t c = min(rem, (uint32_t)a.K);
-        pos[i] = p;
+        const uint64_t p = rs_pos<L>(a, k0 + i);
+        const uint32_t c = min(rs_rem<L>(a, p), (uint32_t)a.K);
+        pos_lo[i] = (uint32_t)p;
+        if (L == FBG_SLOTS_WIDE) pos_hi[L == FBG_SLOTS_WIDE ? i : 0] = (uint8_t)(p >> 32);
         cls[i] = (uint8_t)c;
         atomicAdd(&offs[c + 1], 1u);
     }
@@ -618,7 +626,7 @@ template <bool PK> __global__ __launch_bounds__(256) void k_tie_big(RankArgs a, 
     if (!exact) {
         for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
             const uint32_t dst = atomicAdd(&offs[cls[i]], 1u);
-            rs_set_pos<PK>(a, k0 + dst, pos[i]);
+            rs_set_pos<L>(a, k0 + dst, member(i));
         }
         __threadfence();
         __syncthreads();
@@ -627,86 +635,86 @@ template <bool PK> __global__ __launch_bounds__(256) void k_tie_big(RankArgs a, 
             if (q > 64) { a.counters[1] = 1; return; }
             const uint64_t kq = k0 + q_start;
             for (uint32_t i = 1; i < q; i++) {                          // insertion sort by the text beyond the key
-                const uint32_t cur = rs_pos<PK>(a, kq + i);
+                const uint64_t cur = rs_pos<L>(a, kq + i);
                 uint32_t j = i;
                 while (j > 0) {
-                    const uint32_t o = rs_pos<PK>(a, kq + j - 1);
-                    const uint32_t h = fbg_extend_match(a.T, (uint64_t)o + a.K, (uint64_t)cur + a.K, 0);
-                    if (a.T[(uint64_t)o + a.K + h] < a.T[(uint64_t)cur + a.K + h]) break;
-                    rs_set_pos<PK>(a, kq + j, o);
+                    const uint64_t o = rs_pos<L>(a, kq + j - 1);
+                    const uint32_t h = fbg_extend_match(a.T, o + a.K, cur + a.K, 0);
+                    if (a.T[o + a.K + h] < a.T[cur + a.K + h]) break;
+                    rs_set_pos<L>(a, kq + j, o);
                     j--;
                 }
-                rs_set_pos<PK>(a, kq + j, cur);
+                rs_set_pos<L>(a, kq + j, cur);
             }
         }
         return;
     }
     // exact: rank of every member among all members by text comparison (distinct suffixes: ranks are a permutation)
     for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
-        const uint32_t p = pos[i];
+        const uint64_t p = member(i);
         uint32_t rank = 0;
         for (uint32_t j = 0; j < s; j++) {
             if (j == i) continue;
-            const uint32_t o = pos[j];
-            const uint32_t h = fbg_extend_match(a.T, (uint64_t)o, (uint64_t)p, 0);
-            rank += a.T[(uint64_t)o + h] < a.T[(uint64_t)p + h] ? 1u : 0u;
+            const uint64_t o = member(j);
+            const uint32_t h = fbg_extend_match(a.T, o, p, 0);
+            rank += a.T[o + h] < a.T[p + h] ? 1u : 0u;
         }
-        rs_set_pos<PK>(a, k0 + rank, p);
+        rs_set_pos<L>(a, k0 + rank, p);
     }
 }
 
 // LCP of the suffixes in SA slots k-1 and k (final order, or a member of an unordered small tie group next to a
 // slot outside it: all its members have K symbols left, the result does not depend on which one it is)
-template <bool PK> __device__ __forceinline__ uint32_t rs_slot_lcp(const RankArgs &a, uint64_t k)
+template <int L> __device__ __forceinline__ uint32_t rs_slot_lcp(const RankArgs &a, uint64_t k)
 {
     if (k == (a.first_part ? a.own_lo : 0) || k >= (a.last_part ? a.own_hi : a.N)) return 0;   // no such neighbour
-    const Slot x = rs_slot<PK>(a, k - 1), y = rs_slot<PK>(a, k);
+    const Slot x = rs_slot<L>(a, k - 1), y = rs_slot<L>(a, k);
     if (x.key != y.key) return min(min(rs_key_lcp(x.key, y.key, a.b, a.key_bits), x.rem), y.rem);
     const uint32_t from = (x.rem < (uint32_t)a.K || y.rem < (uint32_t)a.K) ? 0u : (uint32_t)a.K;
     return fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)x.pos + from, (uint64_t)y.pos + from, 0) + from);
 }
 
 // test / debugging aid (fbg_index_download): suffix array, its inverse and the neighbour LCPs by text position
-template <bool PK> __global__ void k_rank_materialize(RankArgs a, uint32_t *sa, uint32_t *isa, uint32_t *pl, uint32_t *pr)
+template <int L> __global__ void k_rank_materialize(RankArgs a, uint32_t *sa, uint32_t *isa, uint32_t *pl, uint32_t *pr)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.N) return;
-    const uint32_t p = rs_pos<PK>(a, k);
+    const uint32_t p = (uint32_t)rs_pos<L>(a, k);                          // fbg_index_download: texts below 2^32 only
     sa[k] = p;
     isa[p] = (uint32_t)k;
-    pl[p] = rs_slot_lcp<PK>(a, k);
-    pr[p] = rs_slot_lcp<PK>(a, k + 1);
+    pl[p] = rs_slot_lcp<L>(a, k);
+    pr[p] = rs_slot_lcp<L>(a, k + 1);
 }
 
 // candidates (sorted, final SA order): one thread per run head walks its run of same-column slots.  With
 // partitions a run may begin or end in a halo (copies of the neighbouring partition's edge slots): it is walked
 // in full, but only owned members update the column maxima -- the neighbour does the same from its side.
-template <bool PK> __global__ void k_runs(RankArgs a, uint64_t T)
+template <int L> __global__ void k_runs(RankArgs a, uint64_t T)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const uint64_t k0 = a.cand[t];
-    const uint32_t col = rs_col<PK>(a, k0);
+    const uint32_t col = rs_col<L>(a, k0);
     if (col == a.n) return;                                            // '#' / sentinel: not a row pointer
-    if (k0 > a.own_lo && rs_col<PK>(a, k0 - 1) == col) return;         // an owned predecessor heads this run
+    if (k0 > a.own_lo && rs_col<L>(a, k0 - 1) == col) return;         // an owned predecessor heads this run
     const uint64_t lo_slot = a.first_part ? a.own_lo : 0, hi_slot = a.last_part ? a.own_hi : a.N;
     uint64_t ks = k0;                                                  // true head: possibly inside the previous halo
-    while (ks > lo_slot && rs_col<PK>(a, ks - 1) == col) ks--;
+    while (ks > lo_slot && rs_col<L>(a, ks - 1) == col) ks--;
     if (ks == 0 && !a.first_part) { a.counters[1] = 1; return; }       // run longer than the halo
     // forward: running minimum of LCP[lb..r]   (owned members of a run are contiguous in cand[])
-    uint32_t run = rs_slot_lcp<PK>(a, ks);
+    uint32_t run = rs_slot_lcp<L>(a, ks);
     uint64_t s = ks;
     for (;;) {
         if (s >= k0 && s < a.own_hi) a.pm[t + (s - k0)] = run;
-        if (s + 1 >= hi_slot || rs_col<PK>(a, s + 1) != col) break;
+        if (s + 1 >= hi_slot || rs_col<L>(a, s + 1) != col) break;
         s++;
-        run = min(run, rs_slot_lcp<PK>(a, s));
+        run = min(run, rs_slot_lcp<L>(a, s));
     }
     if (s + 1 == a.N && !a.last_part) { a.counters[1] = 1; return; }   // ran through the next halo
     // backward: running minimum of LCP[r+1..rb+1], extension, column maximum   (fbg.cpp:1656)
     uint32_t rmin = 0xffffffffu;
     for (;; s--) {
-        rmin = min(rmin, rs_slot_lcp<PK>(a, s + 1));
+        rmin = min(rmin, rs_slot_lcp<L>(a, s + 1));
         if (s >= k0 && s < a.own_hi) rs_update(a, col, max(a.pm[t + (s - k0)], rmin) + 1);
         if (s == ks || s <= k0) break;                                 // members before k0 belong to the neighbour
     }
@@ -751,20 +759,24 @@ template <class F> static int rs_with_tmp(fbg_ctx *ctx, F &&call)
 }
 
 // kernels exist for both slot layouts
-#define RS_LAUNCH(kernel, packed, grid, block, st, ...)                                        \
-    do {                                                                                       \
-        if (packed) hipLaunchKernelGGL((kernel<true>), grid, block, 0, st, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((kernel<false>), grid, block, 0, st, __VA_ARGS__);             \
+#define RS_LAUNCH(kernel, layout, grid, block, st, ...)                                                     \
+    do {                                                                                                    \
+        if ((layout) == FBG_SLOTS_PACKED) hipLaunchKernelGGL((kernel<FBG_SLOTS_PACKED>), grid, block, 0, st, __VA_ARGS__);  \
+        else if ((layout) == FBG_SLOTS_WIDE) hipLaunchKernelGGL((kernel<FBG_SLOTS_WIDE>), grid, block, 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<FBG_SLOTS_PAIRS>), grid, block, 0, st, __VA_ARGS__);                                \
     } while (0)
 
-static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *vals, uint64_t slots, int packed, int pb, int b,
+static int rs_layout(const KeyGeom &g) { return g.packed ? FBG_SLOTS_PACKED : g.wide ? FBG_SLOTS_WIDE : FBG_SLOTS_PAIRS; }
+
+static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *vals, uint64_t slots, int layout, int pb, int b,
                          int key_bits, int K)
 {
     a.keys = keys; a.vals = vals; a.T = ctx->text.as<uint8_t>();
-    a.pb = packed ? pb : 0; a.pmask = packed ? (1ull << pb) - 1 : 0;
+    a.pb = layout != FBG_SLOTS_PAIRS ? pb : 0; a.pmask = layout != FBG_SLOTS_PAIRS ? (1ull << pb) - 1 : 0;
     a.N = slots; a.Ntext = ctx->N; a.n = ctx->n; a.row_len = (uint32_t)(ctx->n + 1);
     a.own_lo = 0; a.own_hi = slots; a.first_part = a.last_part = 1; a.part_mode = 0; a.values_only = 0;
     a.magic32 = (uint32_t)((1ull << 32) / (ctx->n + 1));
+    a.magic64 = ~0ull / (ctx->n + 1) + 1;
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>();
     a.cand = nullptr; a.pm = nullptr; a.blk_count = nullptr; a.region = 0;
@@ -777,14 +789,14 @@ static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *va
 static void rs_remember(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g)
 {
     ctx->rk_keys = keys; ctx->sa_ptr = vals;
-    ctx->rk_packed = g.packed ? 1 : 0; ctx->rk_pb = g.pb;
+    ctx->rk_layout = rs_layout(g); ctx->rk_pb = g.pb;
     ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
 }
 
 // k_rank_scan over the owned slots, the small tie groups, then the candidates: compacted, sorted, tie groups put
 // in final order.  On return a.cand / a.pm name the sorted list and its scratch; *T = ~0 when a workgroup's
 // candidate region overflowed (similar rows: the caller takes another path).
-static int rs_classify(fbg_ctx *ctx, RankArgs &a, int packed, uint64_t *T_out, int *launches)
+static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches)
 {
     hipStream_t st = ctx->stream;
     const uint64_t own = a.own_hi - a.own_lo;
@@ -805,9 +817,9 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int packed, uint64_t *T_out, i
     a.ties = ctx->tie_list.as<uint32_t>();
     a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    RS_LAUNCH(k_rank_scan, packed, dim3(rs_blocks), dim3(RS_THREADS), st, a);
+    RS_LAUNCH(k_rank_scan, layout, dim3(rs_blocks), dim3(RS_THREADS), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
-    RS_LAUNCH(k_tie_simple, packed, dim3(rs_blocks), dim3(256), st, a);
+    RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
     *launches += 2;
     // candidate counts per workgroup -> offsets; total and the largest count come back to the host
     uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
@@ -839,8 +851,8 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int packed, uint64_t *T_out, i
         }));
         a.cand = sorted;
         a.pm = ctx->dp_b.as<uint32_t>();
-        RS_LAUNCH(k_tie_groups, packed, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
-        RS_LAUNCH(k_tie_big, packed, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
+        RS_LAUNCH(k_tie_groups, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
+        RS_LAUNCH(k_tie_big, layout, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
         *launches += 3;
     }
     return FBG_OK;
@@ -854,7 +866,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     ctx->ranked = false;
     ctx->part_active = false;
     const uint64_t N = ctx->N, n = ctx->n, m = ctx->m;
-    const int packed = geom.packed ? 1 : 0;
+    const int layout = rs_layout(geom);
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
@@ -862,7 +874,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
     RankArgs a;
-    rs_args_init(ctx, a, keys, vals, N, packed, geom.pb, geom.b, geom.key_bits, geom.K);
+    rs_args_init(ctx, a, keys, vals, N, layout, geom.pb, geom.b, geom.key_bits, geom.K);
     int launches = 0;
     if (N > (1u << 22)) {
         // sample: (a) similar rows tie almost everywhere -> do not even try the rank-order scan;
@@ -889,10 +901,10 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
         }
     }
     uint64_t T = 0;
-    FBG_TRY(rs_classify(ctx, a, packed, &T, &launches));
+    FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
     if (T == ~0ull) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
     if (T > 0) {
-        RS_LAUNCH(k_runs, packed, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);
+        RS_LAUNCH(k_runs, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);
         launches++;
     }
     unsigned long long h[5];
@@ -907,7 +919,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     if (a.g_min > 1 && h[4] != 0) {
         a.g_min = 0;
         a.values_only = 1;
-        RS_LAUNCH(k_rank_scan, packed, dim3(fbg_blocks(N, RS_CHUNK, 256 * 16)), dim3(RS_THREADS), st, a);
+        RS_LAUNCH(k_rank_scan, layout, dim3(fbg_blocks(N, RS_CHUNK, 256 * 16)), dim3(RS_THREADS), st, a);
         launches++;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
@@ -953,7 +965,7 @@ __global__ void k_halo_import(const uint8_t *__restrict__ blobs, int part, int n
 
 static void rs_part_args(fbg_ctx *ctx, RankArgs &a)
 {
-    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->part_count + 2 * FBG_PART_HALO, ctx->rk_packed, ctx->rk_pb, ctx->rk_b,
+    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->part_count + 2 * FBG_PART_HALO, ctx->rk_layout, ctx->rk_pb, ctx->rk_b,
                  ctx->rk_key_bits, ctx->rk_K);
     a.own_lo = FBG_PART_HALO; a.own_hi = FBG_PART_HALO + ctx->part_count;
     a.first_part = ctx->part == 0; a.last_part = ctx->part + 1 == ctx->nparts;
@@ -973,7 +985,7 @@ int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_
     ctx->part_count = count;
     ctx->part_T = 0;
     rs_remember(ctx, keys, vals, geom);
-    const int packed = geom.packed ? 1 : 0;
+    const int layout = rs_layout(geom);
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
     FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
@@ -994,7 +1006,7 @@ int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_
     }
     if (good) {
         uint64_t T = 0;
-        FBG_TRY(rs_classify(ctx, a, packed, &T, &launches));
+        FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
         if (T == ~0ull) good = 0;
         else {
             ctx->part_T = T;
@@ -1036,7 +1048,7 @@ int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, i
                            a.own_hi, a.keys, a.vals);
         launches++;
         if (ctx->part_T > 0) {
-            RS_LAUNCH(k_runs, ctx->rk_packed, dim3(fbg_blocks(ctx->part_T, 64)), dim3(64), st, a, ctx->part_T);
+            RS_LAUNCH(k_runs, ctx->rk_layout, dim3(fbg_blocks(ctx->part_T, 64)), dim3(64), st, a, ctx->part_T);
             launches++;
             unsigned long long h[2];
             FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -1067,13 +1079,13 @@ int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disabl
 int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr)
 {
     RankArgs a;
-    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->N, ctx->rk_packed, ctx->rk_pb, ctx->rk_b, ctx->rk_key_bits, ctx->rk_K);
+    rs_args_init(ctx, a, ctx->rk_keys, ctx->sa_ptr, ctx->N, ctx->rk_layout, ctx->rk_pb, ctx->rk_b, ctx->rk_key_bits, ctx->rk_K);
     FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
     a.big = ctx->big_groups.as<uint32_t>();
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 5, 0, sizeof(unsigned long long), ctx->stream));
-    RS_LAUNCH(k_tie_groups, ctx->rk_packed, dim3(fbg_blocks(ctx->N, 256)), dim3(256), ctx->stream, a, ctx->N, 0);
-    RS_LAUNCH(k_tie_big, ctx->rk_packed, dim3(RS_BIG_GROUPS), dim3(256), ctx->stream, a, 1);
-    RS_LAUNCH(k_rank_materialize, ctx->rk_packed, dim3(fbg_blocks(ctx->N, 256)), dim3(256), ctx->stream, a, d_sa, d_isa, d_pl, d_pr);
+    RS_LAUNCH(k_tie_groups, ctx->rk_layout, dim3(fbg_blocks(ctx->N, 256)), dim3(256), ctx->stream, a, ctx->N, 0);
+    RS_LAUNCH(k_tie_big, ctx->rk_layout, dim3(RS_BIG_GROUPS), dim3(256), ctx->stream, a, 1);
+    RS_LAUNCH(k_rank_materialize, ctx->rk_layout, dim3(fbg_blocks(ctx->N, 256)), dim3(256), ctx->stream, a, d_sa, d_isa, d_pl, d_pr);
     FBG_HIP_TRY(ctx, hipGetLastError());
     return FBG_OK;
 }

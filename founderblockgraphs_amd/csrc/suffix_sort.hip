@@ -35,17 +35,6 @@ using fbg_sort_config = rocprim::radix_sort_config<
     rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 32>, rocprim::kernel_config<1024, 8>, 9,
                                         rocprim::block_radix_rank_algorithm::match>>;
 
-__global__ void k_byte_hist(const uint8_t *__restrict__ T, uint64_t N, unsigned *__restrict__ hist)
-{
-    __shared__ unsigned h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (uint64_t)gridDim.x * blockDim.x)
-        atomicAdd(&h[T[p]], 1u);
-    __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
 // key[p] = first K symbol codes of suffix p, most significant first, zero beyond the text.
 // Each thread owns PK_ITEMS consecutive positions: the first key is packed symbol by symbol, the following
 // ones roll (drop the leading symbol, append one), so the cost per position is one LDS byte read.
@@ -54,7 +43,7 @@ __global__ void k_byte_hist(const uint8_t *__restrict__ T, uint64_t N, unsigned 
 // and everything after it inside a key count as code 0, which it shares with the smallest symbol.  Such a key is
 // the smallest one with its leading symbols, i.e. the suffix lands where it belongs up to ties, and the scan
 // knows from the row arithmetic how many symbols of a key are real (rank_scan.hip).  Positions beyond the text
-// are separators too.  PACKED: one word per suffix, key << pb | position.  FILTER: keep keys in [lo, hi) only,
+// are separators too.  LAYOUT (FBG_SLOTS_*): pairs, one packed word per suffix, or wide pairs.  FILTER: keep keys in [lo, hi) only,
 // compacted in no particular order (partitioned index).
 #define PK_ITEMS 8
 #define FBG_SEP 0x80
@@ -70,7 +59,7 @@ struct PackArgs {
     unsigned long long *counter;
 };
 
-template <bool COMPACT, bool PACKED, bool FILTER>
+template <bool COMPACT, int LAYOUT, bool FILTER>
 __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
 {
     constexpr int TILE = SS_THREADS * PK_ITEMS;
@@ -117,7 +106,8 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
             const int j = threadIdx.x + i * SS_THREADS;
             const uint64_t p = base + j;
             if (p < a.N) {
-                if (PACKED) a.keys[p] = (skeys[j] << a.pb) | p;
+                if (LAYOUT == FBG_SLOTS_PACKED) a.keys[p] = (skeys[j] << a.pb) | p;
+                else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[p] = (skeys[j] << a.pb) | (p >> 32); a.vals[p] = (uint32_t)p; }
                 else { a.keys[p] = skeys[j]; a.vals[p] = (uint32_t)p; }
             }
         }
@@ -151,8 +141,10 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
         if ((keep[i] >> lane) & 1ull) {
             const uint64_t o = off + (uint64_t)__popcll(keep[i] & ((1ull << lane) - 1));
             if (o < a.cap) {
-                if (PACKED) a.keys[o] = (skeys[j] << a.pb) | (base + j);
-                else { a.keys[o] = skeys[j]; a.vals[o] = (uint32_t)(base + j); }
+                const uint64_t p = base + j;
+                if (LAYOUT == FBG_SLOTS_PACKED) a.keys[o] = (skeys[j] << a.pb) | p;
+                else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[o] = (skeys[j] << a.pb) | (p >> 32); a.vals[o] = (uint32_t)p; }
+                else { a.keys[o] = skeys[j]; a.vals[o] = (uint32_t)p; }
             }
         }
         off += (uint64_t)__popcll(keep[i]);
@@ -163,12 +155,13 @@ static void launch_pack(fbg_ctx *ctx, const KeyGeom &g, bool filter, PackArgs &a
 {
     const dim3 grid(fbg_blocks(a.N, SS_THREADS * PK_ITEMS)), block(SS_THREADS);
     hipStream_t st = ctx->stream;
-#define FBG_PACK(C, P, F) hipLaunchKernelGGL((k_pack<C, P, F>), grid, block, 0, st, a)
+#define FBG_PACK(C, L, F) hipLaunchKernelGGL((k_pack<C, L, F>), grid, block, 0, st, a)
     if (g.compact) {
-        if (g.packed) { if (filter) FBG_PACK(true, true, true); else FBG_PACK(true, true, false); }
-        else          { if (filter) FBG_PACK(true, false, true); else FBG_PACK(true, false, false); }
+        if (g.packed) { if (filter) FBG_PACK(true, FBG_SLOTS_PACKED, true); else FBG_PACK(true, FBG_SLOTS_PACKED, false); }
+        else if (g.wide) { if (filter) FBG_PACK(true, FBG_SLOTS_WIDE, true); else FBG_PACK(true, FBG_SLOTS_WIDE, false); }
+        else { if (filter) FBG_PACK(true, FBG_SLOTS_PAIRS, true); else FBG_PACK(true, FBG_SLOTS_PAIRS, false); }
     } else {
-        if (filter) FBG_PACK(false, false, true); else FBG_PACK(false, false, false);
+        if (filter) FBG_PACK(false, FBG_SLOTS_PAIRS, true); else FBG_PACK(false, FBG_SLOTS_PAIRS, false);
     }
 #undef FBG_PACK
 }
@@ -386,18 +379,8 @@ int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches)
 {
     const uint64_t N = ctx->N;
     hipStream_t st = ctx->stream;
-    const uint8_t *T = ctx->text.as<uint8_t>();
-    unsigned *d_hist = ctx->small.as<unsigned>() + 256;   // small: bytes [0,256) ignore table, [1024,2048) histogram, [2048,2304) code table
-    uint8_t *d_code = ctx->small.as<uint8_t>() + 2048;
-    unsigned *hist = ctx->byte_hist;
-    if (!ctx->byte_hist_valid) {
-        FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
-        hipLaunchKernelGGL(k_byte_hist, dim3(fbg_blocks(N, 256 * 64, 4096)), dim3(256), 0, st, T, N, d_hist);
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(hist, d_hist, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        ctx->byte_hist_valid = true;
-        *launches += 1;
-    }
+    uint8_t *d_code = ctx->small.as<uint8_t>() + 2048;    // small: [0,256) ignore table, [2048,2304) code table, [4096,6144) histogram
+    const uint64_t *hist = ctx->byte_hist;                // made by fbg_build_text
     if (hist[0] != 1)
         return fbg_fail(ctx, FBG_ERR_INVALID, "the MSA contains a NUL byte; the text needs a unique 0 sentinel");
     // the compact coding needs '#' to be smaller than every symbol of the rows, and room for the separator flag
@@ -432,8 +415,15 @@ int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches)
         const int Kfill = (9 * passes) / b;                  // symbols that fit the same number of passes
         K = Kfill < 64 / b ? Kfill : 64 / b;
     }
-    g->compact = compact; g->packed = false; g->pb = 0;
-    if (compact && !getenv("FBG_NO_PACKED")) {
+    g->compact = compact; g->packed = false; g->wide = false; g->pb = 0;
+    if (N >= (1ull << 32) || (compact && getenv("FBG_FORCE_WIDE"))) {
+        // positions beyond 32 bits: their high bits ride in the low bits of the key word
+        if (!compact) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit positions", (unsigned long long)N);
+        int pb = 1;
+        while ((1ull << (32 + pb)) < N) pb++;
+        g->wide = true; g->pb = pb;
+        if (K > (64 - pb) / b) K = (64 - pb) / b;
+    } else if (compact && !getenv("FBG_NO_PACKED")) {
         // one 64-bit word per suffix if the position leaves room for enough symbols (ties up to ~10% are fine:
         // small tie groups are settled inside the scan)
         int pb = 1;
@@ -465,8 +455,11 @@ static int sort_slots(fbg_ctx *ctx, const KeyGeom &g, uint64_t count, uint64_t o
         });
     }
     uint32_t *va = ctx->valsA.as<uint32_t>(), *vb = ctx->valsB.as<uint32_t>() + out_offset;
+    unsigned lo = g.wide ? (unsigned)g.pb : 0u;
+    const unsigned hi = lo + (unsigned)g.key_bits;
+    if (hi == 64 && count < (1u << 23)) lo = 0;        // same caution as above
     return with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-        return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, ka, kb, va, vb, (size_t)count, 0u, (unsigned)g.key_bits, st);
+        return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, ka, kb, va, vb, (size_t)count, lo, hi, st);
     });
 }
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
                                                           const uint8_t *__restrict__ is_ignore,
                                                           uint32_t *__restrict__ tot,
                                                           unsigned long long *__restrict__ scalars,
-                                                          unsigned *__restrict__ hist)
+                                                          unsigned long long *__restrict__ hist)
 {
     __shared__ uint32_t red[2][TB_THREADS / 64];
     __shared__ uint32_t sh[256];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
     }
     if (lane == 0) { red[0][threadIdx.x >> 6] = nongap; red[1][threadIdx.x >> 6] = ign; }
     __syncthreads();
-    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
     if (threadIdx.x == 0) {
         uint32_t a = 0, b = 0;
         for (int k = 0; k < TB_THREADS / 64; k++) { a += red[0][k]; b += red[1][k]; }
@@ -269,11 +269,10 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_TEXT));
     int launches = 0;
-    ctx->byte_hist_valid = false;
     FBG_TRY(fbg_reserve(ctx, ctx->pos, m * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->tot, m * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->scalars, 256 * sizeof(unsigned long long)));
-    FBG_TRY(fbg_reserve(ctx, ctx->small, 4096));
+    FBG_TRY(fbg_reserve(ctx, ctx->small, 8192));   // [0,256) ignore table, [2048,2304) code table, [4096,6144) symbol histogram
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->scalars.p, 0, 64 * sizeof(unsigned long long), st));
 
     ctx->have_ignore = ignore_len > 0;
@@ -287,8 +286,8 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // table[] is on this stack frame
     }
     unsigned long long *sc = ctx->scalars.as<unsigned long long>();
-    unsigned *d_hist = ctx->small.as<unsigned>() + 256;            // small: bytes [1024, 2048)
-    FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 1024, st));
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ctx->small.as<uint8_t>() + 4096);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 2048, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->tot.p, 0, m * 4, st));
     hipLaunchKernelGGL(k_row_count, dim3((unsigned)((n + RC_SEG - 1) / RC_SEG), (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
                        n, d_is_ignore, ctx->tot.as<uint32_t>(), sc, d_hist);
@@ -297,16 +296,17 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     launches += 2;
     unsigned long long h[3];
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->byte_hist, d_hist, 256 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->byte_hist, d_hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     // symbol histogram of the text: the cells without the gaps, a '#' per row, the sentinel
     ctx->byte_hist['-'] = 0;
-    ctx->byte_hist['#'] += (unsigned)m;
+    ctx->byte_hist['#'] += m;
     ctx->byte_hist[0] += 1;
-    ctx->byte_hist_valid = true;
     ctx->gapfree = h[0] == 0;
     ctx->N = h[2];
-    if (ctx->N >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit ranks", h[2]);
+    if (ctx->N >= (1ull << 32) && !(ctx->allow_wide && ctx->gapfree && !ctx->reversed && !ctx->have_ignore && ctx->N < (1ull << 40)))
+        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit positions (only the partitioned index of a "
+                        "gap-free MSA, elastic scan, goes beyond)", h[2]);
     if (ctx->reversed && !ctx->gapfree)
         return fbg_fail(ctx, FBG_ERR_INVALID,
                         "the non-elastic scan needs gap-free rows (the reference drops rows with gaps when "

@@ -1,6 +1,8 @@
-"""Per-rank cost of the key-range partitioned index at weak-scaled sizes, on ONE GPU: the P partitions of a
-P-GPU job are played one after the other by P contexts (as tests/test_gpu_parity.py::_partitioned does), so each
-context's stage timers show what its rank would spend on a GPU of its own.  Usage: gpu_part_sim.py P [cols_per_gpu]"""
+"""Per-rank cost of the key-range partitioned index at weak-scaled sizes, on ONE GPU.  The P partitions of a P-GPU job
+are played one after the other; each partition's stage timers show what its rank would spend on a GPU of its own.
+Default: P contexts (as tests/test_gpu_parity.py::_partitioned does).  --sequential: one context only, each
+partition built twice (once for its edge slots, once more before its scan) -- for sizes where P contexts do not
+fit one GPU's memory.  Usage: gpu_part_sim.py P [cols_per_gpu] [--sequential]"""
 import json
 import os
 import sys
@@ -11,35 +13,54 @@ import torch
 import founderblockgraphs_amd as F
 from founderblockgraphs_amd._lib import PART_HALO_BYTES
 
-P = int(sys.argv[1])
-cols = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+sequential = "--sequential" in sys.argv
+P = int(args[0])
+cols = int(args[1]) if len(args) > 1 else 1_000_000
 m, n = 1000, cols * P
 d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
-engines = [F.Engine() for _ in range(P)]
+engines = [F.Engine() for _ in range(1 if sequential else P)]
 engines[0].msa_synthetic(d.data_ptr(), m, n)
 blobs = torch.zeros(P * PART_HALO_BYTES, dtype=torch.uint8, device="cuda")
-gm = [torch.zeros(n + 1, dtype=torch.int32, device="cuda") for _ in range(P)]
+red = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+gm = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
-for it in range(2):
+rows = []
+for it in range(1 if sequential else 2):
     wall = [0.0] * P
-    for r, e in enumerate(engines):
+    stages = [None] * P
+    red.zero_()
+    if sequential:
+        e = engines[0]
         e.msa_set_device(d.data_ptr(), m, n)
-        t = time.perf_counter()
-        ok = e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
-        e.sync()
-        wall[r] += time.perf_counter() - t
-        assert ok
-    for r, e in enumerate(engines):
-        t = time.perf_counter()
-        ok = e.part_scan(blobs.data_ptr(), gm[r].data_ptr())
-        e.sync()
-        wall[r] += time.perf_counter() - t
-        assert ok
-    red = gm[0]
-    for g in gm[1:]:
-        red = torch.maximum(red, g)
-    torch.cuda.synchronize()
-    for r, e in enumerate(engines):
+        for r in range(P):
+            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+            e.sync()
+        for r in range(P):
+            t = time.perf_counter()
+            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+            assert e.part_scan(blobs.data_ptr(), gm.data_ptr())
+            e.sync()
+            wall[r] = time.perf_counter() - t
+            stages[r] = {k: round(v[0], 2) for k, v in e.stage_ms().items()}
+            torch.maximum(red, gm, out=red)
+            torch.cuda.synchronize()
+    else:
+        for r, e in enumerate(engines):
+            e.msa_set_device(d.data_ptr(), m, n)
+            t = time.perf_counter()
+            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+            e.sync()
+            wall[r] += time.perf_counter() - t
+        for r, e in enumerate(engines):
+            t = time.perf_counter()
+            assert e.part_scan(blobs.data_ptr(), gm.data_ptr())
+            e.sync()
+            wall[r] += time.perf_counter() - t
+            stages[r] = {k: round(v[0], 2) for k, v in e.stage_ms().items()}
+            torch.maximum(red, gm, out=red)
+            torch.cuda.synchronize()
+    for e in engines:
         assert e.part_finish(red.data_ptr())
     d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
@@ -49,8 +70,8 @@ for it in range(2):
     blocks = engines[0].minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
     engines[0].sync()
     tail = time.perf_counter() - t
-for r, e in enumerate(engines):
-    print(json.dumps({"part": r, "wall_ms": 1e3 * wall[r], "stages": {k: round(v[0], 2) for k, v in e.stage_ms().items()},
-                      "device_GB": e.device_bytes() / 1e9}))
-print(json.dumps({"P": P, "n": n, "blocks": blocks, "rank0_tail_ms": 1e3 * tail,
+for r in range(P):
+    print(json.dumps({"part": r, "wall_ms": 1e3 * wall[r], "stages": stages[r]}))
+print(json.dumps({"P": P, "n": n, "text": m * (n + 1) + 1, "sequential": sequential, "blocks": blocks, "rank0_tail_ms": 1e3 * tail,
+                  "device_GB": engines[0].device_bytes() / 1e9,
                   "est_step_ms": 1e3 * (max(wall) + tail), "est_cols_per_s": n / (max(wall) + tail)}))

@@ -379,6 +379,7 @@ ALT_PATHS = [
     {"FBG_RANK_NO_THRESHOLD": "1"},                  # rank-order scan without the sampled threshold
     {"FBG_NO_PACKED": "1"},                          # rank-order scan on (key, position) pairs instead of packed words
     {"FBG_NO_PACKED": "1", "FBG_FULL_KEYS": "1"},
+    {"FBG_FORCE_WIDE": "1"},                         # ... on wide pairs (the layout for texts beyond 2^32 symbols)
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
     {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
@@ -535,7 +536,8 @@ def test_partitioned_index_full_size():
             e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}], ids=["packed", "pairs", "nothreshold"])
+@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}],
+                         ids=["packed", "pairs", "wide", "nothreshold"])
 def test_rank_scan_sampled_regime_matches_oracle(engine, env):
     """Texts above 2^22 symbols use the sampled threshold and regime test of the rank-order scan: f and v must
     still be the oracle's, for iid rows and for rows with shared stretches (ties, runs, short suffixes)."""
@@ -578,3 +580,76 @@ def test_rank_scan_short_rows_and_heavy_ties(engine, alphabet):
         if exp[0] != n:                                  # otherwise the engine reports "no valid segmentation"
             assert np.array_equal(engine.elastic_f(msa, disable_efg_tricks=True), exp)
         assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa)), (alphabet, m, n)
+
+
+def test_partitioned_index_wide_layout():
+    """The slot layout of texts beyond 2^32 symbols (high position bits in the key word), forced on small inputs."""
+    import os
+    import torch
+    from founderblockgraphs_amd import Engine
+    rng = np.random.default_rng(314)
+    os.environ["FBG_FORCE_WIDE"] = "1"
+    engines = [Engine() for _ in range(3)]
+    try:
+        for (m, n, kw) in [(24, 500, {}), (50, 300, dict(alphabet="AC")), (40, 400, dict(similar=0.5))]:
+            msa = random_msa(rng, m, n, **kw)
+            for e in engines:
+                e.msa_load_host(msa)
+            ok1, ok2, ok3 = _partitioned(engines, n)
+            assert all(ok1) and all(ok2) and all(ok3), (m, n, kw, ok1, ok2, ok3)
+            d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            engines[0].scan_f(0, n, d_f.data_ptr())
+            engines[0].sync()
+            assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa))
+    finally:
+        del os.environ["FBG_FORCE_WIDE"]
+        for e in engines:
+            e.close()
+
+
+def test_partitioned_index_beyond_32bit_positions():
+    """550 x 8,000,000: a text of 4.4e9 symbols, more than 32-bit positions hold.  The key-range partitioned index
+    (4 partitions, wide slots) must give the f of the row-group-pair plan, whose pair texts fit 32 bits
+    (distributed.py: exact by construction, checked against the oracle at small sizes)."""
+    import torch
+    from founderblockgraphs_amd import Engine
+    from founderblockgraphs_amd import distributed as D
+    m, n, P = 550, 8_000_000, 4
+    assert m * (n + 1) + 1 > (1 << 32)
+    d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    engines = [Engine() for _ in range(P)]
+    try:
+        engines[0].msa_synthetic(d.data_ptr(), m, n)
+        for e in engines:
+            e.msa_set_device(d.data_ptr(), m, n)
+        ok1, ok2, ok3 = _partitioned(engines, n)
+        assert all(ok1) and all(ok2) and all(ok3), (ok1, ok2, ok3)
+        d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        engines[2].scan_f(0, n, d_f.data_ptr())
+        engines[2].sync()
+    finally:
+        for e in engines:
+            e.close()
+    # reference: pairs of row groups, each pair's text below 2^32 symbols
+    G, groups, plan = D.plan_row_pairs(m, n, 1)
+    d_g = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_rows = torch.empty(max((groups[a][1] - groups[a][0]) + (groups[b][1] - groups[b][0]) for a, b in plan[0]) * n,
+                         dtype=torch.uint8, device="cuda")
+    eng = Engine()
+    try:
+        for a, b in plan[0]:
+            off = 0
+            for g in (a, b):
+                r0, r1 = groups[g]
+                d_rows[off * n:(off + r1 - r0) * n].copy_(d[r0 * n:r1 * n])
+                off += r1 - r0
+            torch.cuda.synchronize()
+            eng.msa_set_device(d_rows.data_ptr(), off, n)
+            eng.index_build()
+            eng.scan_f(0, n, d_g.data_ptr())
+            eng.sync()
+    finally:
+        eng.close()
+    assert G >= 2 and torch.equal(d_f, d_g)
