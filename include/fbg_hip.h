@@ -137,7 +137,8 @@ int fbg_msa_synthetic(fbg_ctx *ctx, uint8_t *d_msa, uint64_t m, uint64_t n, uint
  */
 int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uint64_t ignore_len);
 /*
- * Partitioned index for multi-GPU jobs (gap-free MSAs without ignore characters): every rank holds the same
+ * Partitioned index for multi-GPU jobs (gap-free MSAs without ignore characters; the only path that accepts texts of
+ * 2^32 symbols and more, elastic scan): every rank holds the same
  * MSA, but sorts and scans only the suffixes of key range `part` of `nparts`, so index memory and sort time
  * divide by the number of GPUs.  The caller moves two small things between the ranks:
  *
