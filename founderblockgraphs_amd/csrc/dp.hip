@@ -703,24 +703,32 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     bool literal = R == 0;
     bool tiled = false;
     if (!literal) {
-        if (R <= 4 && !getenv("FBG_DP_WAVE")) {
-            // sweeps that work straight from f (no bucket order needed)
+        bool settled = false;
+        if (!getenv("FBG_DP_WAVE")) {
+            // sweeps that work straight from f (no bucket order needed).  The window that is provably enough
+            // (64 R >= 2 max_ext + 2) is rarely needed: start with the smallest one that holds every extension and
+            // widen when the sweep reports a value at its limit
             uint8_t *ext7 = ctx->dp_e.as<uint8_t>(), *clen = ctx->dp_f.as<uint8_t>();
-            const bool tile = R == 1 && getenv("FBG_DP_TILE");
-            hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n,
-                               tile ? 127u : 255u, ext7, clen);
-            if (tile) {
-                hipLaunchKernelGGL(k_dp_tile, dim3(1), dim3(64), 0, st, ext7, clen, (uint32_t)n, mml, bt, sc);
-            } else {
-                const uint32_t WN = 64u * R;
-                const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN);
-                FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
-                uint8_t *Wt = ctx->tmp.as<uint8_t>();
-                const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
-                const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
-                const uint32_t Fg = 16;                                  // blocks per group of the chain (a chain step costs ~0.5 us)
-                const uint32_t ngroups = (nblocks + Fg - 1) / Fg;
-                uint8_t *Sg = reinterpret_cast<uint8_t *>(cur);          // (n+2)*4 bytes >= ngroups * WN: free on this path
+            int Rt = 1;
+            while (64ull * Rt < max_ext + 2 && Rt < 4) Rt *= 2;
+            if (getenv("FBG_DP_SAFE_WINDOW")) Rt = R;
+            for (; Rt <= 4 && Rt <= R && !settled; Rt *= 2) {
+                const bool tile = Rt == 1 && getenv("FBG_DP_TILE");
+                FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n,
+                                   tile ? 127u : 255u, ext7, clen);
+                if (tile) {
+                    hipLaunchKernelGGL(k_dp_tile, dim3(1), dim3(64), 0, st, ext7, clen, (uint32_t)n, mml, bt, sc);
+                } else {
+                    const uint32_t WN = 64u * Rt;
+                    const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN);
+                    FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
+                    uint8_t *Wt = ctx->tmp.as<uint8_t>();
+                    const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
+                    const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
+                    const uint32_t Fg = 16;                              // blocks per group of the chain (a chain step costs ~0.5 us)
+                    const uint32_t ngroups = (nblocks + Fg - 1) / Fg;
+                    uint8_t *Sg = reinterpret_cast<uint8_t *>(cur);      // (n+2)*4 bytes >= ngroups * WN: free on this path
 #define FBG_DP_PIPE(RR)                                                                                                   \
     do {                                                                                                                 \
         if (lds > 64 * 1024)                                                                                             \
@@ -732,14 +740,28 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);        \
         hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc);    \
     } while (0)
-                if (R == 1) FBG_DP_PIPE(1);
-                else if (R == 2) FBG_DP_PIPE(2);
-                else FBG_DP_PIPE(4);
+                    if (Rt == 1) FBG_DP_PIPE(1);
+                    else if (Rt == 2) FBG_DP_PIPE(2);
+                    else FBG_DP_PIPE(4);
 #undef FBG_DP_PIPE
-                hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, WN, bt, sc);
+                    hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, WN, bt, sc);
+                }
+                FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+                FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+                settled = hk[4] == 0;
             }
-            tiled = true;
-        } else {
+            tiled = settled;
+            if (!settled) {
+                // ext7 / clen live in count / bcount: the bucket sweeps below want those zeroed again
+                FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+                FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
+                FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
+                FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
+                FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
+                FBG_HIP_TRY(ctx, hipMemsetAsync(cur, 0xff, w, st));
+            }
+        }
+        if (!settled && (R > 4 || getenv("FBG_DP_WAVE"))) {
             switch (R) {
             case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
             case 2: hipLaunchKernelGGL((k_dp_wave<2>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
@@ -747,10 +769,11 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             case 8: hipLaunchKernelGGL((k_dp_wave<8>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
             default: hipLaunchKernelGGL((k_dp_wave<16>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
             }
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            settled = hk[4] == 0;
         }
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (hk[4] != 0) literal = true;   // guard tripped: fall through to the literal sweep
+        if (!settled) literal = true;   // guards tripped: the literal sweep
     }
     if (literal) {
         FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));

@@ -64,12 +64,14 @@ for it in range(1 if sequential else 2):
         assert e.part_finish(red.data_ptr())
     d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    engines[0].scan_f(0, n, d_f.data_ptr())
-    blocks = engines[0].minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
-    engines[0].sync()
-    tail = time.perf_counter() - t
+    for _ in range(2):                                 # the second time: buffers exist
+        d_f.zero_()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        engines[0].scan_f(0, n, d_f.data_ptr())
+        blocks = engines[0].minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        engines[0].sync()
+        tail = time.perf_counter() - t
 for r in range(P):
     print(json.dumps({"part": r, "wall_ms": 1e3 * wall[r], "stages": stages[r]}))
 print(json.dumps({"P": P, "n": n, "text": m * (n + 1) + 1, "sequential": sequential, "blocks": blocks, "rank0_tail_ms": 1e3 * tail,
