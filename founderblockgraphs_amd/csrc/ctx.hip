@@ -155,9 +155,9 @@ int fbg_release_scratch(fbg_ctx *ctx)
     if (!ctx) return FBG_ERR_INVALID;
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // valsB stays: it is the suffix array
-    // keysB stays as well: the rank-order index reads the sorted keys
-    DevBuf *bufs[] = {&ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list,
+    // valsB stays: it is the suffix array; so does whichever key buffer holds the sorted slots of a rank-order index
+    const bool sorted_in_A = ctx->ranked && ctx->rk_keys == ctx->keysA.as<uint64_t>();
+    DevBuf *bufs[] = {sorted_in_A ? &ctx->keysB : &ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);

@@ -122,7 +122,8 @@ int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches);       
 int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int pre_ok,
                            uint8_t *d_blob, int *ok);                         // rank_scan.hip
 int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok);
-int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);                        // suffix_sort.hip
+int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip                        // suffix_sort.hip
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
                      uint64_t *d_out);                                        // scan.hip
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,

@@ -1,0 +1,433 @@
+// msd_sort.hip -- the round-0 sort of the packed slots (key << pb | position) in three passes over the data.
+//
+// An LSD radix sort moves all N slots once per 9-bit digit: 4 passes for the 34 key bits of a 10^9-symbol DNA text,
+// after a pass that writes the unsorted slots and one that reads them for the digit histograms (80 bytes of HBM
+// traffic per suffix with rocPRIM's onesweep).  Most-significant-digit first, each pass only has to bring a slot
+// into the right bucket, in any order, and the last 16 bits can be settled inside LDS:
+//
+//   k_msd_pack_split   pass 1, fused with the key packing of suffix_sort.hip: the keys of 8192 text positions are
+//                      built in registers, ranked by their top 9 bits with LDS atomics, regrouped in LDS and written
+//                      out in runs -- one global atomic per (tile, bucket) reserves the run's place.  No histogram
+//                      pass: every bucket owns a fixed stretch of cap1 slots (mean + 25 %).
+//   k_msd_split        pass 2: every bucket of pass 1, tile by tile, by the next 9 bits into sub-buckets of MSD_FN_CAP
+//                      slots each.
+//   k_msd_finish       pass 3: one workgroup per sub-bucket (a few thousand slots): split on the next 10 bits inside
+//                      LDS, then every slot counts the smaller slots of its bin -- its final place -- and the
+//                      sub-bucket leaves in order, at the offset the scan of the sub-bucket sizes gives it.
+//
+// 8 (text) + 8 + 16 + 16 = 48 bytes of traffic per suffix on paper (a little more for the gaps between buckets).
+// The fixed capacities are an optimistic bet on keys that spread evenly (dissimilar rows -- the only inputs that come
+// here, see sample_says_similar); a bucket or sub-bucket that overflows raises a flag and the caller sorts with
+// rocPRIM instead (suffix_sort.hip).  Equal keys end up in position order.
+#include "fbg_internal.h"
+#include <rocprim/rocprim.hpp>
+
+#define MSD_DIG 9
+#define MSD_NB (1 << MSD_DIG)
+#define MSD_THREADS 1024
+#define MSD_ITEMS 8
+#define MSD_TILE (MSD_THREADS * MSD_ITEMS)
+#define MSD_FN_THREADS 256
+#define MSD_FN_CAP 4608                        // slots per sub-bucket (mean at 10^9 suffixes: 3815)
+#define MSD_FN_ITEMS (MSD_FN_CAP / MSD_FN_THREADS)
+#define MSD_FN_BITS 10
+#define MSD_FN_BINS (1 << MSD_FN_BITS)
+#define MSD_SEP 0x80                           // FBG_SEP of suffix_sort.hip
+#define MSD_BIG_THREADS 1024
+#define MSD_BIG_CAP 16384                      // largest sub-bucket (k_msd_finish_big)
+#define MSD_ARENA (1u << 20)
+
+struct MsdArgs {
+    const uint8_t *T;
+    uint64_t N;
+    const uint8_t *code;
+    int b, K, pb, kb;                          // bits per symbol, symbols per key, position bits, key bits
+    uint64_t *buf1;                            // pass 1 output: MSD_NB stretches of cap1 slots
+    uint64_t cap1;
+    unsigned long long *count1;                // [MSD_NB]
+    const uint32_t *tile_start;                // [MSD_NB + 1]: first tile of every bucket (pass 2)
+    uint64_t *buf2;                            // pass 2 output: MSD_NB^2 stretches of MSD_FN_CAP slots
+    uint32_t *count2;                          // [MSD_NB^2]
+    const unsigned long long *off;             // [MSD_NB^2 + 1]: exclusive scan of count2
+    uint64_t *out;                             // sorted slots
+    uint32_t *arena_sb;                        // slots that did not fit their sub-bucket's stretch: sub-bucket ...
+    uint64_t *arena_w;                         // ... and word, arena_count[0] of them (few: row ends pile up on a few keys)
+    unsigned long long *arena_count;
+    uint32_t arena_cap;
+    unsigned long long *flag;                  // != 0: a capacity was exceeded
+};
+
+// ranks -> exclusive offsets of the MSD_NB digit counts of a tile; thread d < MSD_NB also reserves the run of digit d
+// behind *cursor (one global atomic per non-empty digit) and leaves its start, relative to the bucket, in gbase[d]
+__device__ __forceinline__ void msd_scan_and_reserve(uint32_t *cnt, uint32_t *loff, unsigned long long *gbase, uint32_t *wsum,
+                                                     unsigned long long *cursor_d, bool wide_cursor, uint32_t *cursor32_d)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t c = threadIdx.x < MSD_NB ? cnt[threadIdx.x] : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+    if (threadIdx.x < MSD_NB) {
+        loff[threadIdx.x] = pre + inc - c;
+        unsigned long long g = 0;
+        if (c) g = wide_cursor ? atomicAdd(cursor_d, (unsigned long long)c) : (unsigned long long)atomicAdd(cursor32_d, c);
+        gbase[threadIdx.x] = g;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
+{
+    __shared__ uint64_t buf[MSD_TILE];         // first the symbol codes of the tile (bytes), then the regrouped slots
+    __shared__ uint8_t cd[256];
+    __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
+    __shared__ unsigned long long gbase[MSD_NB];
+    __shared__ uint32_t wsum[MSD_THREADS / 64];
+    uint8_t *tile = reinterpret_cast<uint8_t *>(buf);          // MSD_TILE + 64 bytes
+    const int b = a.b, K = a.K;
+    if (threadIdx.x < 256) cd[threadIdx.x] = a.code[threadIdx.x];
+    if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * MSD_TILE;
+    for (int k = threadIdx.x; k < MSD_TILE + 64; k += MSD_THREADS) {
+        const uint64_t p = base + k;
+        tile[k] = p < a.N ? cd[a.T[p]] : (uint8_t)MSD_SEP;
+    }
+    __syncthreads();
+    // keys of the thread's MSD_ITEMS consecutive positions: rolling, separators handled where a row ends (k_pack)
+    const int t0 = threadIdx.x * MSD_ITEMS;
+    const uint64_t mask = (K * b) >= 64 ? ~0ull : ((1ull << (K * b)) - 1);
+    uint64_t w[MSD_ITEMS];
+    uint64_t key = 0;
+    uint32_t seen = 0;
+    for (int k = 0; k < K; k++) { const uint32_t c = tile[t0 + k]; seen |= c; key = (key << b) | c; }
+#pragma unroll
+    for (int i = 0; i < MSD_ITEMS; i++) {
+        w[i] = key;
+        const uint32_t c = tile[t0 + K + i];
+        seen |= c;
+        key = ((key << b) | c) & mask;
+    }
+    if (seen & MSD_SEP) {
+#pragma unroll
+        for (int i = 0; i < MSD_ITEMS; i++) {
+            uint64_t kk = 0;
+            bool dead = false;
+            for (int k = 0; k < K; k++) {
+                const uint32_t c = tile[t0 + i + k];
+                dead = dead || (c & MSD_SEP);
+                kk = (kk << b) | (dead ? 0u : c);
+            }
+            w[i] = kk;
+        }
+    }
+    __syncthreads();                                            // the byte tile is done with: buf is free
+    uint32_t rk[MSD_ITEMS];
+    const int dshift = a.kb - MSD_DIG;
+#pragma unroll
+    for (int i = 0; i < MSD_ITEMS; i++) {
+        const uint64_t p = base + t0 + i;
+        const bool ok = p < a.N;
+        rk[i] = ok ? atomicAdd(&cnt[(uint32_t)(w[i] >> dshift)], 1u) : 0xffffffffu;
+        w[i] = (w[i] << a.pb) | p;
+    }
+    __syncthreads();
+    msd_scan_and_reserve(cnt, loff, gbase, wsum, a.count1 + (threadIdx.x < MSD_NB ? threadIdx.x : 0), true, nullptr);
+    const int wshift = a.pb + dshift;
+#pragma unroll
+    for (int i = 0; i < MSD_ITEMS; i++)
+        if (rk[i] != 0xffffffffu) buf[loff[(uint32_t)(w[i] >> wshift)] + rk[i]] = w[i];
+    __syncthreads();
+    const uint32_t have = (uint32_t)min((uint64_t)MSD_TILE, a.N - base);
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        if (j < have) {
+            const uint64_t x = buf[j];
+            const uint32_t d = (uint32_t)(x >> wshift);
+            const uint64_t at = gbase[d] + (j - loff[d]);
+            if (at < a.cap1) a.buf1[(uint64_t)d * a.cap1 + at] = x;
+            else *a.flag = 1;
+        }
+    }
+}
+
+// first tile of every bucket of pass 1 (one thread; MSD_NB buckets)
+__global__ void k_msd_tiles(const unsigned long long *__restrict__ count1, uint64_t cap1, uint32_t *__restrict__ tile_start,
+                            unsigned long long *__restrict__ flag)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t t = 0;
+    for (int s = 0; s < MSD_NB; s++) {
+        tile_start[s] = t;
+        const unsigned long long c = count1[s] < cap1 ? count1[s] : cap1;
+        if (count1[s] > cap1) *flag = 1;
+        t += (uint32_t)((c + MSD_TILE - 1) / MSD_TILE);
+    }
+    tile_start[MSD_NB] = t;
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
+{
+    __shared__ uint64_t buf[MSD_TILE];
+    __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
+    __shared__ unsigned long long gbase[MSD_NB];
+    __shared__ uint32_t wsum[MSD_THREADS / 64];
+    // the bucket this tile belongs to: largest s with tile_start[s] <= blockIdx.x
+    uint32_t lo = 0, hi = MSD_NB;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (a.tile_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t seg = lo;
+    const uint64_t segn = min((uint64_t)a.count1[seg], a.cap1);
+    const uint64_t first = (uint64_t)(blockIdx.x - a.tile_start[seg]) * MSD_TILE;
+    const uint32_t have = (uint32_t)min((uint64_t)MSD_TILE, segn - first);
+    const uint64_t *in = a.buf1 + (uint64_t)seg * a.cap1 + first;
+    if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int wshift = a.pb + a.kb - 2 * MSD_DIG;
+    uint64_t w[MSD_ITEMS];
+    uint32_t rk[MSD_ITEMS];
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        w[r] = j < have ? in[j] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        rk[r] = j < have ? atomicAdd(&cnt[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    msd_scan_and_reserve(cnt, loff, gbase, wsum, nullptr, false,
+                         a.count2 + (size_t)seg * MSD_NB + (threadIdx.x < MSD_NB ? threadIdx.x : 0));
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        if (j < have) buf[loff[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)] + rk[r]] = w[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        if (j < have) {
+            const uint64_t x = buf[j];
+            const uint32_t d = (uint32_t)(x >> wshift) & (MSD_NB - 1);
+            const uint64_t at = gbase[d] + (j - loff[d]);
+            if (at < MSD_FN_CAP) a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at] = x;
+            else {
+                const unsigned long long e = atomicAdd(a.arena_count, 1ull);
+                if (e < a.arena_cap) { a.arena_sb[e] = seg * MSD_NB + d; a.arena_w[e] = x; }
+                else *a.flag = 1;
+            }
+        }
+    }
+}
+
+__global__ void k_msd_widen(const uint32_t *__restrict__ count2, unsigned long long *__restrict__ wide, uint64_t cnt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) wide[i] = count2[i];
+}
+
+// `have` slots (the first n_a from in_a, the rest from in_b) -> out, sorted: bins on key bits inside LDS, then every slot
+// counts the smaller slots of its bin (the words are distinct)
+template <int CAP, int THREADS>
+__device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, const uint64_t *in_a,
+                                                uint32_t n_a, const uint64_t *in_b, uint32_t have, uint64_t *out, int fshift,
+                                                uint32_t fmask)
+{
+    constexpr int ITEMS = CAP / THREADS;
+    for (int i = threadIdx.x; i < MSD_FN_BINS; i += THREADS) cnt[i] = 0;
+    __syncthreads();
+    uint64_t w[ITEMS];
+    uint32_t rk[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        w[r] = j < have ? (j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        rk[r] = j < have ? atomicAdd(&cnt[(uint32_t)(w[r] >> fshift) & fmask], 1u) : 0u;
+    }
+    __syncthreads();
+    {   // exclusive scan of the bin counts: consecutive bins per thread (threads beyond the bins idle)
+        constexpr int PER = MSD_FN_BINS / THREADS > 0 ? MSD_FN_BINS / THREADS : 1;
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const bool mine = threadIdx.x * PER < MSD_FN_BINS;
+        uint32_t c[PER], tot = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) { c[q] = mine ? cnt[threadIdx.x * PER + q] : 0u; tot += c[q]; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t pre = inc - tot;
+        for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < PER; q++) { loff[threadIdx.x * PER + q] = pre; pre += c[q]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        if (j < have) buf[loff[(uint32_t)(w[r] >> fshift) & fmask] + rk[r]] = w[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        if (j < have) {
+            const uint32_t bin = (uint32_t)(w[r] >> fshift) & fmask;
+            const uint32_t b0 = loff[bin], c = cnt[bin];
+            uint32_t smaller = 0;
+            for (uint32_t q = 0; q < c; q++) smaller += buf[b0 + q] < w[r] ? 1u : 0u;
+            rk[r] = b0 + smaller;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        if (j < have) buf[rk[r]] = w[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        if (j < have) out[j] = buf[j];
+    }
+}
+
+__global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fshift, uint32_t fmask)
+{
+    __shared__ uint64_t buf[MSD_FN_CAP];
+    __shared__ uint32_t cnt[MSD_FN_BINS], loff[MSD_FN_BINS];
+    __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
+    const uint32_t have = a.count2[blockIdx.x];
+    if (have == 0 || have > MSD_FN_CAP) return;                // the larger ones: k_msd_finish_big
+    const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
+    msd_finish_body<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, in, have, in, have, a.out + a.off[blockIdx.x], fshift, fmask);
+}
+
+// sub-buckets whose stretch overflowed: the arena (sorted by sub-bucket) holds the slots beyond MSD_FN_CAP.  One
+// workgroup per arena entry; the first entry of a sub-bucket's run does the work.
+__global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, const uint32_t *__restrict__ sb_sorted,
+                                                                    const uint64_t *__restrict__ w_sorted, uint32_t entries,
+                                                                    int fshift, uint32_t fmask)
+{
+    __shared__ uint64_t buf[MSD_BIG_CAP];
+    __shared__ uint32_t cnt[MSD_FN_BINS], loff[MSD_FN_BINS];
+    __shared__ uint32_t wsum[MSD_BIG_THREADS / 64];
+    const uint32_t e = blockIdx.x;
+    if (e >= entries) return;
+    const uint32_t sb = sb_sorted[e];
+    if (e > 0 && sb_sorted[e - 1] == sb) return;
+    const uint32_t have = a.count2[sb];
+    if (have > MSD_BIG_CAP || have <= MSD_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
+    msd_finish_body<MSD_BIG_CAP, MSD_BIG_THREADS>(buf, cnt, loff, wsum, a.buf2 + (uint64_t)sb * MSD_FN_CAP, MSD_FN_CAP, w_sorted + e, have,
+                                                  a.out + a.off[sb], fshift, fmask);
+}
+
+// Sorts the packed slots of the current text by their key bits.  *ok = 0: a capacity was exceeded (keys spread
+// unevenly) or the geometry does not suit this sort -- nothing usable was produced.  On success *sorted points at
+// the N sorted words (inside ctx->keysA).
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches)
+{
+    *ok = 0;
+    const uint64_t N = ctx->N;
+    const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
+    const uint64_t min_n = getenv("FBG_MSD_MIN") ? strtoull(getenv("FBG_MSD_MIN"), nullptr, 10) : (1ull << 24);   // tests lower it
+    if (!g.packed || !g.compact || N < min_n || rest < 1 || getenv("FBG_NO_MSD_SORT")) return FBG_OK;
+    const int fbits = rest < MSD_FN_BITS ? rest : MSD_FN_BITS;
+    // without enough bits for the bins the counting in the finish turns quadratic: leave those to rocPRIM
+    if (fbits < 6) return FBG_OK;
+    hipStream_t st = ctx->stream;
+    const uint64_t cap1 = N / MSD_NB + N / (4 * MSD_NB) + 65536;
+    const uint64_t nsub = (uint64_t)MSD_NB * MSD_NB;
+    if (N / nsub + N / (8 * nsub) + 64 > MSD_FN_CAP) return FBG_OK;         // sub-buckets would not fit LDS
+    FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)MSD_NB * cap1 * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->keysB, (size_t)nsub * MSD_FN_CAP * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, MSD_NB * 8 + (MSD_NB + 1) * 4 + 64));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_b, nsub * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (nsub + 1) * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)MSD_ARENA * 4 * 2));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_e, (size_t)MSD_ARENA * 8 * 2));
+    unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;
+    MsdArgs a;
+    a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = g.pb; a.kb = g.key_bits;
+    a.buf1 = ctx->keysA.as<uint64_t>(); a.cap1 = cap1;
+    a.count1 = ctx->dp_a.as<unsigned long long>();
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + MSD_NB * 8);
+    a.tile_start = tile_start;
+    a.buf2 = ctx->keysB.as<uint64_t>();
+    a.count2 = ctx->dp_b.as<uint32_t>();
+    unsigned long long *off = ctx->dp_c.as<unsigned long long>();
+    a.off = off;
+    a.out = ctx->keysA.as<uint64_t>();         // pass 1's slots are dead by then
+    a.flag = flag;
+    a.arena_sb = ctx->dp_d.as<uint32_t>(); a.arena_w = ctx->dp_e.as<uint64_t>(); a.arena_count = flag + 1; a.arena_cap = MSD_ARENA;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 16, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
+    hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag);
+    uint32_t tiles2 = 0;
+    unsigned long long h_flag = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tiles2, tile_start + MSD_NB, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, flag, 8, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 2;
+    if (h_flag != 0 || tiles2 == 0) return FBG_OK;
+    hipLaunchKernelGGL(k_msd_split, dim3(tiles2), dim3(MSD_THREADS), 0, st, a);
+    // offsets of the sub-buckets in the sorted array: exclusive scan of their sizes
+    unsigned long long *wide = reinterpret_cast<unsigned long long *>(ctx->keysA.p);   // scratch: pass 1's slots are dead
+    hipLaunchKernelGGL(k_msd_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);
+    {
+        size_t bytes = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, bytes, wide, off, 0ull, (size_t)nsub, rocprim::plus<unsigned long long>(), st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim scan size query: %s", hipGetErrorString(e));
+        FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+        size_t have = ctx->tmp.cap;
+        e = rocprim::exclusive_scan(ctx->tmp.p, have, wide, off, 0ull, (size_t)nsub, rocprim::plus<unsigned long long>(), st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
+    }
+    const int fshift = g.pb + rest - fbits;
+    const uint32_t fmask = (uint32_t)((1u << fbits) - 1);
+    hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
+    unsigned long long h2[2] = {0, 0};
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 4;
+    if (h2[0] != 0) return FBG_OK;
+    if (h2[1] > 0) {
+        // a few sub-buckets were larger than their stretch (row ends pile up on keys that end in zeros): their
+        // overflow sits in the arena; sorted by sub-bucket, every run joins the MSD_FN_CAP slots that did fit
+        const uint32_t entries = (uint32_t)h2[1];
+        uint32_t *sb_sorted = a.arena_sb + MSD_ARENA;
+        uint64_t *w_sorted = a.arena_w + MSD_ARENA;
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, a.arena_sb, sb_sorted, a.arena_w, w_sorted, (size_t)entries, 0u, 32u, st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim sort size query: %s", hipGetErrorString(e));
+        FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+        size_t have = ctx->tmp.cap;
+        e = rocprim::radix_sort_pairs(ctx->tmp.p, have, a.arena_sb, sb_sorted, a.arena_w, w_sorted, (size_t)entries, 0u, 32u, st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_msd_finish_big, dim3(entries), dim3(MSD_BIG_THREADS), 0, st, a, sb_sorted, w_sorted, entries, fshift, fmask);
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        *launches += 2;
+        if (h2[0] != 0) return FBG_OK;
+    }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    *sorted = ctx->keysA.as<uint64_t>();
+    *ok = 1;
+    return FBG_OK;
+}

@@ -380,6 +380,8 @@ ALT_PATHS = [
     {"FBG_NO_PACKED": "1"},                          # rank-order scan on (key, position) pairs instead of packed words
     {"FBG_NO_PACKED": "1", "FBG_FULL_KEYS": "1"},
     {"FBG_FORCE_WIDE": "1"},                         # ... on wide pairs (the layout for texts beyond 2^32 symbols)
+    {"FBG_MSD_MIN": "1"},                            # three-pass MSD sort (msd_sort.hip) also for small texts
+    {"FBG_NO_MSD_SORT": "1"},                        # rocPRIM's onesweep instead of it
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
     {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
@@ -536,8 +538,8 @@ def test_partitioned_index_full_size():
             e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}],
-                         ids=["packed", "pairs", "wide", "nothreshold"])
+@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}, {"FBG_MSD_MIN": "1"}],
+                         ids=["packed", "pairs", "wide", "nothreshold", "msdsort"])
 def test_rank_scan_sampled_regime_matches_oracle(engine, env):
     """Texts above 2^22 symbols use the sampled threshold and regime test of the rank-order scan: f and v must
     still be the oracle's, for iid rows and for rows with shared stretches (ties, runs, short suffixes)."""
@@ -653,3 +655,42 @@ def test_partitioned_index_beyond_32bit_positions():
     finally:
         eng.close()
     assert G >= 2 and torch.equal(d_f, d_g)
+
+
+def test_msd_sort_gives_the_suffix_array(engine):
+    """The three-pass MSD sort (forced on a 1.2e6-symbol text): suffix array, inverse, LCPs and f equal the oracle's;
+    at C3 size the f it leads to equals the one reached through rocPRIM's sort."""
+    import os
+    import torch
+    rng = np.random.default_rng(123)
+    msa = random_msa(rng, 48, 24000)
+    T, SA, ISA, LCP = O.msa_index(msa)
+    os.environ["FBG_MSD_MIN"] = "1"
+    try:
+        engine.msa_load_host(msa)
+        engine.index_build()
+        gT, gSA, gISA, gPL, gPR = engine.index_download()
+        assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64))
+        lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
+        assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA])
+        assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))
+    finally:
+        del os.environ["FBG_MSD_MIN"]
+    m, n = 1000, 1_000_000
+    d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    engine.msa_synthetic(d.data_ptr(), m, n)
+    engine.msa_set_device(d.data_ptr(), m, n)
+    fs = []
+    for env in ({}, {"FBG_NO_MSD_SORT": "1"}):
+        os.environ.update(env)
+        try:
+            engine.index_build()
+            d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            engine.scan_f(0, n, d_f.data_ptr())
+            engine.sync()
+            fs.append(d_f)
+        finally:
+            for k in env:
+                del os.environ[k]
+    assert torch.equal(fs[0], fs[1])
