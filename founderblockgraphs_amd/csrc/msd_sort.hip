@@ -27,7 +27,7 @@
 #define MSD_THREADS 1024
 #define MSD_ITEMS 8
 #define MSD_TILE (MSD_THREADS * MSD_ITEMS)
-#define MSD_FN_THREADS 256
+#define MSD_FN_THREADS 512
 #define MSD_FN_CAP 4608                        // slots per sub-bucket (mean at 10^9 suffixes: 3815)
 #define MSD_FN_ITEMS (MSD_FN_CAP / MSD_FN_THREADS)
 #define MSD_FN_BITS 10
