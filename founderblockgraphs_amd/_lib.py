@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfbg_hip.so")
 
 FBG_OK, FBG_ERR_INVALID, FBG_ERR_NO_SEGMENTATION, FBG_ERR_OOM, FBG_ERR_HIP, FBG_ERR_TOO_LARGE, \
-    FBG_ERR_NO_DEVICE = range(7)
+    FBG_ERR_NO_DEVICE, FBG_ERR_HASH_COLLISION = range(8)
 PART_HALO = 64                               # FBG_PART_HALO (include/fbg_hip.h)
 PART_HALO_BYTES = 2 * PART_HALO * 12 + 16    # FBG_PART_HALO_BYTES
 STAGES = ("text", "suffix_sort", "lcp", "rank_scan", "scan", "dp", "rank_kernel")
@@ -41,6 +41,7 @@ SIGNATURES = {
     "fbg_part_index_build": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]),
     "fbg_part_scan": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int)]),
     "fbg_part_finish": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+    "fbg_block_graph": (C.c_int, [vp, u64p, C.c_uint64, u32p, u64p, u32p, u64p, u64p]),
     "fbg_scan_f": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp]),
     "fbg_scan_v": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
     "fbg_minmax_dp_device": (C.c_int, [vp, vp, C.c_uint64, vp, u64p, vp, vp]),

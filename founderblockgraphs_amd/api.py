@@ -87,6 +87,7 @@ class Engine:
         """compute_f: f is max-merged into (zeros if omitted), as fbg.cpp:1681 / 3388."""
         msa = as_msa(msa)
         m, n = msa.shape
+        self._msa_rows = m
         ig, il = _ignore(ignorechars)
         f = np.zeros(n, dtype=np.uint64) if f is None else np.ascontiguousarray(f, dtype=np.uint64).copy()
         rc = self._L.fbg_elastic_f(self._h, _u8(msa), m, n, _u8(ig), il, int(disable_efg_tricks), _u64(f))
@@ -127,12 +128,29 @@ class Engine:
         self._chk(rc)
         return s, prev, b[:cnt.value].copy()
 
+    def block_graph(self, boundaries):
+        """Nodes / edges of the elastic founder graph for a segmentation of the current MSA (fbg_block_graph):
+        (node_of[nb, m], first_node[nb + 1], rep_row[nb, m], edge_count[nb], edges[nb, m])."""
+        b = np.ascontiguousarray(boundaries, dtype=np.uint64)
+        nb = len(b)
+        m = self._msa_rows
+        node_of = np.empty((nb, m), dtype=np.uint32)
+        rep_row = np.empty((nb, m), dtype=np.uint32)
+        first = np.empty(nb + 1, dtype=np.uint64)
+        ecount = np.empty(nb, dtype=np.uint64)
+        edges = np.empty((nb, m), dtype=np.uint64)
+        self._chk(self._L.fbg_block_graph(self._h, _u64(b), nb, node_of.ctypes.data_as(_lib.u32p), _u64(first),
+                                          rep_row.ctypes.data_as(_lib.u32p), _u64(ecount), _u64(edges)))
+        return node_of, first, rep_row, ecount, edges
+
     # ---- device-resident staged API ------------------------------------------------------
     def msa_load_host(self, msa):
         msa = as_msa(msa)
+        self._msa_rows = msa.shape[0]
         self._chk(self._L.fbg_msa_load_host(self._h, _u8(msa), msa.shape[0], msa.shape[1]))
 
     def msa_set_device(self, ptr, m, n):
+        self._msa_rows = m
         self._chk(self._L.fbg_msa_set_device(self._h, C.c_void_p(ptr), m, n))
 
     def msa_synthetic(self, ptr, m, n, seed=0x5EED0001, seed2=0x5EED0002, gap_fraction=0.0, gap_run=0,

@@ -130,6 +130,17 @@ int main(int argc, char **argv)
         fbg_ctx_destroy(ctx);
         return EXIT_FAILURE;
     }
+    // nodes and edges of the graph come from the engine too (fbg_block_graph); ask before it goes away
+    BlockGraph graph;
+    bool have_graph = false;
+    if (opt.elastic) {
+        const uint64_t cells = msa.m * boundaries.size();
+        graph.node_of.resize(cells); graph.rep_row.resize(cells); graph.edges.resize(cells);
+        graph.first_node.resize(boundaries.size() + 1); graph.edge_count.resize(boundaries.size());
+        rc = fbg_block_graph(ctx, boundaries.data(), boundaries.size(), graph.node_of.data(), graph.first_node.data(),
+                             graph.rep_row.data(), graph.edge_count.data(), graph.edges.data());
+        have_graph = rc == FBG_OK;          // otherwise (a hash collision, an input beyond its limits): hash on the host
+    }
     fbg_ctx_destroy(ctx);
 
     if (!opt.elastic) {
@@ -144,7 +155,9 @@ int main(int argc, char **argv)
 
     std::cerr << "Writing the xGFA to disk\xe2\x80\xa6\n";                                                   // 3502
     std::string error;
-    if (!write_xgfa(msa, boundaries, opt.output_paths, opt.output, error)) {
+    const bool written = have_graph ? write_xgfa_graph(msa, boundaries, graph, opt.output_paths, opt.output, error)
+                                    : write_xgfa(msa, boundaries, opt.output_paths, opt.output, error);
+    if (!written) {
         // the reference lets std::ios_base::failure escape (fbg.cpp:1197) or trips an assert: it aborts
         std::cerr << "ERROR: " << error << std::endl;
         std::abort();

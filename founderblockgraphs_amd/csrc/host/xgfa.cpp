@@ -145,6 +145,66 @@ bool write_xgfa(const Msa &msa, const std::vector<uint64_t> &boundaries, bool ou
     return ok;
 }
 
+bool write_xgfa_graph(const Msa &msa, const std::vector<uint64_t> &boundaries, const BlockGraph &g, bool output_paths,
+                      const std::string &path, std::string &error)
+{
+    FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp) { error = "cannot open " + path + " for writing"; return false; }
+    Writer w(fp);
+    const uint64_t m = msa.m, n = msa.n, nb = boundaries.size();
+    w.str("M\t"); w.num(m); w.str("\t"); w.num(n); w.str("\n");                     // fbg.cpp:1201
+    w.str("X\t1");                                                                 // 1204-1207
+    for (uint64_t i = 0; i + 1 < nb; i++) { w.str("\t"); w.num(boundaries[i] + 2); }
+    w.str("\n");
+    w.str("B\t");                                                                  // 1210-1220
+    for (uint64_t j = 0; j < nb; j++) { if (j) w.str("\t"); w.num(g.first_node[j + 1] - g.first_node[j]); }
+    w.str("\n");
+    std::vector<char> label;
+    uint64_t prev = 0;
+    for (uint64_t j = 0; j < nb; prev = boundaries[j] + 1, j++) {                  // 1224-1260
+        const uint64_t stop = std::min(boundaries[j] + 1, n);
+        const uint64_t cnt = g.first_node[j + 1] - g.first_node[j];
+        for (uint64_t k = 0; k < cnt; k++) {
+            const uint8_t *row = msa.cells.data() + (uint64_t)g.rep_row[j * m + k] * n;
+            label.clear();
+            for (uint64_t x = prev; x < stop; x++)
+                if (row[x] != '-') label.push_back((char)row[x]);
+            w.str("S\t"); w.num(g.first_node[j] + k); w.str("\t"); w.raw(label.data(), label.size()); w.str("\n");   // 1241
+        }
+        for (uint64_t e = 0; e < g.edge_count[j]; e++) {                            // 1253-1255
+            const uint64_t pr = g.edges[j * m + e];
+            w.str("L\t"); w.num(pr >> 32); w.str("\t+\t"); w.num(pr & 0xffffffffu); w.str("\t+\t0M\n");
+        }
+    }
+    if (output_paths) {                                                                                 // 1291-1300
+        if (msa.identifiers.size() != m) {
+            error = "number of FASTA headers differs from the number of rows kept (the reference asserts here, "
+                    "fbg.cpp:1292)";
+            std::fclose(fp);
+            return false;
+        }
+        std::vector<uint32_t> path_ids;
+        for (uint64_t i = 0; i < m; i++) {
+            path_ids.clear();
+            for (uint64_t j = 0; j < nb; j++)
+                if (g.node_of[j * m + i] != 0xffffffffu) path_ids.push_back(g.node_of[j * m + i]);
+            if (path_ids.empty()) {
+                error = "row " + std::to_string(i) + " has no non-gap character; its P line is undefined in the "
+                        "reference (fbg.cpp:1295)";
+                std::fclose(fp);
+                return false;
+            }
+            w.str("P\t"); w.raw(msa.identifiers[i].data(), msa.identifiers[i].size()); w.str("\t");
+            for (size_t k = 0; k + 1 < path_ids.size(); k++) { w.num(path_ids[k]); w.str("+,"); }
+            w.num(path_ids.back()); w.str("+"); w.str("\t*\n");
+        }
+    }
+    w.flush();
+    const bool ok = w.ok && std::fclose(fp) == 0;
+    if (!ok) error = "write to " + path + " failed";
+    return ok;
+}
+
 GraphStats segment_stats(const Msa &msa, const std::vector<uint64_t> &boundaries)
 {
     // fbg.cpp:667-728: labels deduplicated globally; blocks[j] holds only the nodes first seen in block j

@@ -10,5 +10,15 @@
 bool write_xgfa(const Msa &msa, const std::vector<uint64_t> &boundaries, bool output_paths,
                 const std::string &path, std::string &error);
 
+// The same bytes from the node / edge arrays of fbg_block_graph (include/fbg_hip.h): nothing is hashed here, the
+// labels of the S lines are cut out of the representative rows.
+struct BlockGraph {
+    std::vector<uint32_t> node_of, rep_row;     // [nb * m]
+    std::vector<uint64_t> first_node;           // [nb + 1]
+    std::vector<uint64_t> edge_count, edges;    // [nb], [nb * m]
+};
+bool write_xgfa_graph(const Msa &msa, const std::vector<uint64_t> &boundaries, const BlockGraph &g, bool output_paths,
+                      const std::string &path, std::string &error);
+
 struct GraphStats { uint64_t nodes = 0, total_label_length = 0, founders = 0, edges = 0; };
 GraphStats segment_stats(const Msa &msa, const std::vector<uint64_t> &boundaries);

@@ -39,7 +39,8 @@ enum {
     FBG_ERR_OOM = 3,
     FBG_ERR_HIP = 4,             /* a HIP runtime call or kernel failed; see fbg_last_error */
     FBG_ERR_TOO_LARGE = 5,
-    FBG_ERR_NO_DEVICE = 6
+    FBG_ERR_NO_DEVICE = 6,
+    FBG_ERR_HASH_COLLISION = 7   /* fbg_block_graph only: use the caller's own label numbering instead */
 };
 
 #define FBG_MAX_ROWS 4096   /* scan kernel: one workgroup holds a whole column in LDS */
@@ -170,6 +171,22 @@ int fbg_minmax_dp_device(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t
                          uint64_t *count_out, uint64_t *d_mml, uint64_t *d_bt);
 int fbg_repeatfree_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
                              uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out);
+/*
+ * Nodes and edges of the elastic founder graph for a segmentation of the current MSA (the one last given to
+ * fbg_elastic_f / fbg_msa_load_host / fbg_msa_set_device): what output_efg computes by hashing the gap-stripped
+ * label of every (row, block) twice (fbg.cpp:1210-1260).  boundaries[nb] as produced by fbg_minmax_dp (block j covers
+ * columns boundaries[j-1]+1 .. boundaries[j], the last entry is n).  All outputs are host buffers:
+ *   node_of[j*m + i]     node of row i in block j in the reference's numbering (blocks in order, within a block by
+ *                        first appearance in row order, fbg.cpp:1232-1246); 0xffffffff = the row has only gaps there
+ *   first_node[nb + 1]   first node of every block; first_node[j+1] - first_node[j] = entry j of the B line
+ *   rep_row[j*m + k]     the row whose label defines node first_node[j] + k (its S line)
+ *   edge_count[nb], edges[j*m + e]   the L lines into block j: src << 32 | dst, ascending (std::set order,
+ *                        fbg.cpp:1230,1253), e < edge_count[j]; edge_count[0] = 0
+ * Exact: rows grouped by a 128-bit hash are compared byte by byte with their group's first row; should two different
+ * labels ever collide the call returns FBG_ERR_HASH_COLLISION and the caller numbers the labels itself.
+ */
+int fbg_block_graph(fbg_ctx *ctx, const uint64_t *boundaries, uint64_t nb, uint32_t *node_of, uint64_t *first_node,
+                    uint32_t *rep_row, uint64_t *edge_count, uint64_t *edges);
 /* Copy out index arrays for tests: any pointer may be NULL. Host buffers of N entries
  * (N from fbg_text_length). SA / ISA / LCP-with-predecessor / LCP-with-successor by text position. */
 uint64_t fbg_text_length(const fbg_ctx *ctx);

@@ -694,3 +694,53 @@ def test_msd_sort_gives_the_suffix_array(engine):
             for k in env:
                 del os.environ[k]
     assert torch.equal(fs[0], fs[1])
+
+
+def _block_graph_reference(msa, boundaries):
+    """output_efg's numbering (fbg.cpp:1224-1260) with plain Python dicts: node_of, first_node, rep_row, edges."""
+    m, n = msa.shape
+    nb = len(boundaries)
+    node_of = np.full((nb, m), 0xffffffff, dtype=np.uint32)
+    first = np.zeros(nb + 1, dtype=np.uint64)
+    reps, edges = [], []
+    nodecount, prev = 0, 0
+    for j, end in enumerate(boundaries):
+        cur, r, e = {}, [], set()
+        for i in range(m):
+            lab = bytes(c for c in msa[i, prev:min(int(end) + 1, n)] if c != ord("-"))
+            if not lab:
+                continue
+            if lab not in cur:
+                cur[lab] = nodecount
+                nodecount += 1
+                r.append(i)
+            node_of[j, i] = cur[lab]
+            if j > 0 and node_of[j - 1, i] != 0xffffffff:
+                e.add((int(node_of[j - 1, i]), cur[lab]))
+        first[j + 1] = nodecount
+        reps.append(r)
+        edges.append(sorted(e))
+        prev = int(end) + 1
+    return node_of, first, reps, edges
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_block_graph_matches_reference_numbering(engine, case):
+    """fbg_block_graph (nodes / edges of the xGFA) against the reference's hashing restated with dicts."""
+    rng = np.random.default_rng(900 + case)
+    m, n, kw = [(5, 60, {}), (40, 500, dict(similar=0.97)), (64, 300, dict(similar=0.9, gap_p=0.05, gap_run=6)),
+                (257, 200, dict(similar=0.99, gap_p=0.02, gap_run=30)), (1000, 150, dict(similar=0.98)),
+                (3, 40, dict(gap_p=0.3, gap_run=10))][case]
+    msa = random_msa(rng, m, n, **kw)
+    cuts = np.sort(rng.choice(np.arange(0, n - 1), size=min(n // 4, 40), replace=False)).astype(np.uint64)
+    boundaries = np.concatenate([cuts, [n]]).astype(np.uint64)           # last entry is n (fbg.cpp:2026-2039)
+    engine.msa_load_host(msa)
+    node_of, first, rep_row, ecount, edges = engine.block_graph(boundaries)
+    r_node, r_first, r_reps, r_edges = _block_graph_reference(msa, boundaries)
+    assert np.array_equal(first, r_first)
+    assert np.array_equal(node_of, r_node)
+    for j in range(len(boundaries)):
+        cnt = int(first[j + 1] - first[j])
+        assert list(rep_row[j, :cnt]) == r_reps[j]
+        got = [(int(x) >> 32, int(x) & 0xffffffff) for x in edges[j, :int(ecount[j])]]
+        assert got == r_edges[j], j
