@@ -5,7 +5,8 @@ python - <<'PY'
 import numpy as np, time, sys
 sys.path.insert(0,'.')
 from bench import synth_msa_host
-m,n=1000,200000
+import os
+m,n=1000,int(os.environ.get('E2E_COLS','200000'))
 a=synth_msa_host(m,n,n)
 t=time.time()
 with open('/tmp/c3s.fasta','wb') as fh:
@@ -13,4 +14,4 @@ with open('/tmp/c3s.fasta','wb') as fh:
         fh.write(b'>r%d\n'%i); fh.write(a[i].tobytes()); fh.write(b'\n')
 print('fasta written', time.time()-t, a.shape)
 PY
-S=$(date +%s.%N); ./founderblockgraphs_amd/founderblockgraph --input /tmp/c3s.fasta --output /tmp/c3s.xgfa --elastic --gfa -p 2> gpurun_out/cli_e2e.log; E=$(date +%s.%N); echo wall $(echo "$E - $S" | bc); tail -25 gpurun_out/cli_e2e.log | grep -E "Time taken|Elapsed|Maximum resident|Input MSA|optimal"; ls -la /tmp/c3s.xgfa; head -c 300 /tmp/c3s.xgfa | head -3 | cut -c1-100
+S=$(date +%s.%N); ./founderblockgraphs_amd/founderblockgraph --input /tmp/c3s.fasta --output /tmp/c3s.xgfa --elastic --gfa -p 2> gpurun_out/cli_e2e.log; E=$(date +%s.%N); python3 -c "print('wall seconds', $E - $S)"; tail -25 gpurun_out/cli_e2e.log | grep -E "Time taken|Elapsed|Maximum resident|Input MSA|optimal"; ls -la /tmp/c3s.xgfa; head -c 300 /tmp/c3s.xgfa | head -3 | cut -c1-100
