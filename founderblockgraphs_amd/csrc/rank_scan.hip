@@ -522,11 +522,15 @@ __global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__
     }
 }
 
-// columns that received no value although they have rows: the threshold g_min was too optimistic for them
-__global__ void k_count_unfilled(const uint32_t *__restrict__ gmax, uint64_t n, unsigned long long *__restrict__ counters)
+// columns whose maximum stayed below the threshold: extensions that were skipped for being smaller than g_min may
+// exceed it -- the threshold was too optimistic for them (a maximum of g_min or more cannot be beaten by a skipped one)
+__global__ void k_count_unfilled(const uint32_t *__restrict__ gmax, uint64_t n, uint32_t g_min, int reversed,
+                                 unsigned long long *__restrict__ counters)
 {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool miss = x < n && gmax[x] == 0;
+    // the 64 columns nearest the row end (in text order) are never thresholded (k_rank_scan: rem <= 64)
+    const uint64_t rem = reversed ? x + 1 : n - x;
+    const bool miss = x < n && rem > 64 && gmax[x] < g_min;
     const unsigned long long mask = __ballot(miss);
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&counters[1 + 3], (unsigned long long)__popcll(mask));   // counters[4]
 }
@@ -898,6 +902,9 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
                 above += hh[g];
                 if ((double)above >= need) { a.g_min = (uint32_t)g; break; }
             }
+            // suffixes that tie on the whole key extend by K + 1 at least, more than any that does not tie: where
+            // every column can expect dozens of them nothing else can be a column maximum
+            if ((double)hs[2] / (double)hs[3] * (double)m >= 32.0) a.g_min = (uint32_t)geom.K + 1;
         }
     }
     uint64_t T = 0;
@@ -911,7 +918,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     // a large tie group / an overflowing tie region -> record path; a column without a value lost all its rows
     // to the threshold -> redo without it
     if (a.g_min > 1)
-        hipLaunchKernelGGL(k_count_unfilled, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.gmax, n, cnt);
+        hipLaunchKernelGGL(k_count_unfilled, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.gmax, n, a.g_min, a.reversed, cnt);
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     launches++;
