@@ -75,8 +75,7 @@ def cpu_baseline(m, n_total, sample_cols):
 
 def measured_traffic(m, n, kernel):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected as
-    MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units; the gfx950 FETCH_SIZE doubling applies to
-    16-B-per-lane streams only, see the note in the JSON); None when no pass exists for this workload / kernel."""
+    MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled on gfx950; cross-check in the JSON); None when no pass exists for this workload / kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_kernels.json")) as fh:
             d = json.load(fh)
@@ -254,7 +253,7 @@ def main():
                          "traffic": measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
                          if world == 1 else None,
                          "traffic_source": "profiles/r01_pmc_scan_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                           "passes; 8-B-per-lane loads: raw FETCH_SIZE, which equals one read of every slot)",
+                                           "passes, FETCH_SIZE doubled as the guide prescribes for gfx950: equals one read of every slot)",
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "device_bytes": eng.device_bytes(),
