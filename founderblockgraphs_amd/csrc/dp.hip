@@ -671,22 +671,29 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned long long), st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(bstart, 0, w, st));
     hipLaunchKernelGGL(k_dp_keys, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, d_f, n, e, bstart, sc + 2);
-    {   // exclusive scan of the histogram over keys 0..n+1 -> bucket starts
+    // the bucket order of fbg.cpp:1941-1953 (counting sort of x by f[x]+1): only the wave-parallel and the literal sweep
+    // read it -- built when one of them is about to run
+    bool buckets_ready = false;
+    auto build_buckets = [&]() -> int {
+        if (buckets_ready) return FBG_OK;
         size_t bytes = 0;
         hipError_t er = rocprim::exclusive_scan(nullptr, bytes, bstart, bstart, 0u, (size_t)(n + 2), rocprim::plus<uint32_t>(), st);
         if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim scan size query failed");
+        // ctx->tmp may hold the block matrices of an abandoned attempt: they are dead by now
         FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
         size_t have = ctx->tmp.cap;
         er = rocprim::exclusive_scan(ctx->tmp.p, have, bstart, bstart, 0u, (size_t)(n + 2), rocprim::plus<uint32_t>(), st);
         if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(er));
-    }
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(cur, bstart, w, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_dp_scatter, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, e, n, cur, items);
-    FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(cur, 0xff, w, st));   // thead = DP_NONE
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(cur, bstart, w, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_dp_scatter, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, e, n, cur, items);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(cur, 0xff, w, st));   // thead = DP_NONE
+        buckets_ready = true;
+        return FBG_OK;
+    };
     // which sweep: the wave-parallel one needs f[0] == 0 and a bounded block length
     unsigned long long hk[5];
     uint64_t f0 = 1;
@@ -751,16 +758,9 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                 settled = hk[4] == 0;
             }
             tiled = settled;
-            if (!settled) {
-                // ext7 / clen live in count / bcount: the bucket sweeps below want those zeroed again
-                FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
-                FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
-                FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
-                FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
-                FBG_HIP_TRY(ctx, hipMemsetAsync(bt, 0, w, st));
-                FBG_HIP_TRY(ctx, hipMemsetAsync(cur, 0xff, w, st));
-            }
+            if (!settled) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
         }
+        if (!settled) FBG_TRY(build_buckets());        // also zeroes what the abandoned attempts left in count / bcount / mml / bt
         if (!settled && (R > 4 || getenv("FBG_DP_WAVE"))) {
             switch (R) {
             case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
@@ -776,6 +776,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         if (!settled) literal = true;   // guards tripped: the literal sweep
     }
     if (literal) {
+        FBG_TRY(build_buckets());
         FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
         FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));
         FBG_HIP_TRY(ctx, hipMemsetAsync(mml, 0, w, st));
