@@ -69,6 +69,7 @@ struct fbg_ctx {
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tie_list, big_groups, tmp, small, scalars;
+    DevBuf msd_w, msd_v;       // sub-bucket stretches of the MSD sort of 12-byte slots (msd_sort_pairs.hip)
     DevBuf dp_a, dp_b, dp_c, dp_d, dp_e, dp_f, dp_g, dp_h, io_a, io_b, io_c, io_d;
     DevBuf bt_up, bt_dep;      // binary-lifting tables of the parallel backtrack
 
@@ -123,7 +124,9 @@ int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_
                            uint8_t *d_blob, int *ok);                         // rank_scan.hip
 int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok);
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
-int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip                        // suffix_sort.hip
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip
+int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
+                      uint64_t *count, int *ok, int *launches);                                       // msd_sort_pairs.hip                        // suffix_sort.hip
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
                      uint64_t *d_out);                                        // scan.hip
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,

@@ -20,19 +20,18 @@
 // here, see sample_says_similar); a bucket or sub-bucket that overflows raises a flag and the caller sorts with
 // rocPRIM instead (suffix_sort.hip).  Equal keys end up in position order.
 #include "fbg_internal.h"
+#include "msd_keys.h"
 #include <rocprim/rocprim.hpp>
 
 #define MSD_DIG 9
 #define MSD_NB (1 << MSD_DIG)
 #define MSD_THREADS 1024
-#define MSD_ITEMS 8
 #define MSD_TILE (MSD_THREADS * MSD_ITEMS)
 #define MSD_FN_THREADS 512
 #define MSD_FN_CAP 4608                        // slots per sub-bucket (mean at 10^9 suffixes: 3815)
 #define MSD_FN_ITEMS (MSD_FN_CAP / MSD_FN_THREADS)
 #define MSD_FN_BITS 10
 #define MSD_FN_BINS (1 << MSD_FN_BITS)
-#define MSD_SEP 0x80                           // FBG_SEP of suffix_sort.hip
 #define MSD_BIG_THREADS 1024
 #define MSD_BIG_CAP 16384                      // largest sub-bucket (k_msd_finish_big)
 #define MSD_ARENA (1u << 20)
@@ -93,80 +92,12 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
     if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * MSD_TILE;
-    {   // symbol codes of the tile: 8 text bytes per thread and load (T is padded beyond N; base is a multiple of 8)
-        const int k8 = threadIdx.x * 8;
-        const uint64_t p = base + k8;
-        const uint64_t raw = p < a.N + 56 ? *reinterpret_cast<const uint64_t *>(a.T + p) : 0ull;
-        uint64_t codes = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t c = p + j < a.N ? cd[(raw >> (8 * j)) & 255u] : (uint32_t)MSD_SEP;
-            codes |= (uint64_t)c << (8 * j);
-        }
-        *reinterpret_cast<uint64_t *>(tile + k8) = codes;
-        if (threadIdx.x < 8) {                                  // the 64 bytes of lookahead
-            const int kk = MSD_TILE + threadIdx.x * 8;
-            const uint64_t q = base + kk;
-            const uint64_t raw2 = q < a.N + 56 ? *reinterpret_cast<const uint64_t *>(a.T + q) : 0ull;
-            uint64_t codes2 = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t c = q + j < a.N ? cd[(raw2 >> (8 * j)) & 255u] : (uint32_t)MSD_SEP;
-                codes2 |= (uint64_t)c << (8 * j);
-            }
-            *reinterpret_cast<uint64_t *>(tile + kk) = codes2;
-        }
-    }
+    msd_load_tile<MSD_TILE>(tile, cd, a.T, a.N, base);
     __syncthreads();
     // keys of the thread's MSD_ITEMS consecutive positions
     const int t0 = threadIdx.x * MSD_ITEMS;
     uint64_t w[MSD_ITEMS];
-    bool slow = true;
-    if (b == 2 && K + MSD_ITEMS - 1 <= 32) {
-        // 2-bit symbols: the thread's 32 symbols packed into one word (two multiplies per 8 bytes gather the low
-        // two bits of every byte), every key a shift of it
-        uint64_t P = 0, any = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint64_t x = *reinterpret_cast<const uint64_t *>(tile + t0 + 8 * q);
-            any |= x;
-            const uint32_t lo = (uint32_t)x & 0x03030303u, hi = (uint32_t)(x >> 32) & 0x03030303u;
-            const uint32_t g = (((lo * 0x40100401u) >> 24) << 8) | ((hi * 0x40100401u) >> 24);    // 8 symbols, first one on top
-            P |= (uint64_t)g << (48 - 16 * q);
-        }
-        slow = (any & 0x8080808080808080ull) != 0;              // a separator among the 32 symbols
-#pragma unroll
-        for (int i = 0; i < MSD_ITEMS; i++) w[i] = (P << (2 * i)) >> (64 - 2 * K);
-    }
-    if (b != 2 || K + MSD_ITEMS - 1 > 32) {
-        // general alphabet: rolling, one LDS byte per position (k_pack)
-        const uint64_t mask = (K * b) >= 64 ? ~0ull : ((1ull << (K * b)) - 1);
-        uint64_t key = 0;
-        uint32_t seen = 0;
-        for (int k = 0; k < K; k++) { const uint32_t c = tile[t0 + k]; seen |= c; key = (key << b) | c; }
-#pragma unroll
-        for (int i = 0; i < MSD_ITEMS; i++) {
-            w[i] = key;
-            const uint32_t c = tile[t0 + K + i];
-            seen |= c;
-            key = ((key << b) | c) & mask;
-        }
-        slow = (seen & MSD_SEP) != 0;
-    }
-    if (slow) {
-        // a row ends nearby: symbol by symbol; a separator and all behind it count as 0 (k_pack)
-#pragma unroll
-        for (int i = 0; i < MSD_ITEMS; i++) {
-            uint64_t kk = 0;
-            bool dead = false;
-            for (int k = 0; k < K; k++) {
-                const uint32_t c = tile[t0 + i + k];
-                dead = dead || (c & MSD_SEP);
-                kk = (kk << b) | (dead ? 0u : c);
-            }
-            w[i] = kk;
-        }
-    }
+    msd_build_keys(tile, t0, b, K, w);
     __syncthreads();                                            // the byte tile is done with: buf is free
     uint32_t rk[MSD_ITEMS];
     const int dshift = a.kb - MSD_DIG;

@@ -1,0 +1,440 @@
+// msd_sort_pairs.hip -- the three-pass MSD sort (msd_sort.hip) for the partitioned index: 12-byte slots
+// (key word u64 + low position word u32; pairs / wide layouts) and only the suffixes whose key lies in this
+// partition's range [lo, hi).
+//
+// Buckets cannot be bit fields of the key here (the range is arbitrary): t = floor((key - lo) * 2^27 / (hi - lo)),
+// one 64x64->128 multiply, is monotone in the key, and its three 9-bit digits serve as bucket, sub-bucket and finish
+// bin.  Pass 1 is fused with key packing and filtering: a workgroup walks as many 4096-position tiles as there are
+// partitions, so that it collects about 4096 slots of its range before it regroups and writes them.  Passes 2 and 3
+// are those of msd_sort.hip with a second array riding along.  Capacities are optimistic in the same way; a flag
+// sends the caller back to k_pack<FILTER> + rocPRIM.
+#include "fbg_internal.h"
+#include "msd_keys.h"
+#include <rocprim/rocprim.hpp>
+
+#define PP_NB 512
+#define PP_THREADS 512
+#define PP_TILE (PP_THREADS * MSD_ITEMS)       // text positions per sub-tile of pass 1, slots per tile of pass 2
+#define PP_STAGE 4608                          // slots a workgroup of pass 1 collects (expected 4096)
+#define PP_FN_CAP 4608                         // slots per sub-bucket
+#define PP_ITEMS (PP_FN_CAP / PP_THREADS)
+#define PP_BIG_CAP 9216                        // largest sub-bucket (k_pp_finish_big)
+#define PP_ARENA (1u << 20)
+
+struct PpArgs {
+    const uint8_t *T;
+    uint64_t N;
+    const uint8_t *code;
+    int b, K, pb, nparts;
+    int wide;                                  // key word = key << pb | position >> 32 (else the plain key, pb = 0)
+    uint64_t lo, hi, mul;                      // key range (hi ignored when nohi), t = umul64hi(key - lo, mul) < 2^27
+    int nohi;
+    uint64_t *w1; uint32_t *v1; uint64_t cap1; unsigned long long *count1;      // pass 1 output: PP_NB stretches
+    const uint32_t *tile_start;
+    uint64_t *w2; uint32_t *v2; uint32_t *count2;                               // pass 2 output: PP_NB^2 stretches of PP_FN_CAP
+    const unsigned long long *off;
+    uint64_t *wout; uint32_t *vout;
+    uint32_t *arena_sb; uint64_t *arena_w; uint32_t *arena_v; unsigned long long *arena_count;
+    unsigned long long *flag;
+};
+
+__device__ __forceinline__ uint32_t pp_t27(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
+
+// scan of PP_NB counts (one per thread) + run reservation, as msd_scan_and_reserve
+__device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *loff, unsigned long long *gbase, uint32_t *wsum,
+                                                    unsigned long long *cursor64, uint32_t *cursor32)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t c = cnt[threadIdx.x];                       // PP_THREADS == PP_NB
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+    loff[threadIdx.x] = pre + inc - c;
+    unsigned long long g = 0;
+    if (c) g = cursor64 ? atomicAdd(cursor64 + threadIdx.x, (unsigned long long)c) : (unsigned long long)atomicAdd(cursor32 + threadIdx.x, c);
+    gbase[threadIdx.x] = g;
+    __syncthreads();
+}
+
+// `have` slots sitting in (sw, sv) in any order -> regrouped by digit d(word) in place (through registers), counts in
+// cnt (zeroed by the caller), offsets in loff
+template <int CAP, class Digit>
+__device__ __forceinline__ void pp_regroup(uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t have, Digit digit, uint64_t *w, uint32_t *v,
+                                           uint32_t *rk)
+{
+    constexpr int ITEMS = CAP / PP_THREADS;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        w[r] = j < have ? sw[j] : ~0ull;
+        v[r] = j < have ? sv[j] : 0u;
+        rk[r] = j < have ? atomicAdd(&cnt[digit(w[r])], 1u) : 0u;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
+{
+    __shared__ uint64_t sw[PP_STAGE];
+    __shared__ uint32_t sv[PP_STAGE];
+    __shared__ uint8_t tile[PP_TILE + 64];
+    __shared__ uint8_t cd[256];
+    __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
+    __shared__ unsigned long long gbase[PP_NB];
+    __shared__ uint32_t wsum[PP_THREADS / 64];
+    __shared__ uint32_t staged;
+    if (threadIdx.x < 256) cd[threadIdx.x] = a.code[threadIdx.x];
+    cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) staged = 0;
+    const int lane = threadIdx.x & 63;
+    for (int sub = 0; sub < a.nparts; sub++) {
+        const uint64_t base = ((uint64_t)blockIdx.x * a.nparts + sub) * PP_TILE;
+        __syncthreads();                                        // the tile of the previous round is done with
+        if (base >= a.N) continue;                              // uniform
+        msd_load_tile<PP_TILE>(tile, cd, a.T, a.N, base);
+        __syncthreads();
+        uint64_t key[MSD_ITEMS];
+        msd_build_keys(tile, threadIdx.x * MSD_ITEMS, a.b, a.K, key);
+#pragma unroll
+        for (int i = 0; i < MSD_ITEMS; i++) {
+            const uint64_t p = base + (uint64_t)threadIdx.x * MSD_ITEMS + i;
+            const bool keep = p < a.N && key[i] >= a.lo && (a.nohi || key[i] < a.hi);
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                uint32_t at = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) at = atomicAdd(&staged, (uint32_t)__popcll(m));
+                at = __shfl(at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (keep) {
+                    if (at < PP_STAGE) { sw[at] = a.wide ? (key[i] << a.pb) | (p >> 32) : key[i]; sv[at] = (uint32_t)p; }
+                    else *a.flag = 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t have = min(staged, (uint32_t)PP_STAGE);
+    uint64_t w[PP_STAGE / PP_THREADS];
+    uint32_t v[PP_STAGE / PP_THREADS], rk[PP_STAGE / PP_THREADS];
+    pp_regroup<PP_STAGE>(sw, sv, cnt, have, [&](uint64_t x) { return pp_t27(a, x) >> 18; }, w, v, rk);
+    pp_scan_and_reserve(cnt, loff, gbase, wsum, a.count1, nullptr);
+#pragma unroll
+    for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) { const uint32_t at = loff[pp_t27(a, w[r]) >> 18] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) {
+            const uint64_t x = sw[j];
+            const uint32_t d = pp_t27(a, x) >> 18;
+            const uint64_t at = gbase[d] + (j - loff[d]);
+            if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
+            else *a.flag = 1;
+        }
+    }
+}
+
+__global__ void k_pp_tiles(const unsigned long long *__restrict__ count1, uint64_t cap1, uint32_t *__restrict__ tile_start,
+                           unsigned long long *__restrict__ total, unsigned long long *__restrict__ flag)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t t = 0;
+    unsigned long long sum = 0;
+    for (int s = 0; s < PP_NB; s++) {
+        tile_start[s] = t;
+        if (count1[s] > cap1) *flag = 1;
+        const unsigned long long c = count1[s] < cap1 ? count1[s] : cap1;
+        sum += c;
+        t += (uint32_t)((c + PP_TILE - 1) / PP_TILE);
+    }
+    tile_start[PP_NB] = t;
+    *total = sum;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
+{
+    __shared__ uint64_t sw[PP_TILE];
+    __shared__ uint32_t sv[PP_TILE];
+    __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
+    __shared__ unsigned long long gbase[PP_NB];
+    __shared__ uint32_t wsum[PP_THREADS / 64];
+    uint32_t lo = 0, hi = PP_NB;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (a.tile_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t seg = lo;
+    const uint64_t segn = min((uint64_t)a.count1[seg], a.cap1);
+    const uint64_t first = (uint64_t)(blockIdx.x - a.tile_start[seg]) * PP_TILE;
+    const uint32_t have = (uint32_t)min((uint64_t)PP_TILE, segn - first);
+    const uint64_t *inw = a.w1 + (uint64_t)seg * a.cap1 + first;
+    const uint32_t *inv = a.v1 + (uint64_t)seg * a.cap1 + first;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t w[MSD_ITEMS];
+    uint32_t v[MSD_ITEMS], rk[MSD_ITEMS];
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        w[r] = j < have ? inw[j] : 0ull;
+        v[r] = j < have ? inv[j] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        rk[r] = j < have ? atomicAdd(&cnt[(pp_t27(a, w[r]) >> 9) & (PP_NB - 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    pp_scan_and_reserve(cnt, loff, gbase, wsum, nullptr, a.count2 + (size_t)seg * PP_NB);
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) { const uint32_t at = loff[(pp_t27(a, w[r]) >> 9) & (PP_NB - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) {
+            const uint64_t x = sw[j];
+            const uint32_t d = (pp_t27(a, x) >> 9) & (PP_NB - 1);
+            const uint64_t at = gbase[d] + (j - loff[d]);
+            const uint64_t sb = (uint64_t)seg * PP_NB + d;
+            if (at < PP_FN_CAP) { a.w2[sb * PP_FN_CAP + at] = x; a.v2[sb * PP_FN_CAP + at] = sv[j]; }
+            else {
+                const unsigned long long e = atomicAdd(a.arena_count, 1ull);
+                if (e < PP_ARENA) { a.arena_sb[e] = (uint32_t)sb; a.arena_w[e] = x; a.arena_v[e] = sv[j]; }
+                else *a.flag = 1;
+            }
+        }
+    }
+}
+
+__global__ void k_pp_widen(const uint32_t *__restrict__ count2, unsigned long long *__restrict__ wide, uint64_t cnt)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) wide[i] = count2[i];
+}
+
+// slots (first n_a from a, the rest from b) -> out, sorted by (word, low position): bins on the last 9 bits of t
+// inside LDS, then every slot counts the smaller slots of its bin
+template <int CAP>
+__device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t *loff, uint32_t *wsum,
+                                               const uint64_t *wa, const uint32_t *va, uint32_t n_a, const uint64_t *wb,
+                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout)
+{
+    constexpr int ITEMS = CAP / PP_THREADS;
+    cnt[threadIdx.x] = 0;                                      // PP_NB bins, PP_THREADS == PP_NB
+    __syncthreads();
+    uint64_t w[ITEMS];
+    uint32_t v[ITEMS], rk[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        w[r] = j < have ? (j < n_a ? wa[j] : wb[j - n_a]) : ~0ull;
+        v[r] = j < have ? (j < n_a ? va[j] : vb[j - n_a]) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        rk[r] = j < have ? atomicAdd(&cnt[pp_t27(a, w[r]) & (PP_NB - 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    {
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const uint32_t c = cnt[threadIdx.x];
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+        loff[threadIdx.x] = pre + inc - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) { const uint32_t at = loff[pp_t27(a, w[r]) & (PP_NB - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) {
+            const uint32_t bin = pp_t27(a, w[r]) & (PP_NB - 1);
+            const uint32_t b0 = loff[bin], c = cnt[bin];
+            uint32_t smaller = 0;
+            for (uint32_t q = 0; q < c; q++) {
+                const uint64_t x = sw[b0 + q];
+                smaller += (x < w[r] || (x == w[r] && sv[b0 + q] < v[r])) ? 1u : 0u;
+            }
+            rk[r] = b0 + smaller;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) { sw[rk[r]] = w[r]; sv[rk[r]] = v[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * PP_THREADS;
+        if (j < have) { wout[j] = sw[j]; vout[j] = sv[j]; }
+    }
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a)
+{
+    __shared__ uint64_t sw[PP_FN_CAP];
+    __shared__ uint32_t sv[PP_FN_CAP];
+    __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
+    __shared__ uint32_t wsum[PP_THREADS / 64];
+    const uint32_t have = a.count2[blockIdx.x];
+    if (have == 0 || have > PP_FN_CAP) return;                 // the larger ones: k_pp_finish_big
+    const uint64_t *wa = a.w2 + (uint64_t)blockIdx.x * PP_FN_CAP;
+    const uint32_t *va = a.v2 + (uint64_t)blockIdx.x * PP_FN_CAP;
+    pp_finish_body<PP_FN_CAP>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[blockIdx.x], a.vout + a.off[blockIdx.x]);
+}
+
+__global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
+                                                              const uint32_t *__restrict__ idx_sorted, uint32_t entries,
+                                                              uint64_t *__restrict__ gw, uint32_t *__restrict__ gv)
+{
+    // gw / gv: the arena entries gathered in sb_sorted order (k_pp_gather)
+    __shared__ uint64_t sw[PP_BIG_CAP];
+    __shared__ uint32_t sv[PP_BIG_CAP];
+    __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
+    __shared__ uint32_t wsum[PP_THREADS / 64];
+    const uint32_t e = blockIdx.x;
+    if (e >= entries) return;
+    const uint32_t sb = sb_sorted[e];
+    if (e > 0 && sb_sorted[e - 1] == sb) return;
+    const uint32_t have = a.count2[sb];
+    if (have > PP_BIG_CAP || have <= PP_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
+    pp_finish_body<PP_BIG_CAP>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
+                               gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb]);
+}
+
+__global__ void k_pp_gather(const uint32_t *__restrict__ idx_sorted, const uint64_t *__restrict__ aw, const uint32_t *__restrict__ av,
+                            uint32_t entries, uint64_t *__restrict__ gw, uint32_t *__restrict__ gv)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < entries) { gw[e] = aw[idx_sorted[e]]; gv[e] = av[idx_sorted[e]]; }
+}
+
+__global__ void k_pp_iota(uint32_t *__restrict__ idx, uint32_t n)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) idx[e] = e;
+}
+
+// Packs, filters and sorts the slots of key range [lo, hi) of the current text into out_w / out_v (count of them
+// in *count).  *ok = 0: not done (a capacity was exceeded, or the sizes do not suit this sort): nothing usable.
+int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
+                      uint64_t *count, int *ok, int *launches)
+{
+    *ok = 0;
+    const uint64_t N = ctx->N;
+    const uint64_t min_n = getenv("FBG_MSD_MIN") ? strtoull(getenv("FBG_MSD_MIN"), nullptr, 10) : (1ull << 24);
+    if (!g.compact || g.packed || N / nparts < min_n || getenv("FBG_NO_MSD_SORT")) return FBG_OK;
+    const uint64_t top = g.key_bits >= 64 ? ~0ull : (1ull << g.key_bits);
+    const uint64_t span = (nohi ? top : hi) - lo;
+    if (span < (1ull << 28) || g.key_bits >= 64) return FBG_OK;       // t needs 27 bits of resolution below the span
+    const unsigned __int128 one = 1;
+    const uint64_t mul = (uint64_t)((one << 91) / span);               // < 2^64 since span > 2^27
+    hipStream_t st = ctx->stream;
+    const uint64_t est = N / nparts + N / (64 * (uint64_t)nparts) + 65536;   // the partitions are quantiles of a sample: sizes within a percent
+    const uint64_t cap1 = est / PP_NB + est / (4 * PP_NB) + 65536;
+    const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
+    if (est / nsub + est / (8 * nsub) + 64 > PP_FN_CAP) return FBG_OK;
+    FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)PP_NB * cap1 * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->valsA, (size_t)PP_NB * cap1 * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->msd_w, (size_t)nsub * PP_FN_CAP * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->msd_v, (size_t)nsub * PP_FN_CAP * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, PP_NB * 8 + (PP_NB + 1) * 4 + 64));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_b, nsub * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (nsub + 1) * 8 * 2));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)PP_ARENA * 4 * 5));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_e, (size_t)PP_ARENA * 8 * 2));
+    unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;      // [0] flag, [1] arena count, [2] total
+    PpArgs a;
+    a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = g.wide ? g.pb : 0; a.nparts = nparts;
+    a.wide = g.wide ? 1 : 0;
+    a.lo = lo; a.hi = hi; a.mul = mul; a.nohi = nohi;
+    a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
+    a.count1 = ctx->dp_a.as<unsigned long long>();
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + PP_NB * 8);
+    a.tile_start = tile_start;
+    a.w2 = ctx->msd_w.as<uint64_t>(); a.v2 = ctx->msd_v.as<uint32_t>(); a.count2 = ctx->dp_b.as<uint32_t>();
+    unsigned long long *wide = ctx->dp_c.as<unsigned long long>(), *off = wide + (nsub + 1);
+    a.off = off;
+    a.arena_sb = ctx->dp_d.as<uint32_t>(); a.arena_v = a.arena_sb + PP_ARENA;
+    uint32_t *a_idx = a.arena_sb + 2 * PP_ARENA, *sb_sorted = a.arena_sb + 3 * PP_ARENA, *idx_sorted = a.arena_sb + 4 * PP_ARENA;
+    a.arena_w = ctx->dp_e.as<uint64_t>();
+    a.arena_count = flag + 1;
+    a.flag = flag;
+    a.wout = nullptr; a.vout = nullptr;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 24, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, PP_NB * 8, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
+    hipLaunchKernelGGL(k_pp_pack_split, dim3(fbg_blocks(N, (uint64_t)PP_TILE * nparts)), dim3(PP_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_pp_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag + 2, flag);
+    uint32_t tiles2 = 0;
+    unsigned long long h3[3] = {0, 0, 0};
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tiles2, tile_start + PP_NB, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 2;
+    if (h3[0] != 0 || tiles2 == 0) return FBG_OK;
+    const uint64_t total = h3[2];
+    FBG_TRY(fbg_reserve(ctx, ctx->keysB, (total + 2 * out_offset) * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->valsB, (total + 2 * out_offset) * 4));
+    a.wout = ctx->keysB.as<uint64_t>() + out_offset; a.vout = ctx->valsB.as<uint32_t>() + out_offset;
+    hipLaunchKernelGGL(k_pp_split, dim3(tiles2), dim3(PP_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_pp_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);
+    {
+        size_t bytes = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, bytes, wide, off, 0ull, (size_t)nsub, rocprim::plus<unsigned long long>(), st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim scan size query: %s", hipGetErrorString(e));
+        FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+        size_t have = ctx->tmp.cap;
+        e = rocprim::exclusive_scan(ctx->tmp.p, have, wide, off, 0ull, (size_t)nsub, rocprim::plus<unsigned long long>(), st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_pp_finish, dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a);
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 4;
+    if (h3[0] != 0) return FBG_OK;
+    if (h3[1] > 0) {
+        const uint32_t entries = (uint32_t)h3[1];
+        hipLaunchKernelGGL(k_pp_iota, dim3(fbg_blocks(entries, 256)), dim3(256), 0, st, a_idx, entries);
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, a.arena_sb, sb_sorted, a_idx, idx_sorted, (size_t)entries, 0u, 32u, st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim sort size query: %s", hipGetErrorString(e));
+        FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+        size_t have = ctx->tmp.cap;
+        e = rocprim::radix_sort_pairs(ctx->tmp.p, have, a.arena_sb, sb_sorted, a_idx, idx_sorted, (size_t)entries, 0u, 32u, st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
+        uint64_t *gw = a.arena_w + PP_ARENA;
+        uint32_t *gv = a_idx;                                  // the iota is consumed by the sort
+        hipLaunchKernelGGL(k_pp_gather, dim3(fbg_blocks(entries, 256)), dim3(256), 0, st, idx_sorted, a.arena_w, a.arena_v, entries, gw, gv);
+        hipLaunchKernelGGL(k_pp_finish_big, dim3(entries), dim3(PP_THREADS), 0, st, a, sb_sorted, idx_sorted, entries, gw, gv);
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        *launches += 4;
+        if (h3[0] != 0) return FBG_OK;
+    }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    *count = total;
+    *ok = 1;
+    return FBG_OK;
+}

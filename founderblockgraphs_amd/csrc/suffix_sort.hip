@@ -699,7 +699,10 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
             FBG_HIP_TRY(ctx, hipMemcpyAsync(&hi, smp_sorted + (uint64_t)(part + 1) * S / nparts, 8, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    if (pre_ok) {
+    int msd_ok = 0;
+    if (pre_ok)     // three passes over 12-byte slots, packing and filtering fused into the first (msd_sort_pairs.hip)
+        FBG_TRY(fbg_msd_sort_part(ctx, g, lo, hi, part + 1 >= nparts, nparts, FBG_PART_HALO, &count, &msd_ok, &launches));
+    if (pre_ok && !msd_ok) {
         unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
         uint64_t cap = N / nparts + N / 8 + 65536;
         if (cap > N) cap = N;
@@ -724,7 +727,7 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     const uint64_t slots = count + 2 * FBG_PART_HALO;
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, slots * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsB, slots * 4));
-    if (pre_ok && count > 0) FBG_TRY(sort_slots(ctx, g, count, FBG_PART_HALO));
+    if (pre_ok && !msd_ok && count > 0) FBG_TRY(sort_slots(ctx, g, count, FBG_PART_HALO));
     FBG_HIP_TRY(ctx, hipGetLastError());
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches));
     return fbg_rank_part_classify(ctx, ctx->keysB.as<uint64_t>(), g.packed ? nullptr : ctx->valsB.as<uint32_t>(), count, g,

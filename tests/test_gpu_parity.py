@@ -744,3 +744,33 @@ def test_block_graph_matches_reference_numbering(engine, case):
         assert list(rep_row[j, :cnt]) == r_reps[j]
         got = [(int(x) >> 32, int(x) & 0xffffffff) for x in edges[j, :int(ecount[j])]]
         assert got == r_edges[j], j
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_partitioned_index_msd_sort_of_pairs(P):
+    """msd_sort_pairs.hip (the partitions' three-pass sort of 12-byte slots), forced on small inputs: long keys in wide
+    slots so that the bucket function has its 27 bits of resolution."""
+    import os
+    import torch
+    from founderblockgraphs_amd import Engine
+    rng = np.random.default_rng(555 + P)
+    env = {"FBG_FORCE_WIDE": "1", "FBG_FULL_KEYS": "1", "FBG_MSD_MIN": "1"}
+    os.environ.update(env)
+    engines = [Engine() for _ in range(P)]
+    try:
+        for (m, n, kw) in [(24, 500, {}), (50, 300, dict(alphabet="AC")), (9, 2500, dict(alphabet="ACGTN")), (40, 400, dict(similar=0.5))]:
+            msa = random_msa(rng, m, n, **kw)
+            for e in engines:
+                e.msa_load_host(msa)
+            ok1, ok2, ok3 = _partitioned(engines, n)
+            assert all(ok1) and all(ok2) and all(ok3), (m, n, kw, ok1, ok2, ok3)
+            d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            engines[0].scan_f(0, n, d_f.data_ptr())
+            engines[0].sync()
+            assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa))
+    finally:
+        for k in env:
+            del os.environ[k]
+        for e in engines:
+            e.close()
