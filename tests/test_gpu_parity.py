@@ -774,3 +774,30 @@ def test_partitioned_index_msd_sort_of_pairs(P):
             del os.environ[k]
         for e in engines:
             e.close()
+
+
+@pytest.mark.parametrize("alphabet", ["AAACGT", "ACGTACGTACGTN", "AC"], ids=["skewed", "rareN", "binary"])
+def test_msd_sort_capacity_fallback_is_seamless(engine, alphabet):
+    """Texts large enough for the MSD sort whose keys do NOT spread evenly (skewed composition, a rare fifth symbol, a
+    binary alphabet): bucket capacities overflow or the geometry does not fit, the engine must end up with the same f
+    as with rocPRIM's sort -- and with the oracle's on a smaller cut of the same rows."""
+    import os
+    import torch
+    rng = np.random.default_rng(2024)
+    m, n = 180, 100_000                                   # 1.8e7 symbols: above the 2^24 threshold
+    msa = random_msa(rng, m, n, alphabet=alphabet)
+    got = []
+    for env in ({}, {"FBG_NO_MSD_SORT": "1"}):
+        os.environ.update(env)
+        try:
+            got.append(engine.elastic_f(msa))
+        finally:
+            for k in env:
+                del os.environ[k]
+    assert np.array_equal(got[0], got[1])
+    small = msa[:40, :4000]
+    os.environ["FBG_MSD_MIN"] = "1"
+    try:
+        assert np.array_equal(engine.elastic_f(small), O.compute_f(small))
+    finally:
+        del os.environ["FBG_MSD_MIN"]
