@@ -41,6 +41,7 @@ SIGNATURES = {
     "fbg_part_index_build": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]),
     "fbg_part_scan": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int)]),
     "fbg_part_finish": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+    "fbg_part_rescan": (C.c_int, [vp, vp]),
     "fbg_block_graph": (C.c_int, [vp, u64p, C.c_uint64, u32p, u64p, u32p, u64p, u64p]),
     "fbg_scan_f": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, vp]),
     "fbg_scan_v": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),

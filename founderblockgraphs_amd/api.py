@@ -175,9 +175,13 @@ class Engine:
         return bool(ok.value)
 
     def part_finish(self, d_gmax_ptr):
+        """0: declined, 1: index ready, 2: call part_rescan, reduce again, then part_finish again"""
         ok = C.c_int(0)
         self._chk(self._L.fbg_part_finish(self._h, C.c_void_p(d_gmax_ptr), C.byref(ok)))
-        return bool(ok.value)
+        return int(ok.value)
+
+    def part_rescan(self, d_gmax_ptr):
+        self._chk(self._L.fbg_part_rescan(self._h, C.c_void_p(d_gmax_ptr)))
 
     def scan_f(self, x0, x1, d_f_ptr, disable_efg_tricks=False):
         self._chk(self._L.fbg_scan_f(self._h, x0, x1, int(disable_efg_tricks), C.c_void_p(d_f_ptr)))

@@ -259,7 +259,27 @@ int fbg_part_finish(fbg_ctx *ctx, const uint32_t *d_gmax, int *ok)
     FBG_HIP_TRY(ctx, hipMemcpyAsync(&verdict, d_gmax + ctx->n, 4, hipMemcpyDeviceToHost, ctx->stream));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *ok = verdict == 0;
-    if (*ok) { ctx->n_exc = 0; ctx->ranked = true; ctx->index_valid = true; }
+    if (*ok) {
+        // a column whose maximum is below the threshold some partition scanned with may have lost a larger value
+        uint64_t unfilled = 0;
+        FBG_TRY(fbg_rank_part_unfilled(ctx, &unfilled));
+        if (unfilled) { *ok = 2; return FBG_OK; }
+        ctx->n_exc = 0; ctx->ranked = true; ctx->index_valid = true;
+    }
+    return FBG_OK;
+}
+
+int fbg_part_rescan(fbg_ctx *ctx, uint32_t *d_gmax)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->part_active || ctx->index_valid)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_rescan follows a fbg_part_finish that returned *ok = 2");
+    if (!d_gmax) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_rescan: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FBG_TRY(fbg_rank_part_rescan(ctx));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(d_gmax, ctx->gmax.p, (ctx->n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_gmax + ctx->n, 0, 4, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FBG_OK;
 }
 

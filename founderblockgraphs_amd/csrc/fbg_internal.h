@@ -66,6 +66,7 @@ struct fbg_ctx {
     int part = 0, nparts = 1;
     uint64_t part_count = 0;   // owned slots (keys / vals arrays: FBG_PART_HALO + part_count + FBG_PART_HALO)
     uint64_t part_T = 0;       // candidates found by phase 1
+    uint32_t part_gmin = 0;    // largest threshold any partition scanned with (0: none, nothing to verify)
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tie_list, big_groups, tmp, small, scalars;
@@ -123,6 +124,8 @@ int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches);       
 int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int pre_ok,
                            uint8_t *d_blob, int *ok);                         // rank_scan.hip
 int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok);
+int fbg_rank_part_unfilled(fbg_ctx *ctx, uint64_t *unfilled);
+int fbg_rank_part_rescan(fbg_ctx *ctx);
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
 int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip
 int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,

@@ -30,6 +30,7 @@
 //
 // Falls back to the record path (suffix_sort.hip doubling + scan.hip) when a quarter of the slots tie
 // (similar rows), a workgroup's candidate region overflows, or a tie group exceeds 64 members.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "fbg_internal.h"
@@ -862,6 +863,42 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     return FBG_OK;
 }
 
+// Sample of the sorted keys (count > 2^22 only): (a) similar rows tie almost everywhere -> *reject, the rank-order scan
+// is not for them; (b) a.g_min: extensions so small that >= 32 rows of every column are expected to exceed them cannot
+// be a column maximum -- skipping them removes almost all table reads.  The threshold is verified afterwards
+// (k_count_unfilled), never trusted.
+static int rs_pick_threshold(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, uint64_t count, const KeyGeom &geom, int *reject,
+                             int *launches)
+{
+    *reject = 0;
+    if (count <= (1u << 22)) return FBG_OK;
+    hipStream_t st = ctx->stream;
+    unsigned long long *cnt = a.counters;
+    unsigned int *d_hist = reinterpret_cast<unsigned int *>(cnt + 8);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned int), st));
+    hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(count, 1024 * 256)), dim3(256), 0, st, keys, a.pb, count, geom.b, geom.key_bits,
+                       cnt, d_hist);
+    (*launches)++;
+    unsigned long long hs[4];
+    unsigned int hh[64];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (hs[2] * 4 > hs[3]) { *reject = 1; return FBG_OK; }
+    if (!getenv("FBG_RANK_NO_THRESHOLD")) {
+        const double need = 32.0 / (double)ctx->m * (double)hs[3];    // sampled slots that must lie at or above g_min
+        unsigned long long above = 0;
+        for (int g = 63; g >= 1; g--) {
+            above += hh[g];
+            if ((double)above >= need) { a.g_min = (uint32_t)g; break; }
+        }
+        // suffixes that tie on the whole key extend by K + 1 at least, more than any that does not tie: where
+        // every column can expect dozens of them nothing else can be a column maximum
+        if ((double)hs[2] / (double)hs[3] * (double)ctx->m >= 32.0) a.g_min = (uint32_t)geom.K + 1;
+    }
+    return FBG_OK;
+}
+
 // Called by fbg_suffix_sort right after the round-0 sort of the compact keys.  *done = 1 when the rank-order scan
 // covered the whole input (ctx->ranked set); 0 = continue with the record path.
 int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &geom, int *done)
@@ -869,7 +906,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     *done = 0;
     ctx->ranked = false;
     ctx->part_active = false;
-    const uint64_t N = ctx->N, n = ctx->n, m = ctx->m;
+    const uint64_t N = ctx->N, n = ctx->n;
     const int layout = rs_layout(geom);
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
@@ -880,33 +917,9 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     RankArgs a;
     rs_args_init(ctx, a, keys, vals, N, layout, geom.pb, geom.b, geom.key_bits, geom.K);
     int launches = 0;
-    if (N > (1u << 22)) {
-        // sample: (a) similar rows tie almost everywhere -> do not even try the rank-order scan;
-        //         (b) extensions so small that >= 32 rows of every column are expected to exceed them cannot be
-        //             a column maximum: skipping them removes almost all table reads (verified below)
-        unsigned int *d_hist = reinterpret_cast<unsigned int *>(cnt + 8);
-        FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(N, 1024 * 256)), dim3(256), 0, st, keys, a.pb, N, geom.b, geom.key_bits,
-                           cnt, d_hist);
-        launches++;
-        unsigned long long hs[4];
-        unsigned int hh[64];
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (hs[2] * 4 > hs[3]) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
-        if (!getenv("FBG_RANK_NO_THRESHOLD")) {
-            const double need = 32.0 / (double)m * (double)hs[3];     // sampled slots that must lie at or above g_min
-            unsigned long long above = 0;
-            for (int g = 63; g >= 1; g--) {
-                above += hh[g];
-                if ((double)above >= need) { a.g_min = (uint32_t)g; break; }
-            }
-            // suffixes that tie on the whole key extend by K + 1 at least, more than any that does not tie: where
-            // every column can expect dozens of them nothing else can be a column maximum
-            if ((double)hs[2] / (double)hs[3] * (double)m >= 32.0) a.g_min = (uint32_t)geom.K + 1;
-        }
-    }
+    int reject = 0;
+    FBG_TRY(rs_pick_threshold(ctx, a, keys, N, geom, &reject, &launches));
+    if (reject) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
     uint64_t T = 0;
     FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
     if (T == ~0ull) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
@@ -947,7 +960,7 @@ __global__ void k_halo_export(const uint64_t *__restrict__ keys, const uint32_t 
     uint32_t *bv = reinterpret_cast<uint32_t *>(blob + 2 * FBG_PART_HALO * 8);
     uint64_t *tail = reinterpret_cast<uint64_t *>(blob + 2 * FBG_PART_HALO * 12);
     const uint32_t t = threadIdx.x;                    // 2 * FBG_PART_HALO threads: head slots, then tail slots
-    if (ok) {
+    if (ok & 1) {
         const uint64_t k = t < FBG_PART_HALO ? own_lo + t : own_hi - 2 * FBG_PART_HALO + t;
         bk[t] = keys[k]; bv[t] = vals ? vals[k] : 0u;
     } else { bk[t] = 0; bv[t] = 0; }
@@ -1000,17 +1013,12 @@ int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_
     int good = pre_ok && count >= 2 * FBG_PART_HALO;
     RankArgs a;
     rs_part_args(ctx, a);
-    if (good && count > (1u << 22)) {                  // similar rows tie almost everywhere: not for this path
-        unsigned int *d_hist = reinterpret_cast<unsigned int *>(cnt + 8);
-        FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 64 * sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_tie_sample, dim3(fbg_blocks(count, 1024 * 256)), dim3(256), 0, st, keys + a.own_lo, a.pb, count,
-                           geom.b, geom.key_bits, cnt, d_hist);
-        launches++;
-        unsigned long long hs[4];
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(hs, cnt, sizeof(hs), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (hs[2] * 4 > hs[3]) good = 0;
+    if (good) {                                        // similar rows tie almost everywhere: not for this path
+        int reject = 0;
+        FBG_TRY(rs_pick_threshold(ctx, a, keys + a.own_lo, count, geom, &reject, &launches));
+        if (reject) good = 0;
     }
+    ctx->part_gmin = a.g_min;
     if (good) {
         uint64_t T = 0;
         FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
@@ -1023,7 +1031,9 @@ int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_
             if (h[1] != 0) good = 0;
         }
     }
-    hipLaunchKernelGGL(k_halo_export, dim3(1), dim3(2 * FBG_PART_HALO), 0, st, keys, vals, a.own_lo, a.own_hi, (uint64_t)good, d_blob);
+    // the verdict and the threshold this partition worked with travel in the blob
+    hipLaunchKernelGGL(k_halo_export, dim3(1), dim3(2 * FBG_PART_HALO), 0, st, keys, vals, a.own_lo, a.own_hi,
+                       (uint64_t)good | ((uint64_t)a.g_min << 8), d_blob);
     launches++;
     FBG_HIP_TRY(ctx, hipGetLastError());
     *ok = good;
@@ -1042,11 +1052,14 @@ int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, i
     FBG_HIP_TRY(ctx, hipMemcpyAsync(hb.data(), d_blobs, hb.size(), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     int good = 1;
+    uint32_t gmin_all = 0;
     for (int p = 0; p < ctx->nparts; p++) {
         uint64_t tail[2];
         memcpy(tail, hb.data() + (size_t)p * FBG_PART_HALO_BYTES + 2 * FBG_PART_HALO * 12, sizeof(tail));
-        if (!tail[0]) good = 0;
+        if (!(tail[0] & 1)) good = 0;
+        gmin_all = std::max(gmin_all, (uint32_t)(tail[0] >> 8));
     }
+    ctx->part_gmin = gmin_all;      // a column maximum of at least this cannot be beaten by anything any partition skipped
     if (good) {
         RankArgs a;
         rs_part_args(ctx, a);
@@ -1069,6 +1082,38 @@ int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, i
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *ok = good;
     return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+}
+
+// After the column maxima of all partitions were max-reduced into ctx->gmax: columns whose maximum is below the
+// largest threshold any partition used (and that are not exempt from thresholds)
+int fbg_rank_part_unfilled(fbg_ctx *ctx, uint64_t *unfilled)
+{
+    *unfilled = 0;
+    if (ctx->part_gmin <= 1) return FBG_OK;
+    hipStream_t st = ctx->stream;
+    unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(cnt + 4, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_count_unfilled, dim3(fbg_blocks(ctx->n, 256)), dim3(256), 0, st, ctx->gmax.as<uint32_t>(), ctx->n, ctx->part_gmin,
+                       ctx->reversed, cnt);
+    unsigned long long h = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&h, cnt + 4, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *unfilled = h;
+    return FBG_OK;
+}
+
+// The exact re-scan of this partition's slots without any threshold, on top of the maxima in ctx->gmax
+int fbg_rank_part_rescan(fbg_ctx *ctx)
+{
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
+    RankArgs a;
+    rs_part_args(ctx, a);
+    a.g_min = 0;
+    a.values_only = 1;
+    RS_LAUNCH(k_rank_scan, ctx->rk_layout, dim3(fbg_blocks(ctx->part_count, RS_CHUNK, 256 * 16)), dim3(RS_THREADS), ctx->stream, a);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    ctx->part_gmin = 0;
+    return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, 1);
 }
 
 int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out)

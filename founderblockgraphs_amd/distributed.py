@@ -144,4 +144,14 @@ def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=Fal
     if world > 1:
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     fence()
-    return engine.part_finish(gmax.data_ptr())
+    verdict = engine.part_finish(gmax.data_ptr())
+    if verdict == 2:
+        # some column's maximum did not clear the scan's threshold (every rank sees the same reduced maxima and takes
+        # this branch together): exact re-scan without threshold, reduce once more
+        engine.part_rescan(gmax.data_ptr())
+        fence()
+        if world > 1:
+            dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+        fence()
+        verdict = engine.part_finish(gmax.data_ptr())
+    return verdict == 1

@@ -150,7 +150,9 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
  *                          of this partition's suffixes, word n its verdict
  *       -> all-reduce(MAX) d_gmax over the ranks
  *   fbg_part_finish        takes the reduced maxima; afterwards fbg_scan_f / fbg_scan_v work as after
- *                          fbg_index_build.
+ *                          fbg_index_build.  *ok = 2 (the same on every rank): the scan used a threshold that a few
+ *                          columns did not clear -- call fbg_part_rescan (maxima without threshold into d_gmax),
+ *                          all-reduce(MAX) once more and call fbg_part_finish again.
  *
  * *ok = 0 (from any of the three; the same value on every rank after the collective that follows) means the
  * input does not suit this path (similar rows, long runs): fall back to fbg_index_build on every rank.
@@ -161,6 +163,7 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
 int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void *d_blob, int *ok);
 int fbg_part_scan(fbg_ctx *ctx, const void *d_blobs, uint32_t *d_gmax, int *ok);
 int fbg_part_finish(fbg_ctx *ctx, const uint32_t *d_gmax, int *ok);
+int fbg_part_rescan(fbg_ctx *ctx, uint32_t *d_gmax);
 /* Columns [x0, x1) of f, max-merged into d_f[x0..x1) (d_f has n entries, device memory). */
 int fbg_scan_f(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_f);
 /* Columns [x0, x1) of v, written to d_v[x0..x1). Requires fbg_index_build(reversed = 1). */

@@ -101,9 +101,10 @@ class _OraclePartEngine:
     owns the suffix-array slots [N*r/W, N*(r+1)/W) and contributes the extensions g of exactly those suffixes
     (fbg.cpp:1633-1657 for gap-free rows).  Same calling convention: raw addresses of caller-owned buffers."""
 
-    def __init__(self, msa, fail=False):
+    def __init__(self, msa, fail=False, lazy=False):
         from oracle import pyoracle as O
         self.msa, self.fail = msa, fail
+        self.lazy = lazy               # first scan with a threshold (drops small extensions), like the engine's g_min
         self.m, self.n = msa.shape
         _, self.SA, self.ISA, lcp = O.msa_index(msa)
         self.LCP = np.concatenate([lcp.astype(np.int64), [0]])
@@ -149,6 +150,8 @@ class _OraclePartEngine:
                 for q in range(lb, rb + 1):
                     if lo <= q < hi:
                         ext = 1 + max(self.LCP[lb:q + 1].min(), self.LCP[q + 1:rb + 2].min())
+                        if self.lazy and ext < 4:
+                            continue
                         g[x] = max(g[x], ext)
                 k = e + 1
         return True
@@ -156,9 +159,21 @@ class _OraclePartEngine:
     def part_finish(self, gmax_ptr):
         g = self._view(gmax_ptr, 4 * (self.n + 1), np.int32)
         if g[self.n] != 0:
-            return False
+            return 0
+        if self.lazy and g[:self.n].min() < 4:
+            return 2                   # a column did not clear the threshold: the caller must re-scan
         self.gmax = g[:self.n].astype(np.int64)
-        return True
+        return 1
+
+    def part_rescan(self, gmax_ptr):
+        self.lazy = False
+        blobs = np.zeros(1, dtype=np.uint8)
+        from founderblockgraphs_amd._lib import PART_HALO, PART_HALO_BYTES
+        ok = np.zeros(self.nparts * PART_HALO_BYTES, dtype=np.uint8)
+        for p in range(self.nparts):
+            ok[p * PART_HALO_BYTES + 2 * PART_HALO * 12] = 1
+        self.part_scan(ok.ctypes.data, gmax_ptr)
+        del blobs
 
     def f(self):
         """k_rank_finish: fbg.cpp:1618-1666 with rank_i(x) = x, tot_i = n (gap-free rows)."""
@@ -179,16 +194,17 @@ def _worker_part(rank, world, port, fail_rank, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     msa = random_msa(np.random.default_rng(11), 9, 160, similar=0.8)
-    eng = _OraclePartEngine(msa, fail=(rank == fail_rank))
+    eng = _OraclePartEngine(msa, fail=(rank == fail_rank), lazy=(fail_rank == -2))
     ok = D.partitioned_index(eng, msa.shape[1], device="cpu")
     assert ok == (fail_rank < 0)                     # one failing partition: every rank declines
+    assert not eng.lazy                              # fail_rank -2: the re-scan branch was taken (on every rank)
     if ok:
         assert np.array_equal(eng.f().astype(np.uint64), O.compute_f(msa))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fail_rank", [-1, 0, 1])
+@pytest.mark.parametrize("fail_rank", [-1, 0, 1, -2])
 def test_two_rank_partitioned_index(fail_rank, tmp_path):
     """Key-range partitioned index: halo all-gather + all-reduce(max) of the column maxima, verdict included."""
     mp.spawn(_worker_part, args=(2, _free_port(), fail_rank, str(tmp_path)), nprocs=2, join=True)

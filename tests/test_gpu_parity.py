@@ -443,7 +443,17 @@ def _partitioned(engines, n, reversed=False):
         red = torch.maximum(red, g)
     torch.cuda.synchronize()
     ok3 = [e.part_finish(red.data_ptr()) for e in engines]
-    return ok1, ok2, ok3
+    if all(v == 2 for v in ok3):                      # a threshold was not cleared everywhere: exact re-scan, reduce again
+        for r, e in enumerate(engines):
+            e.part_rescan(gm[r].data_ptr())
+            e.sync()
+        red = gm[0]
+        for g in gm[1:]:
+            red = torch.maximum(red, g)
+        torch.cuda.synchronize()
+        ok3 = [e.part_finish(red.data_ptr()) for e in engines]
+    assert all(v in (0, 1) for v in ok3) and len(set(ok3)) == 1, ok3
+    return ok1, ok2, [v == 1 for v in ok3]
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 5])
