@@ -6,14 +6,25 @@
 #define MSD_SEP 0x80                           // FBG_SEP of suffix_sort.hip
 #define MSD_ITEMS 8
 
-// tile[0 .. TILE + 64): codes of text positions base .. (cd = the 256-entry code table in LDS); TILE = 8 * blockDim.x
+// The symbol codes of text positions base .. base + TILE + 64 go to LDS in two steps, so that a kernel walking several
+// tiles can have the next tile's loads in flight: msd_fetch_raw (8 text bytes per thread, threads 0..7 also the 64
+// bytes of lookahead; T is padded beyond N, base is a multiple of 8) and msd_store_tile (code table cd in LDS).
 template <int TILE>
-__device__ __forceinline__ void msd_load_tile(uint8_t *tile, const uint8_t *cd, const uint8_t *__restrict__ T, uint64_t N, uint64_t base)
+__device__ __forceinline__ void msd_fetch_raw(const uint8_t *__restrict__ T, uint64_t N, uint64_t base, uint64_t &raw, uint64_t &raw2)
 {
-    // 8 text bytes per thread and load (T is padded beyond N; base is a multiple of 8)
+    const uint64_t p = base + threadIdx.x * 8;
+    raw = p < N + 56 ? *reinterpret_cast<const uint64_t *>(T + p) : 0ull;
+    raw2 = 0;
+    if (threadIdx.x < 8) {
+        const uint64_t q = base + TILE + threadIdx.x * 8;
+        raw2 = q < N + 56 ? *reinterpret_cast<const uint64_t *>(T + q) : 0ull;
+    }
+}
+template <int TILE>
+__device__ __forceinline__ void msd_store_tile(uint8_t *tile, const uint8_t *cd, uint64_t N, uint64_t base, uint64_t raw, uint64_t raw2)
+{
     const int k8 = threadIdx.x * 8;
     const uint64_t p = base + k8;
-    const uint64_t raw = p < N + 56 ? *reinterpret_cast<const uint64_t *>(T + p) : 0ull;
     uint64_t codes = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -21,10 +32,9 @@ __device__ __forceinline__ void msd_load_tile(uint8_t *tile, const uint8_t *cd, 
         codes |= (uint64_t)c << (8 * j);
     }
     *reinterpret_cast<uint64_t *>(tile + k8) = codes;
-    if (threadIdx.x < 8) {                                  // the 64 bytes of lookahead
+    if (threadIdx.x < 8) {
         const int kk = TILE + threadIdx.x * 8;
         const uint64_t q = base + kk;
-        const uint64_t raw2 = q < N + 56 ? *reinterpret_cast<const uint64_t *>(T + q) : 0ull;
         uint64_t codes2 = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -33,6 +43,13 @@ __device__ __forceinline__ void msd_load_tile(uint8_t *tile, const uint8_t *cd, 
         }
         *reinterpret_cast<uint64_t *>(tile + kk) = codes2;
     }
+}
+template <int TILE>
+__device__ __forceinline__ void msd_load_tile(uint8_t *tile, const uint8_t *cd, const uint8_t *__restrict__ T, uint64_t N, uint64_t base)
+{
+    uint64_t raw, raw2;
+    msd_fetch_raw<TILE>(T, N, base, raw, raw2);
+    msd_store_tile<TILE>(tile, cd, N, base, raw, raw2);
 }
 
 // w[i] = key of position t0 + i of the tile, i < MSD_ITEMS (t0 = 8 * threadIdx.x)

@@ -91,11 +91,15 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
     cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) staged = 0;
     const int lane = threadIdx.x & 63;
+    const uint64_t base0 = (uint64_t)blockIdx.x * a.nparts * PP_TILE;
+    uint64_t raw = 0, raw2 = 0;
+    if (base0 < a.N) msd_fetch_raw<PP_TILE>(a.T, a.N, base0, raw, raw2);
     for (int sub = 0; sub < a.nparts; sub++) {
-        const uint64_t base = ((uint64_t)blockIdx.x * a.nparts + sub) * PP_TILE;
+        const uint64_t base = base0 + (uint64_t)sub * PP_TILE;
         __syncthreads();                                        // the tile of the previous round is done with
         if (base >= a.N) continue;                              // uniform
-        msd_load_tile<PP_TILE>(tile, cd, a.T, a.N, base);
+        msd_store_tile<PP_TILE>(tile, cd, a.N, base, raw, raw2);
+        if (sub + 1 < a.nparts && base + PP_TILE < a.N) msd_fetch_raw<PP_TILE>(a.T, a.N, base + PP_TILE, raw, raw2);   // in flight during this tile's work
         __syncthreads();
         uint64_t key[MSD_ITEMS];
         msd_build_keys(tile, threadIdx.x * MSD_ITEMS, a.b, a.K, key);
