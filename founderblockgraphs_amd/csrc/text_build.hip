@@ -79,7 +79,69 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
             rest &= ~same;
         }
     };
-    if ((((uintptr_t)row + x_lo) & 3) == 0) {
+    if ((((uintptr_t)row + x_lo) & 7) == 0 && !is_ignore) {
+        // 8 bytes per lane and load.  The segment's alphabet is guessed from its first 64 bytes (up to RC_CAND symbols,
+        // '-' always among them); the bytes of a word equal to a candidate are counted with a handful of word
+        // operations per candidate into per-thread counters; only bytes outside the guess go through count()
+        constexpr int RC_CAND = 6;
+        uint32_t cand[RC_CAND];
+        {
+            const uint64_t x = x_lo + lane;
+            uint32_t c = x < x_hi ? (uint32_t)row[x] : 0x100u;
+            cand[0] = '-';
+            unsigned long long rest = __ballot(c < 0x100u && c != '-');
+#pragma unroll
+            for (int k = 1; k < RC_CAND; k++) {
+                cand[k] = 0x100u;                                       // no byte equals 0x100: an unused candidate
+                if (rest) {
+                    const int l = __ffsll((long long)rest) - 1;
+                    cand[k] = __shfl(c, l, 64);
+                    rest &= ~__ballot(c == cand[k]);
+                }
+            }
+        }
+        uint32_t pc[RC_CAND];
+#pragma unroll
+        for (int k = 0; k < RC_CAND; k++) pc[k] = 0;
+        const uint64_t *words = reinterpret_cast<const uint64_t *>(row + x_lo);
+        const uint64_t nbytes = x_hi > x_lo ? x_hi - x_lo : 0, nwords = nbytes / 8;
+        for (uint64_t q = threadIdx.x; q < RC_SEG / 8; q += (uint64_t)TB_THREADS * RC_UNROLL) {     // uniform trip count
+            uint64_t wv[RC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RC_UNROLL; u++) {
+                const uint64_t qq = q + (uint64_t)u * TB_THREADS;
+                wv[u] = qq < nwords ? words[qq] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < RC_UNROLL; u++) {
+                const bool valid = q + (uint64_t)u * TB_THREADS < nwords;
+                uint64_t hit = 0;                                       // 0x80 in every byte that equals some candidate
+#pragma unroll
+                for (int k = 0; k < RC_CAND; k++) {
+                    const uint64_t d = wv[u] ^ (0x0101010101010101ull * (cand[k] & 0xffu));
+                    uint64_t z = ~(((d & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | d) & 0x8080808080808080ull;   // bytes of d that are 0
+                    if (cand[k] > 0xffu || !valid) z = 0;
+                    pc[k] += (uint32_t)__popcll(z);
+                    hit |= z;
+                }
+                const bool odd = valid && hit != 0x8080808080808080ull;  // a byte outside the guess
+                if (__ballot(odd)) {
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++)
+                        count((uint32_t)(wv[u] >> (8 * bb)) & 0xffu, odd && !((hit >> (8 * bb + 7)) & 1ull));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RC_CAND; k++) {
+            uint32_t v = pc[k];
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+            if (lane == 0 && v && cand[k] <= 0xffu) atomicAdd(&sh[cand[k]], v);
+            if (k > 0) nongap += lane == 0 ? v : 0u;                    // cand[0] is the gap symbol
+        }
+        const uint64_t tail = x_lo + nwords * 8 + threadIdx.x;         // up to seven bytes left (first wave only)
+        if (threadIdx.x < 64) count(tail < x_hi ? (uint32_t)row[tail] : 0u, tail < x_hi);
+    } else if ((((uintptr_t)row + x_lo) & 3) == 0) {
         // 4 bytes per lane and load (rows of MSAs whose width is a multiple of 4 all start aligned)
         const uint32_t *words = reinterpret_cast<const uint32_t *>(row + x_lo);
         const uint64_t nbytes = x_hi > x_lo ? x_hi - x_lo : 0, nwords = nbytes / 4;
