@@ -269,7 +269,9 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
 // finished on the spot from registers (its neighbours are the thread's own slots or the adjacent lanes'), the
 // others queue up; (3) the queue is worked off, out of LDS, by as many lanes as it has entries instead of a few
 // lanes in every wave.
-template <int L> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
+// PLAIN = false: the threshold lies above K, nothing that does not tie can be a column maximum -- except in the 64
+// columns nearest a row end, which are never thresholded: those slots take the general path, the rest only classify.
+template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
 {
     __shared__ uint64_t skey[RS_CHUNK + 2 * RS_HALO];
     __shared__ uint32_t srem[RS_CHUNK + 2 * RS_HALO];   // symbols left in the row: names the column as well
@@ -357,7 +359,7 @@ template <int L> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankA
         for (int r = 0; r < RS_ITEMS; r++) { upd_g[r] = 0; upd_c[r] = 0; }
         uint32_t lcp[RS_ITEMS + 1];                                    // key LCP of slots my_i + r - 1 and my_i + r (K for equal keys)
 #pragma unroll
-        for (int r = 0; r <= RS_ITEMS; r++) lcp[r] = rs_key_lcp(kk[r + 2], kk[r + 3], a.b, a.key_bits);
+        for (int r = 0; r <= RS_ITEMS; r++) lcp[r] = PLAIN ? rs_key_lcp(kk[r + 2], kk[r + 3], a.b, a.key_bits) : 0u;
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) {
             // slot i with keys K[-3..3] = kk[r .. r+6] and columns C[-2..2] = cc[r .. r+4]
@@ -383,11 +385,11 @@ template <int L> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankA
                             if (prev_tie) { run = run || cc[r] == rem; mrp = max(mrp, cc[r]); }
                             if (next_tie) { run = run || cc[r + 4] == rem; mrn = max(mrn, cc[r + 4]); }
                             if (run) want_cand = true;
-                            else {
+                            else if (PLAIN) {
                                 const uint32_t g = max(min(lcp[r], min(rem, mrp)), min(lcp[r + 1], min(rem, mrn))) + 1;
                                 // near the end of a row few suffixes compete and extensions stay short: no threshold there
                                 if (g >= a.g_min || rem <= 64) { upd_g[r] = g; upd_c[r] = rs_col_of_rem(a, rem); }
-                            }
+                            } else if (rem <= 64) slow = true;
                         }
                     }
                 } else if (!eqp && kk[r + 5] != key && i + 4 < hi_i) {
@@ -419,7 +421,7 @@ template <int L> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankA
         // looked at after the queue has been worked off
         uint32_t cur[RS_ITEMS];
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++) cur[r] = upd_g[r] ? a.gmax[upd_c[r]] : 0xffffffffu;
+        for (int r = 0; r < RS_ITEMS; r++) cur[r] = (PLAIN && upd_g[r]) ? a.gmax[upd_c[r]] : 0xffffffffu;
         __syncthreads();
         {
             const uint32_t qn = sqn;
@@ -440,9 +442,11 @@ template <int L> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankA
                 }
             }
         }
+        if (PLAIN) {
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++)
-            if (cur[r] < upd_g[r]) atomicMax(&a.gmax[upd_c[r]], upd_g[r]);
+            for (int r = 0; r < RS_ITEMS; r++)
+                if (cur[r] < upd_g[r]) atomicMax(&a.gmax[upd_c[r]], upd_g[r]);
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
@@ -771,6 +775,17 @@ template <class F> static int rs_with_tmp(fbg_ctx *ctx, F &&call)
         else hipLaunchKernelGGL((kernel<FBG_SLOTS_PAIRS>), grid, block, 0, st, __VA_ARGS__);                                \
     } while (0)
 
+#define RS_LAUNCH_SCAN(layout, plain, grid, st, args)                                                                         \
+    do {                                                                                                                     \
+        const dim3 blk_(RS_THREADS);                                                                                         \
+        if ((layout) == FBG_SLOTS_PACKED) { if (plain) hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_PACKED, true>), grid, blk_, 0, st, args);   \
+                                            else hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_PACKED, false>), grid, blk_, 0, st, args); }      \
+        else if ((layout) == FBG_SLOTS_WIDE) { if (plain) hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_WIDE, true>), grid, blk_, 0, st, args);  \
+                                               else hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_WIDE, false>), grid, blk_, 0, st, args); }     \
+        else { if (plain) hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_PAIRS, true>), grid, blk_, 0, st, args);                               \
+               else hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_PAIRS, false>), grid, blk_, 0, st, args); }                                  \
+    } while (0)
+
 static int rs_layout(const KeyGeom &g) { return g.packed ? FBG_SLOTS_PACKED : g.wide ? FBG_SLOTS_WIDE : FBG_SLOTS_PAIRS; }
 
 static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *vals, uint64_t slots, int layout, int pb, int b,
@@ -822,7 +837,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     a.ties = ctx->tie_list.as<uint32_t>();
     a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    RS_LAUNCH(k_rank_scan, layout, dim3(rs_blocks), dim3(RS_THREADS), st, a);
+    RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
     *launches += 2;
@@ -939,7 +954,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     if (a.g_min > 1 && h[4] != 0) {
         a.g_min = 0;
         a.values_only = 1;
-        RS_LAUNCH(k_rank_scan, layout, dim3(fbg_blocks(N, RS_CHUNK, 256 * 16)), dim3(RS_THREADS), st, a);
+        RS_LAUNCH_SCAN(layout, true, dim3(fbg_blocks(N, RS_CHUNK, 256 * 16)), st, a);
         launches++;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
@@ -1110,7 +1125,7 @@ int fbg_rank_part_rescan(fbg_ctx *ctx)
     rs_part_args(ctx, a);
     a.g_min = 0;
     a.values_only = 1;
-    RS_LAUNCH(k_rank_scan, ctx->rk_layout, dim3(fbg_blocks(ctx->part_count, RS_CHUNK, 256 * 16)), dim3(RS_THREADS), ctx->stream, a);
+    RS_LAUNCH_SCAN(ctx->rk_layout, true, dim3(fbg_blocks(ctx->part_count, RS_CHUNK, 256 * 16)), ctx->stream, a);
     FBG_HIP_TRY(ctx, hipGetLastError());
     ctx->part_gmin = 0;
     return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, 1);
