@@ -271,7 +271,7 @@ __device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t
 // lanes in every wave.
 // PLAIN = false: the threshold lies above K, nothing that does not tie can be a column maximum -- except in the 64
 // columns nearest a row end, which are never thresholded: those slots take the general path, the rest only classify.
-template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) void k_rank_scan(RankArgs a)
+template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_rank_scan(RankArgs a)
 {
     __shared__ uint64_t skey[RS_CHUNK + 2 * RS_HALO];
     __shared__ uint32_t srem[RS_CHUNK + 2 * RS_HALO];   // symbols left in the row: names the column as well
