@@ -28,7 +28,7 @@
 #define MSD_THREADS 1024
 #define MSD_TILE (MSD_THREADS * MSD_ITEMS)
 #define MSD_FN_THREADS 512
-#define MSD_FN_CAP 4608                        // slots per sub-bucket (mean at 10^9 suffixes: 3815)
+#define MSD_FN_CAP 4096                        // slots per sub-bucket stretch (mean at 10^9 suffixes: 3815; the few that overflow: arena)
 #define MSD_FN_ITEMS (MSD_FN_CAP / MSD_FN_THREADS)
 #define MSD_FN_BITS 10
 #define MSD_FN_BINS (1 << MSD_FN_BITS)
@@ -325,7 +325,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     hipStream_t st = ctx->stream;
     const uint64_t cap1 = N / MSD_NB + N / (4 * MSD_NB) + 65536;
     const uint64_t nsub = (uint64_t)MSD_NB * MSD_NB;
-    if (N / nsub + N / (8 * nsub) + 64 > MSD_FN_CAP) return FBG_OK;         // sub-buckets would not fit LDS
+    if (N / nsub + N / (32 * nsub) + 64 > MSD_FN_CAP) return FBG_OK;        // sub-buckets would not fit their stretches
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)MSD_NB * cap1 * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, (size_t)nsub * MSD_FN_CAP * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_a, MSD_NB * 8 + (MSD_NB + 1) * 4 + 64));
