@@ -60,6 +60,15 @@ int main(int argc, char **argv)
     }
 
     const auto start = std::chrono::high_resolution_clock::now();
+    // FBG_TIMING=1: where the wall time goes, on stderr (not part of the reference's output)
+    const bool timing = std::getenv("FBG_TIMING") != nullptr;
+    auto last = start;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::high_resolution_clock::now();
+        std::cerr << "[timing] " << what << ": " << std::chrono::duration<double>(now - last).count() << " s\n";
+        last = now;
+    };
 
     Msa msa;
     if (!read_msa(opt.input, opt.gap_limit, opt.elastic, opt.output_paths, msa) || msa.m == 0 || msa.n == 0) {
@@ -67,6 +76,7 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
     std::cerr << "Input MSA[1.." << msa.m << ",1.." << msa.n << "]" << std::endl;                            // 3357
+    lap("read FASTA");
 
     if (opt.elastic && opt.threads != -1 && opt.threads <= 0) {                                              // 3396-3399
         std::cerr << "Invalid number of threads." << std::endl;
@@ -80,6 +90,7 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
 
+    lap("open the GPU engine");
     int status = EXIT_SUCCESS;
     std::vector<uint64_t> boundaries;
     if (opt.elastic) {
@@ -130,6 +141,7 @@ int main(int argc, char **argv)
         fbg_ctx_destroy(ctx);
         return EXIT_FAILURE;
     }
+    lap("segmentation (copy in, index, scan, sweep)");
     // nodes and edges of the graph come from the engine too (fbg_block_graph); ask before it goes away
     BlockGraph graph;
     bool have_graph = false;
@@ -141,6 +153,7 @@ int main(int argc, char **argv)
                              graph.rep_row.data(), graph.edge_count.data(), graph.edges.data());
         have_graph = rc == FBG_OK;          // otherwise (a hash collision, an input beyond its limits): hash on the host
     }
+    lap("graph nodes and edges");
     fbg_ctx_destroy(ctx);
 
     if (!opt.elastic) {
@@ -163,6 +176,7 @@ int main(int argc, char **argv)
         std::abort();
     }
 
+    lap("write xGFA");
     const auto end = std::chrono::high_resolution_clock::now();
     const auto seconds = std::chrono::duration_cast<std::chrono::seconds>(end - start).count();
     if (opt.graphviz_output_given) {                                                                         // 3511-3515

@@ -5,6 +5,9 @@
 #include <string_view>
 #include <unordered_map>
 #include <unordered_set>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace {
 
@@ -145,37 +148,120 @@ bool write_xgfa(const Msa &msa, const std::vector<uint64_t> &boundaries, bool ou
     return ok;
 }
 
+namespace {
+
+// append-only text buffer with the same number / string helpers as Writer
+struct Chunk {
+    std::vector<char> d;
+    void raw(const char *p, size_t len) { d.insert(d.end(), p, p + len); }
+    void str(const char *s) { raw(s, std::strlen(s)); }
+    void num(uint64_t v)
+    {
+        char t[24]; int k = 24;
+        do { t[--k] = char('0' + v % 10); v /= 10; } while (v);
+        raw(t + k, 24 - k);
+    }
+};
+
+// Runs make(unit, chunk) for unit = 0 .. units-1 on a few threads and writes the chunks to fp in unit order.
+// At most `window` finished-but-unwritten units are kept, so memory stays bounded whatever the output size.
+template <class Make> bool ordered_parallel_write(FILE *fp, uint64_t units, Make make)
+{
+    if (units == 0) return true;
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 1;
+    if (T > 16) T = 16;
+    if ((uint64_t)T > units) T = (unsigned)units;
+    const uint64_t window = 4 * (uint64_t)T;
+    std::vector<Chunk> slot(window);
+    std::vector<char> ready(window, 0);
+    std::mutex mu;
+    std::condition_variable cv_ready, cv_space;
+    uint64_t next_unit = 0, written = 0;
+    bool ok = true;
+    auto worker = [&]() {
+        for (;;) {
+            uint64_t u;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_space.wait(lk, [&] { return next_unit >= units || next_unit < written + window; });
+                if (next_unit >= units) return;
+                u = next_unit++;
+            }
+            Chunk &c = slot[u % window];
+            c.d.clear();
+            make(u, c);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ready[u % window] = 1;
+            }
+            cv_ready.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; t++) pool.emplace_back(worker);
+    for (uint64_t u = 0; u < units; u++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_ready.wait(lk, [&] { return ready[u % window] != 0; });
+        }
+        Chunk &c = slot[u % window];
+        if (!c.d.empty() && std::fwrite(c.d.data(), 1, c.d.size(), fp) != c.d.size()) ok = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ready[u % window] = 0;
+            written = u + 1;
+        }
+        cv_space.notify_all();
+    }
+    for (auto &th : pool) th.join();
+    return ok;
+}
+
+} // namespace
+
 bool write_xgfa_graph(const Msa &msa, const std::vector<uint64_t> &boundaries, const BlockGraph &g, bool output_paths,
                       const std::string &path, std::string &error)
 {
     FILE *fp = std::fopen(path.c_str(), "wb");
     if (!fp) { error = "cannot open " + path + " for writing"; return false; }
-    Writer w(fp);
+    std::setvbuf(fp, nullptr, _IOFBF, 1 << 22);
     const uint64_t m = msa.m, n = msa.n, nb = boundaries.size();
-    w.str("M\t"); w.num(m); w.str("\t"); w.num(n); w.str("\n");                     // fbg.cpp:1201
-    w.str("X\t1");                                                                 // 1204-1207
-    for (uint64_t i = 0; i + 1 < nb; i++) { w.str("\t"); w.num(boundaries[i] + 2); }
-    w.str("\n");
-    w.str("B\t");                                                                  // 1210-1220
-    for (uint64_t j = 0; j < nb; j++) { if (j) w.str("\t"); w.num(g.first_node[j + 1] - g.first_node[j]); }
-    w.str("\n");
-    std::vector<char> label;
-    uint64_t prev = 0;
-    for (uint64_t j = 0; j < nb; prev = boundaries[j] + 1, j++) {                  // 1224-1260
-        const uint64_t stop = std::min(boundaries[j] + 1, n);
-        const uint64_t cnt = g.first_node[j + 1] - g.first_node[j];
-        for (uint64_t k = 0; k < cnt; k++) {
-            const uint8_t *row = msa.cells.data() + (uint64_t)g.rep_row[j * m + k] * n;
-            label.clear();
-            for (uint64_t x = prev; x < stop; x++)
-                if (row[x] != '-') label.push_back((char)row[x]);
-            w.str("S\t"); w.num(g.first_node[j] + k); w.str("\t"); w.raw(label.data(), label.size()); w.str("\n");   // 1241
-        }
-        for (uint64_t e = 0; e < g.edge_count[j]; e++) {                            // 1253-1255
-            const uint64_t pr = g.edges[j * m + e];
-            w.str("L\t"); w.num(pr >> 32); w.str("\t+\t"); w.num(pr & 0xffffffffu); w.str("\t+\t0M\n");
-        }
+    bool ok = true;
+    {
+        Writer w(fp);
+        w.str("M\t"); w.num(m); w.str("\t"); w.num(n); w.str("\n");                     // fbg.cpp:1201
+        w.str("X\t1");                                                                 // 1204-1207
+        for (uint64_t i = 0; i + 1 < nb; i++) { w.str("\t"); w.num(boundaries[i] + 2); }
+        w.str("\n");
+        w.str("B\t");                                                                  // 1210-1220
+        for (uint64_t j = 0; j < nb; j++) { if (j) w.str("\t"); w.num(g.first_node[j + 1] - g.first_node[j]); }
+        w.str("\n");
+        w.flush();
+        ok = w.ok;
     }
+    // S and L lines, block by block (1224-1260): formatted by several threads, written in block order
+    const uint64_t per_unit = 256;
+    ok = ordered_parallel_write(fp, (nb + per_unit - 1) / per_unit, [&](uint64_t u, Chunk &c) {
+        const uint64_t j0 = u * per_unit, j1 = std::min(nb, j0 + per_unit);
+        std::vector<char> label;
+        for (uint64_t j = j0; j < j1; j++) {
+            const uint64_t prev = j ? boundaries[j - 1] + 1 : 0;
+            const uint64_t stop = std::min(boundaries[j] + 1, n);
+            const uint64_t cnt = g.first_node[j + 1] - g.first_node[j];
+            for (uint64_t k = 0; k < cnt; k++) {
+                const uint8_t *row = msa.cells.data() + (uint64_t)g.rep_row[j * m + k] * n;
+                label.clear();
+                for (uint64_t x = prev; x < stop; x++)
+                    if (row[x] != '-') label.push_back((char)row[x]);
+                c.str("S\t"); c.num(g.first_node[j] + k); c.str("\t"); c.raw(label.data(), label.size()); c.str("\n");   // 1241
+            }
+            for (uint64_t e = 0; e < g.edge_count[j]; e++) {                            // 1253-1255
+                const uint64_t pr = g.edges[j * m + e];
+                c.str("L\t"); c.num(pr >> 32); c.str("\t+\t"); c.num(pr & 0xffffffffu); c.str("\t+\t0M\n");
+            }
+        }
+    }) && ok;
     if (output_paths) {                                                                                 // 1291-1300
         if (msa.identifiers.size() != m) {
             error = "number of FASTA headers differs from the number of rows kept (the reference asserts here, "
@@ -183,24 +269,30 @@ bool write_xgfa_graph(const Msa &msa, const std::vector<uint64_t> &boundaries, c
             std::fclose(fp);
             return false;
         }
-        std::vector<uint32_t> path_ids;
         for (uint64_t i = 0; i < m; i++) {
-            path_ids.clear();
-            for (uint64_t j = 0; j < nb; j++)
-                if (g.node_of[j * m + i] != 0xffffffffu) path_ids.push_back(g.node_of[j * m + i]);
-            if (path_ids.empty()) {
+            bool any = false;
+            for (uint64_t j = 0; j < nb && !any; j++) any = g.node_of[j * m + i] != 0xffffffffu;
+            if (!any) {
                 error = "row " + std::to_string(i) + " has no non-gap character; its P line is undefined in the "
                         "reference (fbg.cpp:1295)";
                 std::fclose(fp);
                 return false;
             }
-            w.str("P\t"); w.raw(msa.identifiers[i].data(), msa.identifiers[i].size()); w.str("\t");
-            for (size_t k = 0; k + 1 < path_ids.size(); k++) { w.num(path_ids[k]); w.str("+,"); }
-            w.num(path_ids.back()); w.str("+"); w.str("\t*\n");
         }
+        ok = ordered_parallel_write(fp, m, [&](uint64_t i, Chunk &c) {
+            c.str("P\t"); c.raw(msa.identifiers[i].data(), msa.identifiers[i].size()); c.str("\t");
+            bool first = true;
+            for (uint64_t j = 0; j < nb; j++) {
+                const uint32_t id = g.node_of[j * m + i];
+                if (id == 0xffffffffu) continue;
+                if (!first) c.str("+,");
+                c.num(id);
+                first = false;
+            }
+            c.str("+"); c.str("\t*\n");
+        }) && ok;
     }
-    w.flush();
-    const bool ok = w.ok && std::fclose(fp) == 0;
+    ok = (std::fclose(fp) == 0) && ok;
     if (!ok) error = "write to " + path + " failed";
     return ok;
 }
