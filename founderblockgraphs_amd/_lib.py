@@ -33,6 +33,8 @@ SIGNATURES = {
     "fbg_minmax_dp": (C.c_int, [vp, u64p, C.c_uint64, u64p, u64p, u64p, u64p]),
     "fbg_repeatfree_v": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u64p]),
     "fbg_repeatfree_dp": (C.c_int, [vp, u64p, C.c_uint64, u64p, u64p, u64p, u64p]),
+    "fbg_gapped_v": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u64p]),
+    "fbg_gapped_dp": (C.c_int, [vp, u64p, C.c_uint64, u64p, u64p, u64p, u64p]),
     "fbg_msa_set_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64]),
     "fbg_msa_load_host": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64]),
     "fbg_msa_synthetic": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -47,6 +49,8 @@ SIGNATURES = {
     "fbg_scan_v": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
     "fbg_minmax_dp_device": (C.c_int, [vp, vp, C.c_uint64, vp, u64p, vp, vp]),
     "fbg_repeatfree_dp_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp, u64p]),
+    "fbg_scan_gapped_v": (C.c_int, [vp, vp]),
+    "fbg_gapped_dp_device": (C.c_int, [vp, vp, C.c_uint64, vp, vp, vp, u64p]),
     "fbg_text_length": (C.c_uint64, [vp]),
     "fbg_index_download": (C.c_int, [vp, u8p, u32p, u32p, u32p, u32p]),
     "fbg_sync": (C.c_int, [vp]),

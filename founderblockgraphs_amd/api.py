@@ -128,6 +128,28 @@ class Engine:
         self._chk(rc)
         return s, prev, b[:cnt.value].copy()
 
+    def gapped_v(self, msa):
+        """v[] of segment2elasticValid (fbg.cpp:763-822): non-elastic mode, rows may hold gaps."""
+        msa = as_msa(msa)
+        m, n = msa.shape
+        v = np.empty(n, dtype=np.uint64)
+        self._chk(self._L.fbg_gapped_v(self._h, _u8(msa), m, n, _u64(v)))
+        return v
+
+    def gapped_dp(self, v):
+        """fbg.cpp:827-866 -> (s, prev, boundaries); boundaries is None for 'No valid segmentation found!'."""
+        v = np.ascontiguousarray(v, dtype=np.uint64)
+        n = len(v)
+        s = np.empty(n, dtype=np.uint64)
+        prev = np.empty(n, dtype=np.uint64)
+        b = np.empty(n, dtype=np.uint64)
+        cnt = C.c_uint64(0)
+        rc = self._L.fbg_gapped_dp(self._h, _u64(v), n, _u64(s), _u64(prev), _u64(b), C.byref(cnt))
+        if rc == FBG_ERR_NO_SEGMENTATION:
+            return s, prev, None
+        self._chk(rc)
+        return s, prev, b[:cnt.value].copy()
+
     def block_graph(self, boundaries):
         """Nodes / edges of the elastic founder graph for a segmentation of the current MSA (fbg_block_graph):
         (node_of[nb, m], first_node[nb + 1], rep_row[nb, m], edge_count[nb], edges[nb, m])."""
@@ -202,6 +224,18 @@ class Engine:
                                                    C.byref(cnt)))
         return cnt.value
 
+    def scan_gapped_v(self, d_v_ptr):
+        self._chk(self._L.fbg_scan_gapped_v(self._h, C.c_void_p(d_v_ptr)))
+
+    def gapped_dp_device(self, d_v_ptr, n, d_boundaries_ptr, d_s_ptr=None, d_prev_ptr=None):
+        cnt = C.c_uint64(0)
+        rc = self._L.fbg_gapped_dp_device(self._h, C.c_void_p(d_v_ptr), n, C.c_void_p(d_s_ptr),
+                                          C.c_void_p(d_prev_ptr), C.c_void_p(d_boundaries_ptr), C.byref(cnt))
+        if rc == FBG_ERR_NO_SEGMENTATION:
+            return None
+        self._chk(rc)
+        return cnt.value
+
     def set_stream(self, stream_handle):
         self._chk(self._L.fbg_set_stream(self._h, C.c_void_p(stream_handle)))
 
@@ -244,6 +278,19 @@ def segment_elastic_minmaxlength(MSA, ignorechars="", disable_efg_tricks=False, 
         if not segment:
             return None, f
         return eng.minmax_dp(f), f
+    finally:
+        if engine is None:
+            eng.close()
+
+
+def segment2elasticValid(MSA, engine=None):
+    """fbg.cpp:738-866 up to the boundaries (non-elastic mode with --gap-limit != 1).  Returns
+    (status, v, s, prev, boundaries): status 1 = EXIT_FAILURE ('No valid segmentation found!')."""
+    eng = engine or Engine()
+    try:
+        v = eng.gapped_v(MSA)
+        s, prev, b = eng.gapped_dp(v)
+        return (0 if b is not None else 1), v, s, prev, b
     finally:
         if engine is None:
             eng.close()

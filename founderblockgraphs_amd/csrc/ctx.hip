@@ -323,6 +323,31 @@ int fbg_repeatfree_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint
     return fbg_dp_repeatfree(ctx, d_v, n, d_s, d_prev, d_boundaries, count_out);
 }
 
+int fbg_scan_gapped_v(fbg_ctx *ctx, uint64_t *d_v)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!ctx->index_valid || ctx->reversed)
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_scan_gapped_v needs fbg_index_build(reversed=0) first");
+    if (!d_v) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_scan_gapped_v: null d_v");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n;
+    FBG_TRY(fbg_reserve(ctx, ctx->io_d, n * sizeof(uint64_t)));
+    uint64_t *d_f = ctx->io_d.as<uint64_t>();
+    FBG_HIP_TRY(ctx, hipMemsetAsync(d_f, 0, n * sizeof(uint64_t), ctx->stream));
+    FBG_TRY(fbg_scan_columns(ctx, 0, n, FBG_SCAN_F, 1, d_f));        // f without the elastic tricks
+    return fbg_gapped_v_from_f(ctx, d_f, n, d_v);
+}
+
+int fbg_gapped_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
+                         uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!d_v || !d_boundaries || !count_out || n == 0 || n >= (1ull << 31))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_gapped_dp_device: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return fbg_dp_gapped(ctx, d_v, n, d_s, d_prev, d_boundaries, count_out);
+}
+
 // ---- host-buffer entry points ---------------------------------------------------------------
 
 int fbg_elastic_f(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, const uint8_t *ignore_chars,
@@ -397,6 +422,44 @@ int fbg_repeatfree_dp(fbg_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *s_o
     FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, v, w, hipMemcpyHostToDevice, ctx->stream));
     int rc = fbg_dp_repeatfree(ctx, ctx->io_a.as<uint64_t>(), n, ctx->io_c.as<uint64_t>(),
                                ctx->io_d.as<uint64_t>(), ctx->io_b.as<uint64_t>(), count_out);
+    if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) return rc;
+    if (s_out) FBG_HIP_TRY(ctx, hipMemcpyAsync(s_out, ctx->io_c.p, w, hipMemcpyDeviceToHost, ctx->stream));
+    if (prev_out) FBG_HIP_TRY(ctx, hipMemcpyAsync(prev_out, ctx->io_d.p, w, hipMemcpyDeviceToHost, ctx->stream));
+    if (rc == FBG_OK)
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(boundaries_out, ctx->io_b.p, *count_out * sizeof(uint64_t),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int fbg_gapped_v(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, uint64_t *v)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!v) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_gapped_v: null v");
+    FBG_TRY(fbg_msa_load_host(ctx, msa, m, n));
+    FBG_TRY(fbg_index_build(ctx, 0, nullptr, 0));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_a, n * sizeof(uint64_t)));
+    FBG_TRY(fbg_scan_gapped_v(ctx, ctx->io_a.as<uint64_t>()));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(v, ctx->io_a.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FBG_OK;
+}
+
+int fbg_gapped_dp(fbg_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *s_out, uint64_t *prev_out,
+                  uint64_t *boundaries_out, uint64_t *count_out)
+{
+    if (!ctx) return FBG_ERR_INVALID;
+    if (!v || !boundaries_out || !count_out || n == 0 || n >= (1ull << 31))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_gapped_dp: bad arguments");
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t w = n * sizeof(uint64_t);
+    FBG_TRY(fbg_reserve(ctx, ctx->io_a, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_b, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_c, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->io_d, w));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, v, w, hipMemcpyHostToDevice, ctx->stream));
+    int rc = fbg_dp_gapped(ctx, ctx->io_a.as<uint64_t>(), n, ctx->io_c.as<uint64_t>(),
+                           ctx->io_d.as<uint64_t>(), ctx->io_b.as<uint64_t>(), count_out);
     if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) return rc;
     if (s_out) FBG_HIP_TRY(ctx, hipMemcpyAsync(s_out, ctx->io_c.p, w, hipMemcpyDeviceToHost, ctx->stream));
     if (prev_out) FBG_HIP_TRY(ctx, hipMemcpyAsync(prev_out, ctx->io_d.p, w, hipMemcpyDeviceToHost, ctx->stream));

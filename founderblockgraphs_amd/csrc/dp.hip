@@ -969,3 +969,168 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
     if (h[1] != 0) return fbg_fail(ctx, FBG_ERR_NO_SEGMENTATION, "No proper segmentation exists.");
     return FBG_OK;
 }
+
+// ---- non-elastic mode with gaps: segment2elasticValid (fbg.cpp:738-866) ---------------------------------------
+// v[] from the f of the elastic scan without tricks: block [jp..j] passes the interval-union test of fbg.cpp:786-808
+// iff F[jp] <= j (all rows have a symbol in it and every occurrence of every row's string starts at some row's first
+// symbol at or after jp -- what compute_f evaluates with all rows coloured).  The reference's left-moving pointer
+// (763-822) never binds, because the largest passing jp cannot decrease as j grows: v[j] = max{jp : F[jp] <= j}.
+
+__global__ void k_gv_scatter(const uint64_t *__restrict__ f, uint32_t n, uint32_t *__restrict__ best)
+{
+    const uint32_t jp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jp >= n) return;
+    const uint64_t F = f[jp];
+    if (F < n) atomicMax(best + F, jp + 1);          // 0 = no block ends here
+}
+
+__global__ void k_gv_finish(const uint32_t *__restrict__ best, uint32_t n, uint64_t *__restrict__ v)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t b = best[j];                      // running maximum by now
+    v[j] = b ? (uint64_t)b - 1 : (uint64_t)j + 1;   // 764, 806
+}
+
+int fbg_gapped_v_from_f(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_v)
+{
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, (n + 2) * 4));
+    uint32_t *best = ctx->dp_a.as<uint32_t>();
+    FBG_HIP_TRY(ctx, hipMemsetAsync(best, 0, (n + 2) * 4, st));
+    hipLaunchKernelGGL(k_gv_scatter, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, d_f, (uint32_t)n, best);
+    size_t bytes = 0;
+    hipError_t er = rocprim::inclusive_scan(nullptr, bytes, best, best, (size_t)n, rocprim::maximum<uint32_t>(), st);
+    if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim scan size query failed");
+    FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+    size_t have = ctx->tmp.cap;
+    er = rocprim::inclusive_scan(ctx->tmp.p, have, best, best, (size_t)n, rocprim::maximum<uint32_t>(), st);
+    if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim inclusive_scan: %s", hipGetErrorString(er));
+    hipLaunchKernelGGL(k_gv_finish, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, best, (uint32_t)n, d_v);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return FBG_OK;
+}
+
+// The recurrence of fbg.cpp:830-846 is a chain: column j takes either a new block [v[j]..j] on top of s[v[j]-1] or the
+// solution of column j-1 with its last block extended, so one wave walks the columns -- but it walks from event to event,
+// not from column to column.  Between two events (a new block taken at 838-841 or 834-837, or a column without a block,
+// 832) the state is the last event's (a, P) with the last block growing: s[j] = max(a, j - P + 1), prev[j] = P.  A tile of
+// 64 columns sits in the lanes; every lane evaluates its column under the assumption that nothing happens between the
+// last event and itself (its lookback s[v-1] is then either a finished value or the same closed form), a ballot finds
+// the first lane whose test fires -- for that lane the assumption is true -- and the walk jumps there.  Lookbacks in
+// front of the tile come from a ring of the last GD_RING values of s in LDS (or, beyond it, from memory), fetched by
+// all lanes at once before the walk.  INV = n+1 is the reference's initial value of both arrays; with prev[j-1] = n+1
+// the reference's j - prev[j-1] + 1 wraps around to something larger than any score (838, 843), spelled GD_HUGE here.
+#define GD_RING 8192u
+#define GD_HUGE 0xffffffffu
+#define GD_TILES 8u          // tiles per prefetch group
+
+__global__ __launch_bounds__(64) void k_dp_gapped(const uint64_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ s,
+                                                 uint32_t *__restrict__ prev, uint32_t *__restrict__ btp)
+{
+    __shared__ uint32_t ring[GD_RING];
+    const uint32_t lane = threadIdx.x, INV = n + 1;
+    uint32_t sa = INV, sp = INV;                               // the last event: s and prev it left behind
+    auto fetch = [&](uint32_t t0) -> uint32_t {                // v of column t0 + lane; INV = no block ends here (832)
+        const uint32_t j = t0 + lane;
+        if (j >= n || j == 0) return INV;                      // the loop starts at 1 (830)
+        const uint64_t x = v[j];
+        return x > j ? INV : (uint32_t)x;
+    };
+    if (lane == 0) btp[0] = 0;
+    uint32_t cur[GD_TILES], nxt[GD_TILES];
+#pragma unroll
+    for (uint32_t q = 0; q < GD_TILES; q++) nxt[q] = fetch(q * 64);
+    for (uint32_t g0 = 0; g0 < n; g0 += 64 * GD_TILES) {
+#pragma unroll
+        for (uint32_t q = 0; q < GD_TILES; q++) cur[q] = nxt[q];
+        if (g0 + 64 * GD_TILES < n) {
+#pragma unroll
+            for (uint32_t q = 0; q < GD_TILES; q++) nxt[q] = fetch(g0 + 64 * GD_TILES + q * 64);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < GD_TILES; q++) {
+            const uint32_t t0 = g0 + q * 64;
+            if (t0 >= n) break;
+            const uint32_t vj = cur[q], j = t0 + lane;
+            const bool skip = vj == INV, first = vj == 0;
+            const uint32_t look = vj - 1;                      // column whose s the new block builds on
+            // s[v-1] for lookbacks that land in front of this tile
+            uint32_t aext = INV;
+            bool far = false;
+            if (!skip && !first && look < t0) {
+                if (t0 - look <= GD_RING) aext = ring[look % GD_RING]; else far = true;
+            }
+            if (__ballot(far)) {
+                __threadfence();
+                if (far) aext = __hip_atomic_load(s + look, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const uint32_t len_new = j - vj + 1;
+            uint32_t s_vec = INV, p_vec = INV;
+            const uint32_t cnt = min(64u, n - t0);
+            uint32_t k0 = 0;                                   // lanes below k0 are finished
+            while (k0 < cnt) {
+                // the state of column j-1 if nothing happens between the last event and j
+                const uint32_t b = sp == INV ? GD_HUGE : max(sa, j - sp + 1);
+                // every lane takes part in the exchange (a lane switched off would hand out nothing)
+                const uint32_t fin = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((look - t0) & 63u) << 2), (int)s_vec);
+                const uint32_t A = look < t0 ? aext : look - t0 < k0 ? fin : max(sa, look - sp + 1);
+                const uint32_t a = max(A, len_new);
+                const bool fire = skip || first || a < b;                                   // 832, 834, 838
+                const unsigned long long mask = __ballot(fire && lane >= k0 && lane < cnt);
+                const uint32_t ks = mask ? (uint32_t)__builtin_ctzll(mask) : cnt;
+                if (lane >= k0 && lane < ks) { s_vec = b; p_vec = sp; }                     // 842-845
+                if (ks >= cnt) break;
+                const uint32_t ns = skip ? INV : first ? j + 1 : a;                         // 836, 839
+                const uint32_t np = skip ? INV : vj;                                        // 837, 840
+                if (lane == ks) { s_vec = ns; p_vec = np; }
+                sa = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)ks);
+                sp = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)ks);
+                k0 = ks + 1;
+            }
+            if (j < n) {
+                s[j] = s_vec; prev[j] = p_vec;
+                btp[j + 1] = p_vec;                // in prefix lengths: the block that ends prefix j+1 starts after prefix prev[j]
+                ring[j % GD_RING] = s_vec;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// "No valid segmentation found!" is decided on s[n-1] (fbg.cpp:850-854)
+__global__ void k_gd_verdict(const uint32_t *__restrict__ s, uint32_t n, uint64_t *__restrict__ boundaries,
+                             unsigned long long *__restrict__ result)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (s[n - 1] == n + 1) { result[0] = 0; result[1] = 1; return; }
+    if (result[0] > 0) boundaries[result[0] - 1] -= 1;          // the shared backtrack ends at n; this one at n-1 (857-858)
+}
+
+int fbg_dp_gapped(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s, uint64_t *d_prev,
+                  uint64_t *d_boundaries, uint64_t *count_out)
+{
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_DP));
+    const size_t w = (n + 2) * 4;
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_g, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_h, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_b, w));
+    FBG_TRY(fbg_reserve(ctx, ctx->scalars, 256 * sizeof(unsigned long long)));
+    uint32_t *s = ctx->dp_g.as<uint32_t>(), *prev = ctx->dp_h.as<uint32_t>(), *btp = ctx->dp_b.as<uint32_t>();
+    unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 16 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_dp_gapped, dim3(1), dim3(64), 0, st, d_v, (uint32_t)n, s, prev, btp);
+    FBG_TRY(fbg_backtrack_lifted(ctx, btp, (uint32_t)n, d_boundaries, sc));
+    hipLaunchKernelGGL(k_gd_verdict, dim3(1), dim3(64), 0, st, s, (uint32_t)n, d_boundaries, sc);
+    if (d_s) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, s, n, d_s, 0);
+    if (d_prev) hipLaunchKernelGGL(k_widen, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, prev, n, d_prev, 0);
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_DP, 3));
+    unsigned long long h[2];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, sc, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *count_out = h[1] ? 0 : h[0];
+    if (h[1] != 0) return fbg_fail(ctx, FBG_ERR_NO_SEGMENTATION, "No valid segmentation found!");
+    return FBG_OK;
+}

@@ -136,6 +136,9 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                   uint64_t *count_out, uint64_t *d_mml, uint64_t *d_bt);      // dp.hip
 int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
                       uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out);
+int fbg_gapped_v_from_f(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_v);
+int fbg_dp_gapped(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s, uint64_t *d_prev,
+                  uint64_t *d_boundaries, uint64_t *count_out);
 
 #define FBG_SCAN_F 0
 #define FBG_SCAN_V 1

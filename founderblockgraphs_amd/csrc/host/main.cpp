@@ -136,10 +136,31 @@ int main(int argc, char **argv)
         std::cerr << "#founders=" << st.founders << std::endl;
         std::cerr << "#edges=" << st.edges << std::endl;
     } else {
-        std::cerr << "Non-elastic mode with --gap-limit != 1 (segment2elasticValid, fbg.cpp:738-935) is not provided "
-                     "by this build.\n";
-        fbg_ctx_destroy(ctx);
-        return EXIT_FAILURE;
+        // segment2elasticValid (fbg.cpp:738-935): rows may hold gaps (runs shorter than the limit survived read_msa)
+        std::vector<uint64_t> v(msa.n), s(msa.n), prev(msa.n);
+        rc = fbg_gapped_v(ctx, msa.cells.data(), msa.m, msa.n, v.data());
+        if (rc != FBG_OK) { status = engine_failure(ctx, "fbg_gapped_v", rc); fbg_ctx_destroy(ctx); return status; }
+        std::cerr << "MSA index construction complete, index requires "
+                  << (double)fbg_device_bytes(ctx) / (1024.0 * 1024.0) << " MiB." << std::endl;
+        boundaries.resize(msa.n);
+        uint64_t count = 0;
+        rc = fbg_gapped_dp(ctx, v.data(), msa.n, s.data(), prev.data(), boundaries.data(), &count);
+        if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) {
+            status = engine_failure(ctx, "fbg_gapped_dp", rc); fbg_ctx_destroy(ctx); return status;
+        }
+        std::cerr << "Optimal score: " << s[msa.n - 1] << std::endl;                                        // 848
+        if (rc == FBG_ERR_NO_SEGMENTATION) {                                                                 // 850-854
+            std::cerr << "No valid segmentation found!\n";
+            fbg_ctx_destroy(ctx);
+            return EXIT_FAILURE;
+        }
+        boundaries.resize(count);
+        std::cerr << "Number of segments: " << boundaries.size() << std::endl;                               // 866
+        const GraphStats st = segment_stats(msa, boundaries);
+        std::cerr << "#nodes=" << st.nodes << std::endl;                                                     // 896-929
+        std::cerr << "total length of node labels=" << st.total_label_length << std::endl;
+        std::cerr << "#founders=" << st.founders << std::endl;
+        std::cerr << "#edges=" << st.edges << std::endl;
     }
     lap("segmentation (copy in, index, scan, sweep)");
     // nodes and edges of the graph come from the engine too (fbg_block_graph); ask before it goes away

@@ -114,6 +114,25 @@ int fbg_repeatfree_v(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, u
 int fbg_repeatfree_dp(fbg_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *s_out,
                       uint64_t *prev_out, uint64_t *boundaries_out, uint64_t *count_out);
 
+/*
+ * Replaces load_cst + the v[j] scan of segment2elasticValid (fbg.cpp:763-822), the non-elastic
+ * mode for --gap-limit != 1: rows may hold gaps.  v[j] = largest jp such that the gap-stripped
+ * strings of block [jp..j] occur nowhere but at the m aligned places, j+1 if there is none
+ * (fbg.cpp:764, 805-807).  v[0..n) is overwritten.
+ */
+int fbg_gapped_v(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, uint64_t *v);
+
+/*
+ * Replaces the s[]/prev[] recurrence and backtrack of segment2elasticValid (fbg.cpp:827-866),
+ * a heuristic (new block at v[j], or the previous column's solution with its last block
+ * extended), reproduced with the reference's unsigned wrap-around; s[0] = prev[0] = n+1 always
+ * (the loop starts at 1).  s_out, prev_out: n values each (may be NULL); boundaries_out: room
+ * for n values, last one is n-1.  FBG_ERR_NO_SEGMENTATION iff s[n-1] == n+1 (fbg.cpp:850-854);
+ * s/prev are still written.
+ */
+int fbg_gapped_dp(fbg_ctx *ctx, const uint64_t *v, uint64_t n, uint64_t *s_out,
+                  uint64_t *prev_out, uint64_t *boundaries_out, uint64_t *count_out);
+
 /* ---- device-resident staged API (bench, multi-GPU column shards) --------------------- */
 
 /* Borrow an MSA already resident in device memory (row-major m x n bytes). */
@@ -174,6 +193,11 @@ int fbg_minmax_dp_device(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t
                          uint64_t *count_out, uint64_t *d_mml, uint64_t *d_bt);
 int fbg_repeatfree_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
                              uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out);
+/* v[] of segment2elasticValid (fbg.cpp:763-822) for all n columns into d_v (device).  Requires
+ * fbg_index_build(reversed = 0) or a finished partitioned index, without ignore characters. */
+int fbg_scan_gapped_v(fbg_ctx *ctx, uint64_t *d_v);
+int fbg_gapped_dp_device(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d_s,
+                         uint64_t *d_prev, uint64_t *d_boundaries, uint64_t *count_out);
 /*
  * Nodes and edges of the elastic founder graph for a segmentation of the current MSA (the one last given to
  * fbg_elastic_f / fbg_msa_load_host / fbg_msa_set_device): what output_efg computes by hashing the gap-stripped

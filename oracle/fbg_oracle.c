@@ -732,6 +732,8 @@ int orc_segment_v_literal(const uint8_t *msa, int64_t m, int64_t n, uint64_t *v)
             run[bwt[r]]++;
             cnt[ix.T[r]]++;
         }
+        if ((N & ((1 << fm.stride_log) - 1)) == 0)      /* fm_occ(c, N) reads the block that starts at N */
+            memcpy(fm.occ + (size_t)(N >> fm.stride_log) * 256, run, sizeof(run));
         idx_t s = 0;
         for (int c = 0; c < 256; c++) { fm.C[c] = s; s += cnt[c]; }
         fm.C[256] = s;
@@ -880,6 +882,93 @@ int orc_segment_dp(const uint64_t *v, int64_t n_, uint64_t *s_out, uint64_t *pre
         cnt = 1;
         while (prev[j] != 0) { cnt++; j = prev[j] - 1; }                 /* 657-660 */
         if (boundaries_out) {
+            int64_t k = cnt - 1;
+            j = n - 1;
+            boundaries_out[k--] = j;
+            while (prev[j] != 0) { boundaries_out[k--] = prev[j] - 1; j = prev[j] - 1; }
+        }
+    }
+    if (count_out) *count_out = cnt;
+    if (s_out) memcpy(s_out, s, (size_t)n * sizeof(uint64_t));
+    if (prev_out) memcpy(prev_out, prev, (size_t)n * sizeof(uint64_t));
+    free(s); free(prev);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Non-elastic path with gaps: segment2elasticValid (fbg.cpp:738-866).        */
+/* Its v[j] scan (763-822) is line for line the one of segment() (552-611):   */
+/* orc_segment_v_literal above is the literal restatement of both.            */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * The formulation the HIP path uses, checked against the literal scan in tests.  Block [jp..j] passes the
+ * test of fbg.cpp:786-808 (the m BWT intervals cover exactly m suffixes) iff every row has a symbol in it
+ * and every occurrence of every row's gap-stripped string starts at some row's first symbol at or after
+ * column jp -- the condition compute_f evaluates with the elastic tricks disabled (all rows coloured,
+ * f = n when a row runs out of symbols; fbg.cpp:1605-1608, 1657-1667).  So [jp..j] passes iff F[jp] <= j,
+ * F = f without tricks.  The two-pointer only ever moves jp to the left (763-822), but the largest passing
+ * jp never decreases as j grows, so that restriction is never binding: v[j] = max{jp : F[jp] <= j}, or j+1
+ * when there is none.
+ */
+int orc_gapped_v(const uint8_t *msa, int64_t m, int64_t n, uint64_t *v)
+{
+    uint64_t *F = (uint64_t *)calloc((size_t)n, sizeof(uint64_t));
+    int64_t *best = (int64_t *)malloc((size_t)n * sizeof(int64_t));
+    if (!F || !best) { free(F); free(best); return ORC_ERR_ALLOC; }
+    uint8_t none = 0;
+    int rc = orc_compute_f(msa, m, n, &none, 0, 1, 1, F, NULL, NULL);
+    if (!rc) {
+        for (int64_t j = 0; j < n; j++) best[j] = -1;
+        for (int64_t jp = 0; jp < n; jp++)
+            if (F[jp] < (uint64_t)n && best[F[jp]] < jp) best[F[jp]] = jp;
+        int64_t cur = -1;
+        for (int64_t j = 0; j < n; j++) {
+            if (best[j] > cur) cur = best[j];
+            v[j] = cur >= 0 ? (uint64_t)cur : (uint64_t)(j + 1);
+        }
+    }
+    free(F); free(best);
+    return rc;
+}
+
+/*
+ * DP + backtrack of segment2elasticValid (fbg.cpp:827-866), statement by statement, in the reference's
+ * unsigned 64-bit arithmetic (j - prev[j-1] + 1 wraps when prev[j-1] is still n+1).  The loop starts at
+ * j = 1, so s[0] and prev[0] keep their initial n+1.  s_out / prev_out: n entries each; boundaries_out:
+ * room for n entries, last one n-1.  ORC_ERR_NO_SEGMENTATION when s[n-1] == n+1 ("No valid segmentation
+ * found!", 850-854); s and prev are still written.
+ */
+int orc_segment2_dp(const uint64_t *v, int64_t n_, uint64_t *s_out, uint64_t *prev_out,
+                    uint64_t *boundaries_out, int64_t *count_out)
+{
+    uint64_t n = (uint64_t)n_;
+    uint64_t *s = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    uint64_t *prev = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    if (!s || !prev) { free(s); free(prev); return ORC_ERR_ALLOC; }
+    for (uint64_t j = 0; j < n; j++) { s[j] = n + 1; prev[j] = n + 1; }      /* 827-829 */
+    for (uint64_t j = 1; j < n; j++) {                                       /* 830 */
+        uint64_t jp = v[j];
+        if (jp > j) continue;                                                /* 832-833 */
+        if (jp == 0) { s[j] = j + 1; prev[j] = 0; continue; }                /* 834-837 */
+        uint64_t len_new = j - jp + 1, len_ext = j - prev[j - 1] + 1;        /* wraps, as in the reference */
+        uint64_t a = s[jp - 1] > len_new ? s[jp - 1] : len_new;
+        uint64_t b = s[j - 1] > len_ext ? s[j - 1] : len_ext;
+        if (a < b) { s[j] = a; prev[j] = jp; }                               /* 838-841 */
+        else { s[j] = b; prev[j] = prev[j - 1]; }                            /* 842-845 */
+    }
+    int rc = 0;
+    int64_t cnt = 0;
+    if (s[n - 1] == n + 1) {                                                 /* 850-854 */
+        rc = ORC_ERR_NO_SEGMENTATION;
+    } else {
+        uint64_t j = n - 1;
+        cnt = 1;
+        while (prev[j] != 0) {                                               /* 857-862 */
+            if (prev[j] > j || cnt > n_) { rc = ORC_ERR_NO_SEGMENTATION; cnt = 0; break; }   /* the reference would leave the array */
+            cnt++; j = prev[j] - 1;
+        }
+        if (!rc && boundaries_out) {
             int64_t k = cnt - 1;
             j = n - 1;
             boundaries_out[k--] = j;

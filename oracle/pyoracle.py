@@ -45,10 +45,13 @@ def lib(path=None):
     L.orc_segment_v_literal.argtypes = [u8p, C.c_int64, C.c_int64, u64p]
     L.orc_segment_v.argtypes = [u8p, C.c_int64, C.c_int64, u64p, dp, dp]
     L.orc_segment_dp.argtypes = [u64p, C.c_int64, u64p, u64p, u64p, i64p]
+    L.orc_gapped_v.argtypes = [u8p, C.c_int64, C.c_int64, u64p]
+    L.orc_segment2_dp.argtypes = [u64p, C.c_int64, u64p, u64p, u64p, i64p]
     L.orc_write_xgfa.argtypes = [u8p, C.c_int64, C.c_int64, u64p, C.c_int64, C.c_int, u8p, i64p, C.c_char_p]
     L.orc_segment_stats.argtypes = [u8p, C.c_int64, C.c_int64, u64p, C.c_int64, u64p]
     for f in ("orc_suffix_array", "orc_msa_index", "orc_compute_f", "orc_compute_f_literal",
               "orc_minmax_dp", "orc_segment_v_literal", "orc_segment_v", "orc_segment_dp",
+              "orc_gapped_v", "orc_segment2_dp",
               "orc_write_xgfa", "orc_segment_stats"):
         getattr(L, f).restype = C.c_int
     if path is None:
@@ -170,6 +173,34 @@ def segment_dp(v):
     cnt = C.c_int64(0)
     rc = lib().orc_segment_dp(_p(v, C.c_uint64), n, _p(s, C.c_uint64), _p(prev, C.c_uint64),
                               _p(b, C.c_uint64), C.byref(cnt))
+    if rc == ORC_ERR_NO_SEGMENTATION:
+        return s, prev, None
+    _chk(rc)
+    return s, prev, b[:cnt.value].copy()
+
+
+def gapped_v(msa, literal=False):
+    """v[] of segment2elasticValid (fbg.cpp:763-822); literal = the two-pointer over BWT intervals."""
+    msa = np.ascontiguousarray(msa, dtype=np.uint8)
+    m, n = msa.shape
+    v = np.empty(n, dtype=np.uint64)
+    if literal:
+        _chk(lib().orc_segment_v_literal(_p(msa, C.c_uint8), m, n, _p(v, C.c_uint64)))
+    else:
+        _chk(lib().orc_gapped_v(_p(msa, C.c_uint8), m, n, _p(v, C.c_uint64)))
+    return v
+
+
+def segment2_dp(v):
+    """segment2elasticValid's DP (fbg.cpp:827-866) -> (s, prev, boundaries or None)."""
+    v = np.ascontiguousarray(v, dtype=np.uint64)
+    n = len(v)
+    s = np.empty(n, dtype=np.uint64)
+    prev = np.empty(n, dtype=np.uint64)
+    b = np.empty(n, dtype=np.uint64)
+    cnt = C.c_int64(0)
+    rc = lib().orc_segment2_dp(_p(v, C.c_uint64), n, _p(s, C.c_uint64), _p(prev, C.c_uint64),
+                               _p(b, C.c_uint64), C.byref(cnt))
     if rc == ORC_ERR_NO_SEGMENTATION:
         return s, prev, None
     _chk(rc)

@@ -27,7 +27,7 @@ def star_msa(m, n, p=0.01, seed=7):
     return out.reshape(-1)
 
 
-def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_fraction=0.0, star=False, reps=2):
+def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_fraction=0.0, star=False, reps=2, gapped=False):
     eng = F.Engine(0)
     st = torch.cuda.Stream()
     torch.cuda.set_stream(st)
@@ -44,9 +44,12 @@ def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_frac
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.msa_set_device(d.data_ptr(), m, n)
-        eng.index_build(reversed=not elastic, ignorechars=ignore)
+        eng.index_build(reversed=not (elastic or gapped), ignorechars=ignore)
         d_f.zero_()
-        if elastic:
+        if gapped:       # segment2elasticValid: non-elastic mode, rows with gaps
+            eng.scan_gapped_v(d_f.data_ptr())
+            blocks = eng.gapped_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        elif elastic:
             eng.scan_f(0, n, d_f.data_ptr())
             blocks = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
         else:
@@ -71,6 +74,11 @@ if __name__ == "__main__":
         run("C2 64x100k non-elastic", 64, 100_000, elastic=False)
     if "c5" in which:
         run("C5 256x2M gaps+N elastic ignore=N", 256, 2_000_000, ignore="N", gap_fraction=0.05, gap_run=16, n_fraction=0.001)
+    if "c5gapped" in which:
+        run("C5-shaped 256x2M gaps, non-elastic (segment2elasticValid)", 256, 2_000_000, elastic=False, gapped=True,
+            gap_fraction=0.05, gap_run=16)
+    if "c3gapped" in which:
+        run("C3 1000x1M, non-elastic through segment2elasticValid", 1000, 1_000_000, elastic=False, gapped=True)
     if "star" in which:
         run("star phylogeny 1000x200k p=0.01", 1000, 200_000, star=True)
     if "star1m" in which:

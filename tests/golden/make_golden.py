@@ -31,6 +31,8 @@ CASES = [
     dict(seed=7, m=12, n=4000, kw=dict(alphabet="AC", similar=0.995)),
     dict(seed=8, m=64, n=3000, kw={}, nonelastic=True),
     dict(seed=9, m=10, n=900, kw=dict(similar=0.9), nonelastic=True),
+    dict(seed=10, m=16, n=2500, kw=dict(gap_p=0.02, gap_run=4), nonelastic=True, gapped=True),
+    dict(seed=11, m=40, n=1200, kw=dict(similar=0.9, gap_p=0.01, gap_run=7), nonelastic=True, gapped=True),
 ]
 
 
@@ -44,8 +46,15 @@ def run_case(c):
     out["msa_sha256"] = hashlib.sha256(msa.tobytes()).hexdigest()
     small = c["m"] * c["n"] <= 4000
     if c.get("nonelastic"):
-        v = O.segment_v(msa)
-        s, prev, b = O.segment_dp(v)
+        if c.get("gapped"):      # segment2elasticValid (fbg.cpp:738-866)
+            if c["seed"] == 10:
+                msa[:, 0] = np.arange(c["m"]) % 4 + ord("E")      # a first block exists: the heuristic finds a segmentation
+            v = O.gapped_v(msa)
+            s, prev, b = O.segment2_dp(v)
+            out["msa_sha256"] = hashlib.sha256(msa.tobytes()).hexdigest()
+        else:
+            v = O.segment_v(msa)
+            s, prev, b = O.segment_dp(v)
         out.update(v=digest(v), s=digest(s), prev=digest(prev), boundaries=None if b is None else b.tolist())
         if b is not None:
             out["stats"] = O.segment_stats(msa, b)

@@ -167,3 +167,33 @@ def test_cli_nonelastic_stats(tmp_path):
                  "#founders=2", "#edges=2"):
         assert line in text
     assert rc == 1     # no defined .index output at this commit of the reference (see main.cpp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(4))
+def test_cli_gapped_nonelastic_stats(case, tmp_path):
+    """Non-elastic mode with --gap-limit != 1 -> segment2elasticValid (fbg.cpp:3438-3439): score, segment count and
+    graph statistics on stderr (738-929), then the same undefined make_efg call as the gap-free mode."""
+    rng = np.random.default_rng(500 + case)
+    m, n, kw, limit = [(6, 120, dict(gap_p=0.03, gap_run=2), 0), (12, 400, dict(gap_p=0.02, gap_run=3), 5),
+                       (30, 900, dict(similar=0.9, gap_p=0.01, gap_run=4), 6), (3, 40, dict(gap_p=0.3), 0)][case]
+    msa = random_msa(rng, m, n, **kw)
+    msa[:, 0] = np.arange(m) % 4 + ord("E")          # rows start differently: a first block exists quickly
+    src = tmp_path / "in.fasta"
+    write_fasta(src, msa, [f"r{i}" for i in range(m)])
+    from fasta_util import read_fasta
+    kept, _ = read_fasta(str(src), elastic=False, gap_limit=limit)
+    rc, _, se = run(BIN, "--input", str(src), "--output", str(tmp_path / "o.index"), f"--gap-limit={limit}")
+    text = se.decode()
+    v = O.gapped_v(kept)
+    s, prev, b = O.segment2_dp(v)
+    assert f"Input MSA[1..{kept.shape[0]},1..{n}]" in text
+    assert f"Optimal score: {int(s[-1])}" in text
+    if b is None:
+        assert rc == 1 and "No valid segmentation found!" in text
+        return
+    st = O.segment_stats(kept, b)
+    for line in (f"Number of segments: {len(b)}", f"#nodes={st['nodes']}", f"total length of node labels={st['total_label_length']}",
+                 f"#founders={st['founders']}", f"#edges={st['edges']}"):
+        assert line in text
+    assert rc == 1     # no defined .index output at this commit of the reference (see main.cpp)

@@ -229,10 +229,16 @@ def test_committed_oracle_vectors(engine):
     path = os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")
     for c in json.load(open(path)):
         msa = random_msa(np.random.default_rng(c["seed"]), c["m"], c["n"], **c["kw"])
+        if c.get("gapped") and c["seed"] == 10:
+            msa[:, 0] = np.arange(c["m"]) % 4 + ord("E")
         assert hashlib.sha256(msa.tobytes()).hexdigest() == c["msa_sha256"]
         if c.get("nonelastic"):
-            v = engine.repeatfree_v(msa)
-            s, prev, b = engine.repeatfree_dp(v)
+            if c.get("gapped"):
+                v = engine.gapped_v(msa)
+                s, prev, b = engine.gapped_dp(v)
+            else:
+                v = engine.repeatfree_v(msa)
+                s, prev, b = engine.repeatfree_dp(v)
             assert digest(v) == c["v"] and digest(s) == c["s"] and digest(prev) == c["prev"]
             assert (None if b is None else b.tolist()) == c["boundaries"]
         else:
@@ -811,3 +817,105 @@ def test_msd_sort_capacity_fallback_is_seamless(engine, alphabet):
         assert np.array_equal(engine.elastic_f(small), O.compute_f(small))
     finally:
         del os.environ["FBG_MSD_MIN"]
+
+
+# ---- non-elastic mode with gaps: segment2elasticValid (fbg.cpp:738-866) ------------------------------------
+
+def _check_gapped(engine, msa, literal=False):
+    v = O.gapped_v(msa, literal=literal)
+    gv = engine.gapped_v(msa)
+    assert np.array_equal(gv, v)
+    s, prev, b = O.segment2_dp(v)
+    gs, gprev, gb = engine.gapped_dp(gv)
+    assert np.array_equal(gs, s) and np.array_equal(gprev, prev)
+    assert (b is None) == (gb is None)
+    if b is not None:
+        assert np.array_equal(gb, b)
+    return b
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_reference_fixtures_gapped_nonelastic(engine, name):
+    msa = O.msa_array(FIXTURES[name])
+    assert _check_gapped(engine, msa, literal=True) is None      # the heuristic finds nothing for the reference's fixtures
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_gapped_nonelastic(engine, case):
+    rng = np.random.default_rng(700 + case)
+    m, n, kw = [(2, 15, dict(gap_p=0.1)), (4, 200, dict(gap_p=0.05, gap_run=3)), (64, 700, dict(gap_p=0.02, gap_run=8)),
+                (10, 500, dict(similar=0.9, gap_p=0.03, gap_run=4)), (3, 400, dict(alphabet="AC", gap_p=0.05)),
+                (1, 50, dict(gap_p=0.2)), (100, 300, dict(similar=0.97, gap_p=0.01, gap_run=20)), (5, 1, {}),
+                (40, 3000, {}), (200, 2500, dict(gap_p=0.004, gap_run=16))][case]
+    msa = random_msa(rng, m, n, **kw)
+    _check_gapped(engine, msa, literal=m * n <= 4000)
+
+
+def test_gapped_nonelastic_small_exhaustive(engine):
+    """Tiny inputs with many gaps, empty rows and repeats: the cases where a segmentation exists must be among them."""
+    rng = np.random.default_rng(77)
+    solved = 0
+    for it in range(300):
+        m, n = int(rng.integers(1, 7)), int(rng.integers(1, 15))
+        alpha = ["AC", "ACGT", "A"][it % 3]
+        msa = random_msa(rng, m, n, alphabet=alpha, gap_p=[0.0, 0.1, 0.3][it % 3 if it % 2 else 0])
+        solved += _check_gapped(engine, msa, literal=True) is not None
+    assert solved > 20
+
+
+def test_gapped_dp_on_arbitrary_v(engine):
+    """The recurrence alone, on v arrays the scan would never produce: far lookbacks (beyond the LDS ring of the
+    kernel), columns without a block in the middle, n around the tile size, v[0] = 0."""
+    rng = np.random.default_rng(78)
+    for n in (1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 20000, 70000):
+        for mode in range(5):
+            j = np.arange(n, dtype=np.int64)
+            if mode == 0:      # short blocks, first block from column 0
+                v = np.maximum(0, j - rng.integers(0, 6, n))
+                v[: min(n, 4)] = 0
+            elif mode == 1:    # monotone like the real thing, long blocks
+                v = np.maximum.accumulate(np.maximum(0, j - rng.integers(0, 300, n)))
+                v[: min(n, 300)] = 0
+            elif mode == 2:    # holes: columns where no block ends
+                v = np.maximum(0, j - rng.integers(0, 20, n))
+                v[rng.random(n) < 0.3] = n + 5
+                v[: min(n, 2)] = 0
+            elif mode == 3:    # far lookbacks
+                v = np.maximum(0, j - rng.integers(0, 30000, n))
+            else:              # nothing works
+                v = j + 1
+            v = v.astype(np.uint64)
+            s, prev, b = O.segment2_dp(v)
+            gs, gprev, gb = engine.gapped_dp(v)
+            assert np.array_equal(gs, s) and np.array_equal(gprev, prev), (n, mode)
+            assert (b is None) == (gb is None)
+            if b is not None:
+                assert np.array_equal(gb, b)
+
+
+def test_gapped_nonelastic_large(engine):
+    """C5-shaped input (gap runs of 16 over 5 % of the cells) at a size the oracle still does in seconds, and the
+    v derivation at a larger one against the same derivation in numpy from the engine's own f."""
+    rng = np.random.default_rng(79)
+    msa = random_msa(rng, 64, 60000, gap_p=0.05 / 16, gap_run=16)
+    _check_gapped(engine, msa)
+    msa = random_msa(rng, 128, 400000, gap_p=0.05 / 16, gap_run=16)
+    n = msa.shape[1]
+    gv = engine.gapped_v(msa)
+    import founderblockgraphs_amd as Fm
+    try:
+        F = engine.elastic_f(msa, disable_efg_tricks=True)
+    except Fm.NoSegmentation:        # f[0] == n (fbg.cpp:1932-1937): not with this input
+        F = None
+    assert F is not None
+    if F is not None:
+        best = np.full(n, -1, dtype=np.int64)
+        ok = F < n
+        np.maximum.at(best, F[ok].astype(np.int64), np.nonzero(ok)[0])
+        run = np.maximum.accumulate(best)
+        exp = np.where(run >= 0, run, np.arange(n) + 1).astype(np.uint64)
+        assert np.array_equal(gv, exp)
+    s, prev, b = O.segment2_dp(gv)
+    gs, gprev, gb = engine.gapped_dp(gv)
+    assert np.array_equal(gs, s) and np.array_equal(gprev, prev)
+    assert (b is None) == (gb is None) and (b is None or np.array_equal(gb, b))

@@ -2,6 +2,7 @@
 and against brute-force definition checkers.  The oracle is test infrastructure (oracle/)."""
 import json
 import os
+import random
 
 import numpy as np
 import pytest
@@ -229,3 +230,105 @@ def test_xgfa_edge_cases(tmp_path):
     assert x["S"] == ["AC", "TT", "GT", "GA"]
     assert x["L"] == [[0, 1], [1, 2]]           # rows a, b have no node in block 2 -> no edge into block 3
     assert x["P"] == {"a": [0, 2], "b": [0, 3], "c": [0, 1, 2]}
+
+
+# ---- non-elastic mode with gaps: segment2elasticValid (fbg.cpp:738-866) -------------------------------------
+
+def brute_gapped_v(rows):
+    """fbg.cpp:763-822 by definition: the union of the occurrence sets (by start position in T) of the rows'
+    gap-stripped strings has exactly m members; an empty string occurs at all N = |T|+1 suffixes."""
+    m, n = len(rows), len(rows[0])
+    T = "".join(r.replace("-", "") + "#" for r in rows)
+    N = len(T) + 1
+
+    def occ(p):
+        if p == "":
+            return set(range(N))
+        out, k = set(), T.find(p)
+        while k >= 0:
+            out.add(k)
+            k = T.find(p, k + 1)
+        return out
+    v, jp = [0] * n, n
+    for j in range(n - 1, -1, -1):
+        v[j] = j + 1
+        while True:
+            u = set()
+            for r in rows:
+                u |= occ(r[jp:j + 1].replace("-", ""))
+            if len(u) == m:
+                v[j] = jp
+                break
+            if jp == 0:
+                break
+            jp -= 1
+    return v
+
+
+def brute_segment2_dp(v):
+    """fbg.cpp:827-846 in explicit arithmetic modulo 2^64."""
+    n, M = len(v), 1 << 64
+    s, prev = [n + 1] * n, [n + 1] * n
+    for j in range(1, n):
+        jp = v[j]
+        if jp > j:
+            continue
+        if jp == 0:
+            s[j], prev[j] = j + 1, 0
+            continue
+        a = max(s[jp - 1], (j - jp + 1) % M)
+        b = max(s[j - 1], (j - prev[j - 1] + 1) % M)
+        if a < b:
+            s[j], prev[j] = a, jp
+        else:
+            s[j], prev[j] = b, prev[j - 1]
+    return s, prev
+
+
+@pytest.mark.parametrize("name", ["msa.fasta", "test.fasta", "test2.fasta", "test3.fasta"])
+def test_golden_gapped_nonelastic(name):
+    """--gap-limit=0 keeps every row (fbg.cpp:105-106) and runs segment2elasticValid (3438-3439)."""
+    msa, _ = read_fasta(os.path.join(GOLD, name), elastic=False, gap_limit=0)
+    exp = APPX[name]["nonelastic_gap_limit_0"]
+    for literal in (False, True):
+        assert O.gapped_v(msa, literal=literal).tolist() == exp["v"]
+    s, prev, b = O.segment2_dp(np.array(exp["v"], dtype=np.uint64))
+    assert s.tolist() == exp["s"] and prev.tolist() == exp["prev"]
+    assert (None if b is None else b.tolist()) == exp["boundaries"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gapped_v_and_dp_vs_bruteforce(seed):
+    rng = random.Random(900 + seed)
+    solved = 0
+    for it in range(150):
+        m, n = rng.randint(1, 6), rng.randint(1, 14)
+        sig = rng.choice(["AC", "ACGT", "A"])
+        pg = rng.choice([0, 0.1, 0.3, 0.6])
+        rows = ["".join("-" if rng.random() < pg else rng.choice(sig) for _ in range(n)) for _ in range(m)]
+        if it % 3 == 0:
+            rows = ["".join(c if rng.random() > 0.2 else rng.choice(sig + "-") for c in rows[0]) for _ in range(m)]
+        msa = O.msa_array(rows)
+        exp = brute_gapped_v(rows)
+        assert O.gapped_v(msa, literal=True).tolist() == exp, rows
+        assert O.gapped_v(msa).tolist() == exp, rows
+        s, prev, b = O.segment2_dp(np.array(exp, dtype=np.uint64))
+        es, ep = brute_segment2_dp(exp)
+        assert s.tolist() == es and prev.tolist() == ep, rows
+        assert (b is None) == (es[-1] == n + 1)
+        if b is not None:
+            solved += 1
+            # every block of the answer passes the reference's own test: it starts at or before v[end]
+            lo = 0
+            for e in b.tolist():
+                assert lo <= exp[e] <= e
+                lo = e + 1
+            assert b[-1] == n - 1
+    assert solved > 10
+
+
+def test_literal_scan_text_length_multiple_of_64():
+    """N = 64: the occurrence table of the literal scan needs its closing block."""
+    rows = ['AACACCAAAACC', 'AACACCAAAACC', 'CACACCAAAACC', 'AACACCAAAAC-', 'AACCCC-AAACC']
+    msa = O.msa_array(rows)
+    assert O.gapped_v(msa, literal=True).tolist() == brute_gapped_v(rows) == O.gapped_v(msa).tolist()
