@@ -83,6 +83,8 @@ int main(int argc, char **argv)
         return EXIT_FAILURE;
     }
 
+    if (opt.threads > 0) set_host_threads((unsigned)opt.threads);
+
     fbg_ctx *ctx = nullptr;
     int rc = fbg_ctx_create(0, &ctx);
     if (rc != FBG_OK) {

@@ -9,6 +9,9 @@
 #include <mutex>
 #include <thread>
 
+static unsigned g_host_threads = 0;      // 0 = as many as the machine has, at most 16
+void set_host_threads(unsigned t) { g_host_threads = t; }
+
 namespace {
 
 // Labels of one block: gap-stripped MSA[i].substr(prev, end-prev+1), std::string::substr clamping
@@ -171,6 +174,7 @@ template <class Make> bool ordered_parallel_write(FILE *fp, uint64_t units, Make
     unsigned T = std::thread::hardware_concurrency();
     if (T == 0) T = 1;
     if (T > 16) T = 16;
+    if (g_host_threads && g_host_threads < T) T = g_host_threads;
     if ((uint64_t)T > units) T = (unsigned)units;
     const uint64_t window = 4 * (uint64_t)T;
     std::vector<Chunk> slot(window);

@@ -17,6 +17,9 @@ struct BlockGraph {
     std::vector<uint64_t> first_node;           // [nb + 1]
     std::vector<uint64_t> edge_count, edges;    // [nb], [nb * m]
 };
+// --threads=T of the reference sets the threads of its scan (fbg.cpp:3395); the scan runs on the GPU here, so T
+// bounds the host threads that format the xGFA instead (0 = machine default).
+void set_host_threads(unsigned t);
 bool write_xgfa_graph(const Msa &msa, const std::vector<uint64_t> &boundaries, const BlockGraph &g, bool output_paths,
                       const std::string &path, std::string &error);
 
