@@ -203,12 +203,15 @@ __global__ void k_mark_heads(const uint64_t *__restrict__ keys, uint64_t cnt, co
 }
 
 // number of equal leading symbols of two K-symbol keys (b bits per symbol, right aligned in key_bits)
-__device__ __forceinline__ uint32_t key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
+__device__ __forceinline__ uint32_t key_lcp_inv(uint64_t a, uint64_t c, uint32_t inv_b, int key_bits)
 {
     const uint64_t d = a ^ c;
     const uint32_t bits = (uint32_t)(__clzll((long long)d) - (64 - key_bits));
-    const uint32_t inv_b = (65536u + (uint32_t)b - 1) / (uint32_t)b;   // exact for numerators <= 64
     return (bits * inv_b) >> 16;
+}
+__device__ __forceinline__ uint32_t key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
+{
+    return key_lcp_inv(a, c, (65536u + (uint32_t)b - 1) / (uint32_t)b, key_bits);   // exact for numerators <= 64
 }
 
 // Run hint of two SA-adjacent positions: can both be the pointer of an active row in one column?
@@ -270,6 +273,242 @@ __global__ void k_apply_groups0(const uint32_t *__restrict__ grp, const uint32_t
     }
     rec[p] = make_uint4(g, lp, ln, 0u);
     flags[k] = !(head && next_head);
+}
+
+// ---- the same records without a random scatter -------------------------------------------------------------
+// rec[p] = ... above writes 16 bytes at a random place per suffix: every one of them a read-modify-write of a memory
+// line (36 ms for 5*10^8 suffixes).  The positions are a permutation of 0..N-1, so the way back to text order is a
+// sort whose bucket sizes are known exactly beforehand: two splitting passes on the leading bits of p (tiles
+// regrouped in LDS and written in runs, as msd_sort.hip does; every bucket owns precisely the stretch of the
+// positions it covers, no capacities to bet on) and a last pass that drops each leaf of 4096 positions into place
+// inside LDS and writes it out whole.  5 x 16 bytes of streamed traffic per suffix instead: 18 ms for the same input.
+#define BP_THREADS 1024                        // 512-thread tiles (two workgroups per CU) were 30 % slower: shorter runs
+#define BP_ITEMS 8
+#define BP_TILE (BP_THREADS * BP_ITEMS)
+#define BP_MAXD 1024
+#define BP_LEAF_BITS 12
+#define BP_LEAF (1u << BP_LEAF_BITS)
+
+struct BpArgs {
+    uint64_t N;
+    int shift;                       // bucket of an element = p >> shift; its stretch starts at bucket << shift
+    uint32_t nd;                     // buckets a tile can meet (power of two): LDS digit = bucket & (nd - 1)
+    const uint4 *in;                 // pass B: stretches of 1 << seg_shift elements
+    int seg_shift;
+    uint32_t tiles_per_seg;
+    uint4 *out;
+    unsigned long long *cursor;      // [N >> shift + 1], zeroed: fill of every bucket
+    unsigned long long *flag;
+    // pass A makes its elements from the sorted keys (k_apply_groups0)
+    const uint32_t *grp, *vals;
+    const uint64_t *keys;
+    int b, key_bits;
+    ColTest ct;
+    uint8_t *flags;
+    // MSAs with gaps: first column and number of gaps of every window of BP_WIN text positions (no row end inside),
+    // from which a position's column span is bounded without touching colT
+    const uint2 *win;
+    const uint32_t *win_lo;          // exact lower end of the span of every window's first position
+};
+
+#define BP_WIN_BITS 10
+#define BP_WIN (1u << BP_WIN_BITS)
+#define BP_WIN_NONE 0xffffffffu
+
+// one wave per window: a window that holds a '#' or the sentinel (column n) bounds nothing
+__global__ __launch_bounds__(256) void k_bp_windows(const uint32_t *__restrict__ colT, uint64_t N, uint32_t n,
+                                                    uint2 *__restrict__ win, uint32_t *__restrict__ win_lo)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lo = w << BP_WIN_BITS;
+    if (lo >= N) return;
+    const uint64_t hi = min(N, lo + BP_WIN);
+    bool bad = false;
+    for (uint64_t q = lo + lane; q < hi; q += 64) bad = bad || colT[q] >= n;
+    if (lane == 0) { const uint32_t cp = lo > 0 ? colT[lo - 1] : n; win_lo[w] = cp >= n ? 0u : cp + 1; }   // as ColTest::span
+    if (__ballot(bad)) { if (lane == 0) win[w] = make_uint2(BP_WIN_NONE, 0u); return; }
+    if (lane == 0) {
+        const uint32_t first = colT[lo], last = colT[hi - 1];
+        win[w] = make_uint2(first, last - first - (uint32_t)(hi - 1 - lo));
+    }
+}
+
+// an interval that contains the column span of text position p (ColTest::span), from the window tables alone
+__device__ __forceinline__ uint2 bp_span_bound(const BpArgs &a, uint32_t p)
+{
+    if (p == a.ct.last) return make_uint2(1u, 0u);
+    const uint32_t o = p & (BP_WIN - 1);
+    const uint2 w = a.win[p >> BP_WIN_BITS];
+    if (w.x == BP_WIN_NONE) return make_uint2(0u, a.ct.n);
+    // the window's first position is every 1024th: with a loose lower end half of them would go on to the exact test
+    return make_uint2(o ? w.x + o : a.win_lo[p >> BP_WIN_BITS], w.x + o + w.y);
+}
+
+// e[r] (valid for r with j = threadIdx.x + r * BP_THREADS < have; e.x = position) -> runs in the buckets' stretches
+__device__ __forceinline__ void bp_regroup_write(const BpArgs &a, uint4 (&e)[BP_ITEMS], uint32_t have, uint4 *buf, uint32_t *cnt,
+                                                 uint32_t *loff, unsigned long long *gbase, uint32_t *wsum)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t rk[BP_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * BP_THREADS;
+        rk[r] = j < have ? atomicAdd(&cnt[(e[r].x >> a.shift) & (a.nd - 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    {   // exclusive offsets of the digit counts; one global atomic per non-empty digit reserves its run
+        const uint32_t c = cnt[threadIdx.x];                       // BP_THREADS == BP_MAXD
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+        loff[threadIdx.x] = pre + inc - c;
+        gbase[threadIdx.x] = 0;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * BP_THREADS;
+        if (j < have) {
+            const uint32_t d = (e[r].x >> a.shift) & (a.nd - 1);
+            buf[loff[d] + rk[r]] = e[r];
+            if (rk[r] == 0) {                                      // first of its digit in this tile: reserve the run
+                const uint64_t bucket = (uint64_t)e[r].x >> a.shift;
+                gbase[d] = (bucket << a.shift) + atomicAdd(&a.cursor[bucket], (unsigned long long)cnt[d]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * BP_THREADS;
+        if (j < have) {
+            const uint4 x = buf[j];
+            const uint32_t d = (x.x >> a.shift) & (a.nd - 1);
+            const uint64_t at = gbase[d] + (j - loff[d]);
+            const uint64_t end = min(a.N, (((uint64_t)x.x >> a.shift) + 1) << a.shift);
+            if (at < end) a.out[at] = x;
+            else *a.flag = 1;                                      // cannot happen for a permutation
+        }
+    }
+}
+
+// first splitting pass: k_apply_groups0's record of every suffix, sent towards its position instead of written there.
+// (As two kernels -- a streaming one that writes the records in suffix order, then k_bp_split over the whole array --
+// the same work took 15 ms instead of 12.)
+__global__ __launch_bounds__(BP_THREADS) void k_bp_groups0(BpArgs a)
+{
+    __shared__ uint4 buf[BP_TILE];
+    __shared__ uint32_t cnt[BP_MAXD], loff[BP_MAXD];
+    __shared__ unsigned long long gbase[BP_MAXD];
+    __shared__ uint32_t wsum[BP_THREADS / 64];
+    const uint64_t first = (uint64_t)blockIdx.x * BP_TILE;
+    const uint32_t have = (uint32_t)min((uint64_t)BP_TILE, a.N - first);
+    cnt[threadIdx.x] = 0;
+    uint4 e[BP_ITEMS];
+    // all loads of the tile first, then the window tables, then keys and spans of the whole tile into LDS, where every
+    // element finds its two SA neighbours (the tile's first and last element fetch theirs from memory)
+    const bool bounded = a.ct.colT != nullptr;
+    const uint32_t inv_b = (65536u + (uint32_t)a.b - 1) / (uint32_t)a.b;
+    uint32_t gg[BP_ITEMS], pp[BP_ITEMS];
+    uint64_t key[BP_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * BP_THREADS;
+        const uint64_t k = first + j;
+        const bool in = j < have;
+        gg[r] = in ? a.grp[k] : 0u;
+        pp[r] = in ? a.vals[k] : a.ct.last;
+        key[r] = in ? a.keys[k] : 0ull;
+    }
+    uint2 sp[BP_ITEMS];
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        // the run hints need the column spans of SA neighbours.  With gaps a span costs two reads of colT at a random
+        // place: bounds from the window tables (small enough to stay in L2) rule nearly every pair out first
+        sp[r] = bounded ? bp_span_bound(a, pp[r]) : a.ct.span(pp[r]);
+        buf[threadIdx.x + r * BP_THREADS] = make_uint4((uint32_t)key[r], (uint32_t)(key[r] >> 32), sp[r].x, sp[r].y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * BP_THREADS;
+        const uint64_t k = first + j;
+        const bool in = j < have;
+        const uint32_t p = pp[r];
+        uint32_t lp = 0, ln = 0;
+        const bool head = gg[r] == (uint32_t)k;
+        bool next_head = true;
+        if (in && k > 0) {
+            uint64_t kp;
+            uint2 sprev;
+            if (j > 0) { const uint4 q = buf[j - 1]; kp = (uint64_t)q.y << 32 | q.x; sprev = make_uint2(q.z, q.w); }
+            else { kp = a.keys[k - 1]; const uint32_t pq = a.vals[k - 1]; sprev = bounded ? bp_span_bound(a, pq) : a.ct.span(pq); }
+            if (kp != key[r]) {
+                uint32_t hint = ColTest::meet(sprev, sp[r]);
+                if (hint && bounded) hint = a.ct.same(a.vals[k - 1], p);
+                lp = key_lcp_inv(kp, key[r], inv_b, a.key_bits) | hint;
+            }
+        }
+        if (in && k + 1 < a.N) {
+            uint64_t kn;
+            uint2 snext;
+            if (j + 1 < have) { const uint4 q = buf[j + 1]; kn = (uint64_t)q.y << 32 | q.x; snext = make_uint2(q.z, q.w); }
+            else { kn = a.keys[k + 1]; const uint32_t pq = a.vals[k + 1]; snext = bounded ? bp_span_bound(a, pq) : a.ct.span(pq); }
+            next_head = kn != key[r];
+            if (next_head) {
+                uint32_t hint = ColTest::meet(sp[r], snext);
+                if (hint && bounded) hint = a.ct.same(p, a.vals[k + 1]);
+                ln = key_lcp_inv(key[r], kn, inv_b, a.key_bits) | hint;
+            }
+        }
+        e[r] = make_uint4(p, gg[r], lp, ln);
+        if (in) a.flags[k] = !(head && next_head);
+    }
+    bp_regroup_write(a, e, have, buf, cnt, loff, gbase, wsum);
+}
+
+// second splitting pass: a stretch of the first, tile by tile, by the next bits of the position
+__global__ __launch_bounds__(BP_THREADS) void k_bp_split(BpArgs a)
+{
+    __shared__ uint4 buf[BP_TILE];
+    __shared__ uint32_t cnt[BP_MAXD], loff[BP_MAXD];
+    __shared__ unsigned long long gbase[BP_MAXD];
+    __shared__ uint32_t wsum[BP_THREADS / 64];
+    const uint64_t seg = blockIdx.x / a.tiles_per_seg;
+    const uint64_t seg_lo = seg << a.seg_shift, seg_hi = min(a.N, (seg + 1) << a.seg_shift);
+    const uint64_t first = seg_lo + (uint64_t)(blockIdx.x % a.tiles_per_seg) * BP_TILE;
+    cnt[threadIdx.x] = 0;
+    uint4 e[BP_ITEMS];
+    const uint32_t have = first < seg_hi ? (uint32_t)min((uint64_t)BP_TILE, seg_hi - first) : 0u;
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * BP_THREADS;
+        e[r] = j < have ? a.in[first + j] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (have == 0) return;                                         // uniform
+    bp_regroup_write(a, e, have, buf, cnt, loff, gbase, wsum);
+}
+
+// last pass: the BP_LEAF positions of a leaf, each dropped at its own place in LDS, leave as finished records
+__global__ __launch_bounds__(512) void k_bp_leaf(const uint4 *__restrict__ in, uint64_t N, uint4 *__restrict__ rec,
+                                                 unsigned long long *__restrict__ flag)
+{
+    __shared__ uint32_t sg[BP_LEAF], sl[BP_LEAF], sn[BP_LEAF];
+    const uint64_t lo = (uint64_t)blockIdx.x << BP_LEAF_BITS;
+    const uint32_t have = (uint32_t)min((uint64_t)BP_LEAF, N - lo);
+    for (uint32_t j = threadIdx.x; j < have; j += blockDim.x) {
+        const uint4 x = in[lo + j];
+        const uint32_t i = x.x - (uint32_t)lo;
+        if (i < have) { sg[i] = x.y; sl[i] = x.z; sn[i] = x.w; }
+        else *flag = 1;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < have; j += blockDim.x) rec[lo + j] = make_uint4(sg[j], sl[j], sn[j], 0u);
 }
 
 // doubling rounds: new group heads -> rank word of the records, suffix array slots, unresolved flags
@@ -580,9 +819,51 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
         return rocprim::inclusive_scan(tmp, bytes, grp, grp, (size_t)N, rocprim::maximum<uint32_t>(), st);
     }));
-    hipLaunchKernelGGL(k_apply_groups0, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, grp, valsB, keysB, N, b, key_bits,
-                       ct, rec, flags);
-    launches += 4;
+    // FBG_BP_MIN lowers the size from which the records travel to their positions in passes (tests); FBG_RECORD_SCATTER
+    // keeps the direct scatter
+    const uint64_t bp_min = getenv("FBG_BP_MIN") ? strtoull(getenv("FBG_BP_MIN"), nullptr, 10) : (1ull << 24);
+    const bool by_position = N >= bp_min && N > 2 * BP_LEAF && N <= 1500000000ull && !getenv("FBG_RECORD_SCATTER");
+    if (by_position) {
+        int bits = 0;
+        while ((1ull << bits) < N) bits++;
+        const int S = bits - BP_LEAF_BITS, d1 = (S + 1) / 2, d2 = S - d1;      // two splitting passes, then leaves
+        FBG_TRY(fbg_reserve(ctx, ctx->msd_w, N * 16));
+        FBG_TRY(fbg_reserve(ctx, ctx->msd_v, N * 16));
+        const uint64_t nleaf = (N + BP_LEAF - 1) >> BP_LEAF_BITS, ntop = (N >> (d2 + BP_LEAF_BITS)) + 1;
+        const uint64_t nwin = (N >> BP_WIN_BITS) + 1;
+        FBG_TRY(fbg_reserve(ctx, ctx->list, (ntop + nleaf + 2) * 8 + 3 * nwin * 4));
+        unsigned long long *cur1 = ctx->list.as<unsigned long long>(), *cur2 = cur1 + ntop + 1;
+        uint2 *win = reinterpret_cast<uint2 *>(cur1 + ntop + nleaf + 2);
+        uint32_t *win_lo = reinterpret_cast<uint32_t *>(win + nwin);
+        if (ct.colT) {
+            hipLaunchKernelGGL(k_bp_windows, dim3(fbg_blocks(nwin, 4)), dim3(256), 0, st, ct.colT, N, ct.n, win, win_lo);
+            launches++;
+        }
+        unsigned long long *bflag = ctx->scalars.as<unsigned long long>() + 120;
+        FBG_HIP_TRY(ctx, hipMemsetAsync(cur1, 0, (ntop + nleaf + 2) * 8, st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(bflag, 0, 8, st));
+        BpArgs a;
+        a.N = N; a.flag = bflag;
+        a.grp = grp; a.vals = valsB; a.keys = keysB; a.b = b; a.key_bits = key_bits; a.ct = ct; a.flags = flags;
+        a.win = win; a.win_lo = win_lo;
+        a.shift = d2 + BP_LEAF_BITS; a.nd = 1u << d1; a.in = nullptr; a.seg_shift = 0; a.tiles_per_seg = 0;
+        a.out = ctx->msd_w.as<uint4>(); a.cursor = cur1;
+        hipLaunchKernelGGL(k_bp_groups0, dim3(fbg_blocks(N, BP_TILE)), dim3(BP_THREADS), 0, st, a);
+        a.in = ctx->msd_w.as<uint4>(); a.seg_shift = d2 + BP_LEAF_BITS;
+        a.tiles_per_seg = (uint32_t)(((1ull << a.seg_shift) + BP_TILE - 1) / BP_TILE);
+        a.shift = BP_LEAF_BITS; a.nd = 1u << d2; a.out = ctx->msd_v.as<uint4>(); a.cursor = cur2;
+        hipLaunchKernelGGL(k_bp_split, dim3((unsigned)(ntop * a.tiles_per_seg)), dim3(BP_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_bp_leaf, dim3((unsigned)nleaf), dim3(512), 0, st, ctx->msd_v.as<uint4>(), N, rec, bflag);
+        unsigned long long hf = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&hf, bflag, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        launches += 6;
+        if (hf != 0) return fbg_fail(ctx, FBG_ERR_HIP, "records by position: the sorted positions are not a permutation");
+    } else {
+        hipLaunchKernelGGL(k_apply_groups0, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, grp, valsB, keysB, N, b, key_bits,
+                           ct, rec, flags);
+        launches += 4;
+    }
 
     // ---- doubling rounds on the unresolved suffixes ----------------------------------------
     // state of the compacted list (in SA order): where[k] = SA index, vals[k] = position, grp[k]

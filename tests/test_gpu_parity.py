@@ -388,6 +388,9 @@ ALT_PATHS = [
     {"FBG_FORCE_WIDE": "1"},                         # ... on wide pairs (the layout for texts beyond 2^32 symbols)
     {"FBG_MSD_MIN": "1"},                            # three-pass MSD sort (msd_sort.hip) also for small texts
     {"FBG_NO_MSD_SORT": "1"},                        # rocPRIM's onesweep instead of it
+    {"FBG_BP_MIN": "1"},                             # records reach their text positions through splitting passes ...
+    {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},       # ... also for gap-free MSAs
+    {"FBG_RECORD_SCATTER": "1"},                     # ... or by a direct scatter whatever the size
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
     {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
@@ -919,3 +922,33 @@ def test_gapped_nonelastic_large(engine):
     gs, gprev, gb = engine.gapped_dp(gv)
     assert np.array_equal(gs, s) and np.array_equal(gprev, prev)
     assert (b is None) == (gb is None) and (b is None or np.array_equal(gb, b))
+
+
+def test_records_by_position_passes(engine):
+    """The record path's way back from suffix order to text order (k_bp_groups0 / k_bp_split / k_bp_leaf): index arrays
+    against the oracle with the passes forced on small texts, and a gapped MSA large enough to take them by itself."""
+    import os
+    rng = np.random.default_rng(31)
+    old = {k: os.environ.get(k) for k in ("FBG_BP_MIN", "FBG_NO_RANKED")}
+    os.environ.update({"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"})
+    try:
+        for (m, n, kw) in [(7, 1300, dict(gap_p=0.03, gap_run=5)), (33, 257, dict(similar=0.95)), (3, 3000, dict(alphabet="AC", similar=0.99)),
+                           (65, 1290, dict(alphabet="ACGTN")), (2, 4097, {}), (9, 70000, dict(gap_p=0.01, gap_run=3))]:
+            msa = random_msa(rng, m, n, **kw)
+            T, SA, ISA, LCP = O.msa_index(msa)
+            engine.msa_load_host(msa)
+            engine.index_build()
+            gT, gSA, gISA, gPL, gPR = engine.index_download()
+            assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64)), (m, n)
+            assert np.array_equal(gISA.astype(np.int64), ISA.astype(np.int64)), (m, n)
+            lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
+            assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA]), (m, n)
+            assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1]), (m, n)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    msa = random_msa(rng, 24, 800000, gap_p=0.05 / 16, gap_run=16, n_p=0.001)      # 1.9 * 10^7 symbols > 2^24
+    assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), O.compute_f(msa, ignore="N", threads=8))
