@@ -2,7 +2,7 @@
 // (key word u64 + low position word u32; pairs / wide layouts) and only the suffixes whose key lies in this
 // partition's range [lo, hi).
 //
-// Buckets cannot be bit fields of the key here (the range is arbitrary): t = floor((key - lo) * 2^27 / (hi - lo)),
+// Buckets cannot be bit fields of the key here (the range is arbitrary): t = floor((key - lo) * 2^28 / (hi - lo)),
 // one 64x64->128 multiply, is monotone in the key, and its three 9-bit digits serve as bucket, sub-bucket and finish
 // bin.  Pass 1 is fused with key packing and filtering: a workgroup walks as many 4096-position tiles as there are
 // partitions, so that it collects about 4096 slots of its range before it regroups and writes them.  Passes 2 and 3
@@ -27,7 +27,8 @@ struct PpArgs {
     const uint8_t *code;
     int b, K, pb, nparts;
     int wide;                                  // key word = key << pb | position >> 32 (else the plain key, pb = 0)
-    uint64_t lo, hi, mul;                      // key range (hi ignored when nohi), t = umul64hi(key - lo, mul) < 2^27
+    int packed;                                // 8-byte slots: key << pb | position, no second array (texts below 2^32)
+    uint64_t lo, hi, mul;                      // key range (hi ignored when nohi), t = umul64hi(key - lo, mul) < 2^28
     int nohi;
     uint64_t *w1; uint32_t *v1; uint64_t cap1; unsigned long long *count1;      // pass 1 output: PP_NB stretches
     const uint32_t *tile_start;
@@ -38,7 +39,9 @@ struct PpArgs {
     unsigned long long *flag;
 };
 
-__device__ __forceinline__ uint32_t pp_t27(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
+// t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
+__device__ __forceinline__ uint32_t pp_t28(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
+#define PP_FBINS 1024
 
 // scan of PP_NB counts (one per thread) + run reservation, as msd_scan_and_reserve
 __device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *loff, unsigned long long *gbase, uint32_t *wsum,
@@ -103,20 +106,29 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
         __syncthreads();
         uint64_t key[MSD_ITEMS];
         msd_build_keys(tile, threadIdx.x * MSD_ITEMS, a.b, a.K, key);
+        // the slots this thread keeps, then one place reservation per wave (not one per item)
+        uint32_t km = 0;
 #pragma unroll
         for (int i = 0; i < MSD_ITEMS; i++) {
             const uint64_t p = base + (uint64_t)threadIdx.x * MSD_ITEMS + i;
-            const bool keep = p < a.N && key[i] >= a.lo && (a.nohi || key[i] < a.hi);
-            const unsigned long long m = __ballot(keep);
-            if (m) {
-                uint32_t at = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if (lane == leader) at = atomicAdd(&staged, (uint32_t)__popcll(m));
-                at = __shfl(at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                if (keep) {
-                    if (at < PP_STAGE) { sw[at] = a.wide ? (key[i] << a.pb) | (p >> 32) : key[i]; sv[at] = (uint32_t)p; }
-                    else *a.flag = 1;
-                }
+            if (p < a.N && key[i] >= a.lo && (a.nohi || key[i] < a.hi)) km |= 1u << i;
+        }
+        const uint32_t mine = (uint32_t)__popc(km);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        uint32_t at = 0;
+        if (lane == 63 && inc) at = atomicAdd(&staged, inc);
+        at = __shfl(at, 63, 64) + inc - mine;
+#pragma unroll
+        for (int i = 0; i < MSD_ITEMS; i++) {
+            if ((km >> i) & 1u) {
+                const uint64_t p = base + (uint64_t)threadIdx.x * MSD_ITEMS + i;
+                if (at < PP_STAGE) {
+                    sw[at] = a.packed ? (key[i] << a.pb) | p : a.wide ? (key[i] << a.pb) | (p >> 32) : key[i];
+                    sv[at] = a.packed ? 0u : (uint32_t)p;
+                } else *a.flag = 1;
+                at++;
             }
         }
     }
@@ -124,12 +136,12 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
     const uint32_t have = min(staged, (uint32_t)PP_STAGE);
     uint64_t w[PP_STAGE / PP_THREADS];
     uint32_t v[PP_STAGE / PP_THREADS], rk[PP_STAGE / PP_THREADS];
-    pp_regroup<PP_STAGE>(sw, sv, cnt, have, [&](uint64_t x) { return pp_t27(a, x) >> 18; }, w, v, rk);
+    pp_regroup<PP_STAGE>(sw, sv, cnt, have, [&](uint64_t x) { return pp_t28(a, x) >> 19; }, w, v, rk);
     pp_scan_and_reserve(cnt, loff, gbase, wsum, a.count1, nullptr);
 #pragma unroll
     for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[pp_t27(a, w[r]) >> 18] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[pp_t28(a, w[r]) >> 19] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
 #pragma unroll
@@ -137,9 +149,9 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
             const uint64_t x = sw[j];
-            const uint32_t d = pp_t27(a, x) >> 18;
+            const uint32_t d = pp_t28(a, x) >> 19;
             const uint64_t at = gbase[d] + (j - loff[d]);
-            if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
+            if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; if (!a.packed) a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
             else *a.flag = 1;
         }
     }
@@ -185,19 +197,19 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         w[r] = j < have ? inw[j] : 0ull;
-        v[r] = j < have ? inv[j] : 0u;
+        v[r] = (j < have && !a.packed) ? inv[j] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        rk[r] = j < have ? atomicAdd(&cnt[(pp_t27(a, w[r]) >> 9) & (PP_NB - 1)], 1u) : 0u;
+        rk[r] = j < have ? atomicAdd(&cnt[(pp_t28(a, w[r]) >> 10) & (PP_NB - 1)], 1u) : 0u;
     }
     __syncthreads();
     pp_scan_and_reserve(cnt, loff, gbase, wsum, nullptr, a.count2 + (size_t)seg * PP_NB);
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[(pp_t27(a, w[r]) >> 9) & (PP_NB - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[(pp_t28(a, w[r]) >> 10) & (PP_NB - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
 #pragma unroll
@@ -205,13 +217,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
             const uint64_t x = sw[j];
-            const uint32_t d = (pp_t27(a, x) >> 9) & (PP_NB - 1);
+            const uint32_t d = (pp_t28(a, x) >> 10) & (PP_NB - 1);
             const uint64_t at = gbase[d] + (j - loff[d]);
             const uint64_t sb = (uint64_t)seg * PP_NB + d;
-            if (at < PP_FN_CAP) { a.w2[sb * PP_FN_CAP + at] = x; a.v2[sb * PP_FN_CAP + at] = sv[j]; }
+            if (at < PP_FN_CAP) { a.w2[sb * PP_FN_CAP + at] = x; if (!a.packed) a.v2[sb * PP_FN_CAP + at] = sv[j]; }
             else {
                 const unsigned long long e = atomicAdd(a.arena_count, 1ull);
-                if (e < PP_ARENA) { a.arena_sb[e] = (uint32_t)sb; a.arena_w[e] = x; a.arena_v[e] = sv[j]; }
+                if (e < PP_ARENA) { a.arena_sb[e] = (uint32_t)sb; a.arena_w[e] = x; a.arena_v[e] = sv[j]; }      // sv: zeros when packed
                 else *a.flag = 1;
             }
         }
@@ -232,7 +244,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
                                                const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
-    cnt[threadIdx.x] = 0;                                      // PP_NB bins, PP_THREADS == PP_NB
+    cnt[2 * threadIdx.x] = 0; cnt[2 * threadIdx.x + 1] = 0;    // PP_FBINS bins, two per thread
     __syncthreads();
     uint64_t w[ITEMS];
     uint32_t v[ITEMS], rk[ITEMS];
@@ -240,17 +252,17 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         w[r] = j < have ? (j < n_a ? wa[j] : wb[j - n_a]) : ~0ull;
-        v[r] = j < have ? (j < n_a ? va[j] : vb[j - n_a]) : 0u;
+        v[r] = (j < have && !a.packed) ? (j < n_a ? va[j] : vb[j - n_a]) : 0u;
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        rk[r] = j < have ? atomicAdd(&cnt[pp_t27(a, w[r]) & (PP_NB - 1)], 1u) : 0u;
+        rk[r] = j < have ? atomicAdd(&cnt[pp_t28(a, w[r]) & (PP_FBINS - 1)], 1u) : 0u;
     }
     __syncthreads();
     {
         const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const uint32_t c = cnt[threadIdx.x];
+        const uint32_t c0 = cnt[2 * threadIdx.x], c = c0 + cnt[2 * threadIdx.x + 1];
         uint32_t inc = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
@@ -258,20 +270,21 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         __syncthreads();
         uint32_t pre = 0;
         for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
-        loff[threadIdx.x] = pre + inc - c;
+        loff[2 * threadIdx.x] = pre + inc - c;
+        loff[2 * threadIdx.x + 1] = pre + inc - c + c0;
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[pp_t27(a, w[r]) & (PP_NB - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[pp_t28(a, w[r]) & (PP_FBINS - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
-            const uint32_t bin = pp_t27(a, w[r]) & (PP_NB - 1);
+            const uint32_t bin = pp_t28(a, w[r]) & (PP_FBINS - 1);
             const uint32_t b0 = loff[bin], c = cnt[bin];
             uint32_t smaller = 0;
             for (uint32_t q = 0; q < c; q++) {
@@ -291,7 +304,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { wout[j] = sw[j]; vout[j] = sv[j]; }
+        if (j < have) { wout[j] = sw[j]; if (!a.packed) vout[j] = sv[j]; }
     }
 }
 
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a)
 {
     __shared__ uint64_t sw[PP_FN_CAP];
     __shared__ uint32_t sv[PP_FN_CAP];
-    __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
+    __shared__ uint32_t cnt[PP_FBINS], loff[PP_FBINS];
     __shared__ uint32_t wsum[PP_THREADS / 64];
     const uint32_t have = a.count2[blockIdx.x];
     if (have == 0 || have > PP_FN_CAP) return;                 // the larger ones: k_pp_finish_big
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const ui
     // gw / gv: the arena entries gathered in sb_sorted order (k_pp_gather)
     __shared__ uint64_t sw[PP_BIG_CAP];
     __shared__ uint32_t sv[PP_BIG_CAP];
-    __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
+    __shared__ uint32_t cnt[PP_FBINS], loff[PP_FBINS];
     __shared__ uint32_t wsum[PP_THREADS / 64];
     const uint32_t e = blockIdx.x;
     if (e >= entries) return;
@@ -348,21 +361,21 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     *ok = 0;
     const uint64_t N = ctx->N;
     const uint64_t min_n = getenv("FBG_MSD_MIN") ? strtoull(getenv("FBG_MSD_MIN"), nullptr, 10) : (1ull << 24);
-    if (!g.compact || g.packed || N / nparts < min_n || getenv("FBG_NO_MSD_SORT")) return FBG_OK;
+    if (!g.compact || N / nparts < min_n || getenv("FBG_NO_MSD_SORT")) return FBG_OK;
     const uint64_t top = g.key_bits >= 64 ? ~0ull : (1ull << g.key_bits);
     const uint64_t span = (nohi ? top : hi) - lo;
-    if (span < (1ull << 28) || g.key_bits >= 64) return FBG_OK;       // t needs 27 bits of resolution below the span
+    if (span < (1ull << 29) || g.key_bits >= 64) return FBG_OK;       // t needs 28 bits of resolution below the span
     const unsigned __int128 one = 1;
-    const uint64_t mul = (uint64_t)((one << 91) / span);               // < 2^64 since span > 2^27
+    const uint64_t mul = (uint64_t)((one << 92) / span);               // < 2^64 since span > 2^28
     hipStream_t st = ctx->stream;
     const uint64_t est = N / nparts + N / (64 * (uint64_t)nparts) + 65536;   // the partitions are quantiles of a sample: sizes within a percent
     const uint64_t cap1 = est / PP_NB + est / (4 * PP_NB) + 65536;
     const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
     if (est / nsub + est / (8 * nsub) + 64 > PP_FN_CAP) return FBG_OK;
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)PP_NB * cap1 * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->valsA, (size_t)PP_NB * cap1 * 4));
+    if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsA, (size_t)PP_NB * cap1 * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->msd_w, (size_t)nsub * PP_FN_CAP * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->msd_v, (size_t)nsub * PP_FN_CAP * 4));
+    if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->msd_v, (size_t)nsub * PP_FN_CAP * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_a, PP_NB * 8 + (PP_NB + 1) * 4 + 64));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_b, nsub * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (nsub + 1) * 8 * 2));
@@ -370,8 +383,8 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     FBG_TRY(fbg_reserve(ctx, ctx->dp_e, (size_t)PP_ARENA * 8 * 2));
     unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;      // [0] flag, [1] arena count, [2] total
     PpArgs a;
-    a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = g.wide ? g.pb : 0; a.nparts = nparts;
-    a.wide = g.wide ? 1 : 0;
+    a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = (g.wide || g.packed) ? g.pb : 0; a.nparts = nparts;
+    a.wide = g.wide ? 1 : 0; a.packed = g.packed ? 1 : 0;
     a.lo = lo; a.hi = hi; a.mul = mul; a.nohi = nohi;
     a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
     a.count1 = ctx->dp_a.as<unsigned long long>();
@@ -400,7 +413,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     if (h3[0] != 0 || tiles2 == 0) return FBG_OK;
     const uint64_t total = h3[2];
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, (total + 2 * out_offset) * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->valsB, (total + 2 * out_offset) * 4));
+    if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsB, (total + 2 * out_offset) * 4));
     a.wout = ctx->keysB.as<uint64_t>() + out_offset; a.vout = ctx->valsB.as<uint32_t>() + out_offset;
     hipLaunchKernelGGL(k_pp_split, dim3(tiles2), dim3(PP_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_pp_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 bash scripts/gpu_bench_full.sh || exit 1
 bash scripts/gpu_pmc.sh || exit 1
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python scripts/gpu_configs.py c2 c5 star > gpurun_out/configs.log 2>&1 || { tail gpurun_out/configs.log; exit 1; }
+timeout -k 10 600 python scripts/gpu_configs.py c2 c5 c5gapped star > gpurun_out/configs.log 2>&1 || { tail gpurun_out/configs.log; exit 1; }
 grep "{" gpurun_out/configs.log | cut -c1-500
 timeout -k 10 500 python scripts/gpu_part_sim.py 2 > gpurun_out/part_sim2.log 2>&1 || { tail gpurun_out/part_sim2.log; exit 1; }
 tail -1 gpurun_out/part_sim2.log

@@ -765,15 +765,18 @@ def test_block_graph_matches_reference_numbering(engine, case):
         assert got == r_edges[j], j
 
 
+@pytest.mark.parametrize("layout", ["wide", "packed"])
 @pytest.mark.parametrize("P", [2, 3])
-def test_partitioned_index_msd_sort_of_pairs(P):
-    """msd_sort_pairs.hip (the partitions' three-pass sort of 12-byte slots), forced on small inputs: long keys in wide
-    slots so that the bucket function has its 27 bits of resolution."""
+def test_partitioned_index_msd_sort_of_pairs(P, layout):
+    """msd_sort_pairs.hip (the partitions' three-pass sort of 12-byte slots, or of packed 8-byte words), forced on small
+    inputs: long keys so that the bucket function has its 27 bits of resolution."""
     import os
     import torch
     from founderblockgraphs_amd import Engine
     rng = np.random.default_rng(555 + P)
-    env = {"FBG_FORCE_WIDE": "1", "FBG_FULL_KEYS": "1", "FBG_MSD_MIN": "1"}
+    env = {"FBG_FULL_KEYS": "1", "FBG_MSD_MIN": "1"}
+    if layout == "wide":
+        env["FBG_FORCE_WIDE"] = "1"
     os.environ.update(env)
     engines = [Engine() for _ in range(P)]
     try:
