@@ -7,12 +7,16 @@ One "step" = one pass of the hot path over one synthetic MSA already resident in
     [N>1: an all-gather of 1.5 KB per rank and one all-reduce(max) of n+1 words, see below]
     min-max-length sweep + backtrack (rank 0)                       -> fbg.cpp:1940-2039
 Workload at N=1: BASELINE config C3, synthetic 1000 rows x 1,000,000 columns, iid ACGT
-(SURVEY.md 8d generator), --elastic.  N>1: weak scaling, 1,000,000 columns per GPU.  While the text
-fits 32-bit positions (N<=4) every rank holds the whole text but sorts and scans only its own key
-range of the suffixes (key-range partitioned index, founderblockgraphs_amd/distributed.py); if a rank
-finds its input unsuitable all ranks fall back to the replicated index with column shards
-(--replicated-index forces it).  Beyond that (N=8, text 8e9) the exact row-group-pair
-plan is used (one all-reduce(max) of f).
+(SURVEY.md 8d generator), --elastic.  N>1: weak scaling, 1,000,000 columns per GPU: every rank holds
+the whole MSA and text but sorts and scans only its own key range of the suffixes (key-range
+partitioned index, founderblockgraphs_amd/distributed.py; texts of 2^32 symbols and more -- N >= 5 --
+included).  If a rank finds its input unsuitable all ranks fall back together: to the replicated
+index with column shards (--replicated-index forces it) while the text fits 32-bit
+positions, else to the exact row-group-pair plan (one all-reduce(max) of f).
+
+The sweep of step i runs on a context and stream of its own on rank 0, beside the index build of
+step i+1 (it is a chain of small launches that would leave the GPU -- at N>1 all GPUs -- idle); all
+of it is joined before the closing barrier, inside the timed region.  --serial-sweep switches that off.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the extension-scan kernel (k_rank_scan; k_scan_stream
 when the MSA has gaps): algorithmic bytes = (13*m + 8) per column over its HIP-event
@@ -98,6 +102,7 @@ def main():
     ap.add_argument("--force-row-pairs", type=int, default=0, help="debug: use the row-group-pair plan with this many rows per pair text")
     ap.add_argument("--replicated-index", action="store_true", help="N>1: every rank builds the whole index (column shards) instead of one key range of it")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: several ranks on one GPU)")
+    ap.add_argument("--serial-sweep", action="store_true", help="debug: run the sweep of a step before the next step starts (no second stream)")
     args = ap.parse_args()
 
     import torch
@@ -127,9 +132,45 @@ def main():
     torch.cuda.set_stream(stream)
     eng.set_stream(stream.cuda_stream)
 
-    d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_fs = [torch.zeros(n, dtype=torch.int64, device="cuda") for _ in range(2)]
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
-    state = {}
+    state = {"step": 0}
+
+    # The sweep of a step (sort of the extensions, min-max DP, backtrack: fbg.cpp:1940-2039) is a chain of small,
+    # latency-bound launches on rank 0.  It runs on a context and stream of its own, beside the index build of the
+    # NEXT step (at N > 1 the other ranks would otherwise idle through it); f is double-buffered, and everything is
+    # joined before the closing fence, so all of its work lies inside the timed region.
+    class Sweeper:
+        def __init__(self):
+            from concurrent.futures import ThreadPoolExecutor
+            self.eng = F.Engine(dev)
+            self.stream = torch.cuda.Stream()
+            self.eng.set_stream(self.stream.cuda_stream)
+            self.pool = ThreadPoolExecutor(max_workers=1)
+            self.pending = None
+
+        def submit(self, d_f):
+            self.join()
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.stream.wait_event(ev)
+            # ctypes drops the GIL for the duration of the call: the main thread goes on to the next step
+            self.pending = self.pool.submit(self.eng.minmax_dp_device, d_f.data_ptr(), n, d_b.data_ptr())
+
+        def join(self):
+            if self.pending is not None:
+                state["blocks"] = self.pending.result()
+                self.pending = None
+
+    sweeper = Sweeper() if rank == 0 and not args.serial_sweep else None
+
+    def sweep(d_f):
+        if rank != 0:
+            return
+        if sweeper is not None:
+            sweeper.submit(d_f)
+        else:
+            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
     fits32 = m * (n + 1) + 1 < (1 << 32) - 1
     want_partition = world > 1 and not args.replicated_index and not args.force_row_pairs
     x0, x1 = D.shard_range(n, rank, world)
@@ -148,9 +189,10 @@ def main():
         if not D.partitioned_index(eng, n, rank, world):
             return False
         if rank == 0:
+            d_f = d_fs[state["step"] & 1]
             d_f.zero_()
             eng.scan_f(0, n, d_f.data_ptr())
-            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+            sweep(d_f)
         return True
 
     def step_replicated():
@@ -158,11 +200,13 @@ def main():
         d_msa = whole_msa()
         eng.msa_set_device(d_msa.data_ptr(), m, n)
         eng.index_build()
+        d_f = d_fs[state["step"] & 1]
         d_f.zero_()
         eng.scan_f(x0, x1, d_f.data_ptr())
         f_full = D.all_gather_columns(d_f[x0:x1], n, rank, world)   # the one exchange of the path
-        if rank == 0:
-            state["blocks"] = eng.minmax_dp_device(f_full.data_ptr(), n, d_b.data_ptr())
+        if f_full.data_ptr() != d_f.data_ptr():
+            d_f.copy_(f_full)                                       # the sweep reads the step's own buffer
+        sweep(d_f)
 
     def step_row_pairs():
         """Text too long for 32-bit positions on one GPU: exact row-group-pair plan, one all-reduce(max) of f."""
@@ -173,6 +217,7 @@ def main():
             rows_pair = max((groups[a][1] - groups[a][0]) + (groups[b][1] - groups[b][0]) for a, b in D.group_pairs(G))
             bufs["plan"] = (G, groups, plan[rank], rows_pair, torch.empty(rows_pair * n, dtype=torch.uint8, device="cuda"))
         G, groups, mine, rows_pair, d_msa = bufs["plan"]
+        d_f = d_fs[state["step"] & 1]
         d_f.zero_()
         for a, b in mine:
             off = 0
@@ -184,12 +229,12 @@ def main():
             eng.index_build()
             eng.scan_f(0, n, d_f.data_ptr())
         D.all_reduce_max(d_f)
-        if rank == 0:
-            state["blocks"] = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+        sweep(d_f)
 
     state["path"] = "partitioned" if want_partition else ("replicated" if fits32 and not args.force_row_pairs else "row_pairs")
 
     def step():
+        state["step"] += 1
         if state["path"] == "partitioned":
             if step_partitioned():
                 return
@@ -200,6 +245,8 @@ def main():
             step_row_pairs()
 
     def fence():
+        if sweeper is not None:
+            sweeper.join()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -212,7 +259,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        torch.cuda.synchronize()
+        stream.synchronize()                       # this step's own stream only: the sweep may still be running
         for k, (ms, ln) in eng.stage_ms().items():
             a = stage_acc.setdefault(k, [0.0, 0])
             a[0] += ms
@@ -256,6 +303,9 @@ def main():
                                            "passes, FETCH_SIZE doubled as the guide prescribes for gfx950: equals one read of every slot)",
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
+            "sweep": ("serial" if sweeper is None else
+                      {"overlapped_with": "the next step's index build (own context and stream on rank 0)",
+                       "dp_ms_last_step": sweeper.eng.stage_ms().get("dp", (0.0, 0))[0]}),
             "device_bytes": eng.device_bytes(),
         }
         if not args.no_cpu_baseline and world == 1:
@@ -263,6 +313,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    if sweeper is not None:
+        sweeper.pool.shutdown()
+        sweeper.eng.close()
     eng.close()
     if world > 1:
         dist.destroy_process_group()
