@@ -12,3 +12,5 @@ timeout -k 10 500 python scripts/gpu_part_sim.py 2 > gpurun_out/part_sim2.log 2>
 tail -1 gpurun_out/part_sim2.log
 timeout -k 10 500 python scripts/gpu_part_sim.py 4 > gpurun_out/part_sim4.log 2>&1 || { tail gpurun_out/part_sim4.log; exit 1; }
 tail -1 gpurun_out/part_sim4.log
+timeout -k 10 500 python scripts/gpu_part_sim.py 8 1000000 --sequential > gpurun_out/part_sim8.log 2>&1 || { tail gpurun_out/part_sim8.log; exit 1; }
+tail -1 gpurun_out/part_sim8.log
