@@ -17,15 +17,20 @@ from founderblockgraphs_amd._lib import PART_HALO_BYTES
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 ENVS = [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_MSD_MIN": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"},
-        {"FBG_NO_RANKED": "1"}, {"FBG_FULL_KEYS": "1"}, {"FBG_MSD_MIN": "1", "FBG_FORCE_WIDE": "1", "FBG_FULL_KEYS": "1"}]
+        {"FBG_NO_RANKED": "1"}, {"FBG_FULL_KEYS": "1"}, {"FBG_MSD_MIN": "1", "FBG_FORCE_WIDE": "1", "FBG_FULL_KEYS": "1"},
+        {"FBG_MSD_MIN": "1", "FBG_FULL_KEYS": "1"}, {"FBG_BP_MIN": "1"}, {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"}]
 ALL_KEYS = sorted({k for e in ENVS for k in e})
 eng = F.Engine(0)
 parts = [F.Engine(0) for _ in range(3)]
 t0 = time.time()
+last_note = t0
 it = 0
 while time.time() - t0 < budget:
     seed = seed0 + it
     it += 1
+    if time.time() - last_note > 30:
+        last_note = time.time()
+        print(f"... {it} cases, {time.time() - t0:.0f} s", flush=True)
     rng = np.random.default_rng(seed)
     m = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 400]))
     n = int(rng.choice([1, 2, 7, 33, 100, 257, 1000, 3000]))
@@ -57,6 +62,13 @@ while time.time() - t0 < budget:
                 assert int(first[-1]) > 0, "graph"
         except F.NoSegmentation:
             assert tricks_off and f[0] == n, "no segmentation"
+        # non-elastic mode with gaps (segment2elasticValid): v[] and its chain DP
+        gv = eng.gapped_v(msa)
+        assert np.array_equal(gv, O.gapped_v(msa, literal=m * n <= 3000)), "gapped v"
+        s2, p2, b2 = O.segment2_dp(gv)
+        gs2, gp2, gb2 = eng.gapped_dp(gv)
+        assert np.array_equal(gs2, s2) and np.array_equal(gp2, p2), "gapped dp"
+        assert (b2 is None) == (gb2 is None) and (b2 is None or np.array_equal(gb2, b2)), "gapped boundaries"
         if not gaps:
             v = O.segment_v(msa)
             assert np.array_equal(eng.repeatfree_v(msa), v), "v"
