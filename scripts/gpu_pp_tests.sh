@@ -5,8 +5,5 @@ timeout -k 10 800 python -m pytest tests -m gpu -x -q -k "partitioned" 2>&1 | ta
 rc=$?
 cat gpurun_out/pp.log
 [ $rc -eq 0 ] || exit $rc
-bash scripts/gpu_prof_part.sh 2
+bash scripts/gpu_prof_part.sh 8 1000000 --sequential
 f=$(find gpurun_out/prof_part -name "*kernel_stats.csv" | head -1); grep -h "k_pp_" $f | cut -d, -f1-4
-cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python scripts/gpu_part_sim.py 8 1000000 --sequential > gpurun_out/part_sim8.log 2>&1 || { tail gpurun_out/part_sim8.log; exit 1; }
-tail -2 gpurun_out/part_sim8.log
