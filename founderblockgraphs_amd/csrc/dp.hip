@@ -1042,8 +1042,10 @@ __global__ __launch_bounds__(64) void k_dp_gapped(const uint64_t *__restrict__ v
 #pragma unroll
     for (uint32_t q = 0; q < GD_TILES; q++) nxt[q] = fetch(q * 64);
     for (uint32_t g0 = 0; g0 < n; g0 += 64 * GD_TILES) {
+        // the prefetched columns are settled here, once per group: left to the compiler, the wait for them lands in front
+        // of every tile's walk, and a wait for loads is a wait for the previous tile's stores as well
 #pragma unroll
-        for (uint32_t q = 0; q < GD_TILES; q++) cur[q] = nxt[q];
+        for (uint32_t q = 0; q < GD_TILES; q++) { cur[q] = nxt[q]; asm volatile("" : "+v"(cur[q])); }
         if (g0 + 64 * GD_TILES < n) {
 #pragma unroll
             for (uint32_t q = 0; q < GD_TILES; q++) nxt[q] = fetch(g0 + 64 * GD_TILES + q * 64);
@@ -1064,6 +1066,7 @@ __global__ __launch_bounds__(64) void k_dp_gapped(const uint64_t *__restrict__ v
             if (__ballot(far)) {
                 __threadfence();
                 if (far) aext = __hip_atomic_load(s + look, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0) here, in the rare branch, not in the walk below
             }
             const uint32_t len_new = j - vj + 1;
             uint32_t s_vec = INV, p_vec = INV;
