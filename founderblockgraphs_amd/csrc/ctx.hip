@@ -113,6 +113,9 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
     }
+    if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+    if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -26,6 +26,10 @@ struct fbg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream for work that only raises column maxima (k_tie_simple) beside the candidate kernels
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    bool aux_pending = false;
     std::string err;
     uint64_t held_bytes = 0;
 

@@ -786,6 +786,29 @@ template <class F> static int rs_with_tmp(fbg_ctx *ctx, F &&call)
                else hipLaunchKernelGGL((k_rank_scan<FBG_SLOTS_PAIRS, false>), grid, blk_, 0, st, args); }                                  \
     } while (0)
 
+// k_tie_simple only raises column maxima (atomicMax) from slots no other kernel of the scan writes: it runs on a second
+// stream beside the candidate kernels (compaction, sort, tie groups, runs -- small, latency-bound launches).
+static int rs_fork(fbg_ctx *ctx)
+{
+    if (!ctx->aux) {
+        FBG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        FBG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+        FBG_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+    }
+    FBG_HIP_TRY(ctx, hipEventRecord(ctx->aux_fork, ctx->stream));
+    FBG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->aux_fork, 0));
+    ctx->aux_pending = true;
+    return FBG_OK;
+}
+static int rs_join(fbg_ctx *ctx)
+{
+    if (!ctx->aux_pending) return FBG_OK;
+    ctx->aux_pending = false;
+    FBG_HIP_TRY(ctx, hipEventRecord(ctx->aux_join, ctx->aux));
+    FBG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
+    return FBG_OK;
+}
+
 static int rs_layout(const KeyGeom &g) { return g.packed ? FBG_SLOTS_PACKED : g.wide ? FBG_SLOTS_WIDE : FBG_SLOTS_PAIRS; }
 
 static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *vals, uint64_t slots, int layout, int pb, int b,
@@ -839,7 +862,12 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
-    RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
+    if (getenv("FBG_NO_AUX_STREAM")) {
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
+    } else {
+        FBG_TRY(rs_fork(ctx));
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a);
+    }
     *launches += 2;
     // candidate counts per workgroup -> offsets; total and the largest count come back to the host
     uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
@@ -856,7 +884,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint64_t T = tot;
     *T_out = T;
-    if (mx > region) { *T_out = ~0ull; return FBG_OK; }
+    if (mx > region) { *T_out = ~0ull; return rs_join(ctx); }
     if (T > 0) {
         // candidates in SA order; tie groups first (final order), then the runs
         FBG_TRY(fbg_reserve(ctx, ctx->dp_a, T * 4));
@@ -942,6 +970,7 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
         RS_LAUNCH(k_runs, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);
         launches++;
     }
+    FBG_TRY(rs_join(ctx));
     unsigned long long h[5];
     // a large tie group / an overflowing tie region -> record path; a column without a value lost all its rows
     // to the threshold -> redo without it
@@ -1037,6 +1066,7 @@ int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_
     if (good) {
         uint64_t T = 0;
         FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
+        FBG_TRY(rs_join(ctx));
         if (T == ~0ull) good = 0;
         else {
             ctx->part_T = T;
