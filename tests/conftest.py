@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The library, the host programs and the oracle are build products (git-ignored): a checkout that has not seen
+    __graft_entry__.build() yet gets them built here (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    pkg = os.path.join(ROOT, "founderblockgraphs_amd")
+    need = [os.path.join(pkg, "libfbg_hip.so"), os.path.join(pkg, "founderblockgraph"), os.path.join(pkg, "fbg_options_dump")]
+    if not all(os.path.exists(f) for f in need):
+        subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-j8"], check=True, stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+
+
 def random_msa(rng, m, n, alphabet="ACGT", gap_p=0.0, gap_run=1, similar=0.0, n_p=0.0):
     """Random MSA as (m, n) uint8.  similar>0: rows are noisy copies of one ancestor
     (long runs of consecutive suffix ranks); gap_p: fraction of cells that start a gap run."""
