@@ -955,3 +955,28 @@ def test_records_by_position_passes(engine):
                 os.environ[k] = v
     msa = random_msa(rng, 24, 800000, gap_p=0.05 / 16, gap_run=16, n_p=0.001)      # 1.9 * 10^7 symbols > 2^24
     assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), O.compute_f(msa, ignore="N", threads=8))
+
+
+def test_gapped_v_on_a_partitioned_index():
+    """segment2elasticValid's v[] (fbg_scan_gapped_v) from the key-range partitioned index of a multi-GPU job: the
+    scan without tricks reads the all-reduced column maxima exactly as fbg_scan_f does."""
+    import torch
+    from founderblockgraphs_amd import Engine
+    rng = np.random.default_rng(4711)
+    engines = [Engine() for _ in range(2)]
+    try:
+        for (m, n, kw) in [(30, 700, {}), (64, 400, dict(alphabet="AC")), (12, 1500, dict(similar=0.5))]:
+            msa = random_msa(rng, m, n, **kw)
+            for e in engines:
+                e.msa_load_host(msa)
+            ok1, ok2, ok3 = _partitioned(engines, n)
+            if not (all(ok1) and all(ok2) and all(ok3)):
+                continue                                  # declined (similar rows): the caller falls back, nothing to check
+            d_v = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            engines[0].scan_gapped_v(d_v.data_ptr())
+            engines[0].sync()
+            assert np.array_equal(d_v.cpu().numpy().astype(np.uint64), O.gapped_v(msa)), (m, n, kw)
+    finally:
+        for e in engines:
+            e.close()
