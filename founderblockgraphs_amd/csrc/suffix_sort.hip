@@ -170,15 +170,23 @@ static void launch_pack(fbg_ctx *ctx, const KeyGeom &g, bool filter, PackArgs &a
 __global__ void k_sample_keys(const uint8_t *__restrict__ T, uint64_t N, const uint8_t *__restrict__ code, int b, int K,
                               int compact, uint64_t stride, uint64_t S, uint64_t *__restrict__ out)
 {
+    // the code table in LDS, the text 8 bytes at a time (T is zero padded beyond N): K dependent byte loads through
+    // a table in global memory made this small kernel take 0.3 ms
+    __shared__ uint8_t cd[256];
+    if (threadIdx.x < 256) cd[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     const uint64_t p = i * stride;
     uint64_t key = 0;
     bool dead = false;
-    for (int k = 0; k < K; k++) {
-        const uint32_t c = p + k < N ? code[T[p + k]] : (compact ? FBG_SEP : 0);
-        dead = dead || (compact && (c & FBG_SEP));
-        key = (key << b) | (dead ? 0u : c);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const uint64_t x = p + k0 < N ? fbg_load8(T, p + k0) : 0ull;
+        for (int k = k0; k < K && k < k0 + 8; k++) {
+            const uint32_t c = p + k < N ? cd[(x >> (8 * (k - k0))) & 255u] : (compact ? FBG_SEP : 0);
+            dead = dead || (compact && (c & FBG_SEP));
+            key = (key << b) | (dead ? 0u : c);
+        }
     }
     out[i] = key;
 }
