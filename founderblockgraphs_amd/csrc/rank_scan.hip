@@ -508,15 +508,28 @@ __global__ __launch_bounds__(256) void k_tie_sample(const uint64_t *__restrict__
     if (threadIdx.x == 0) sties = 0;
     __syncthreads();
     const uint64_t k = (uint64_t)blockIdx.x * 1024 * 256 + threadIdx.x;
+    uint32_t bin = 0xffffffffu;                                       // 64 = ties on the whole key
     if (k < N) {
         const uint64_t key = keys[k] >> shift;
         const uint64_t kp = k > 0 ? keys[k - 1] >> shift : ~key, kn = k + 1 < N ? keys[k + 1] >> shift : ~key;
         if (kp == key || kn == key) {
-            atomicAdd(&sties, 1u);
+            bin = 64;
         } else {
             const uint32_t lp = k > 0 ? rs_key_lcp(kp, key, b, key_bits) : 0u;
             const uint32_t ln = k + 1 < N ? rs_key_lcp(key, kn, b, key_bits) : 0u;
-            atomicAdd(&sh[min(max(lp, ln) + 1, 63u)], 1u);
+            bin = min(max(lp, ln) + 1, 63u);
+        }
+    }
+    // a wave's slots fall into a handful of bins: one LDS update per distinct bin instead of 64 on the same word
+    {
+        const int lane = threadIdx.x & 63;
+        unsigned long long rest = __ballot(bin != 0xffffffffu);
+        while (rest) {
+            const int l = __ffsll((long long)rest) - 1;
+            const uint32_t v = __shfl(bin, l, 64);
+            const unsigned long long same = __ballot(bin == v);
+            if (lane == l) { if (v == 64) atomicAdd(&sties, (uint32_t)__popcll(same)); else atomicAdd(&sh[v], (uint32_t)__popcll(same)); }
+            rest &= ~same;
         }
     }
     __syncthreads();

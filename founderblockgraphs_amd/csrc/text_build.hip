@@ -193,11 +193,16 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
 __global__ void k_row_offsets(const uint32_t *__restrict__ tot, uint64_t m, uint32_t *__restrict__ pos,
                               unsigned long long *__restrict__ scalars)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long s = 0;
-        for (uint64_t i = 0; i < m; i++) { pos[i] = (uint32_t)s; s += (unsigned long long)tot[i] + 1; }
-        scalars[2] = s + 1;
-    }
+    // one wave: every lane sums a stretch of rows, the stretches are scanned across the lanes
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const uint64_t per = (m + 63) / 64, lo = min(m, (uint64_t)threadIdx.x * per), hi = min(m, lo + per);
+    unsigned long long mine = 0;
+    for (uint64_t i = lo; i < hi; i++) mine += (unsigned long long)tot[i] + 1;
+    unsigned long long inc = mine;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += o; }
+    unsigned long long s = inc - mine;
+    for (uint64_t i = lo; i < hi; i++) { pos[i] = (uint32_t)s; s += (unsigned long long)tot[i] + 1; }
+    if (threadIdx.x == 63) scalars[2] = inc + 1;
 }
 
 template <bool GAPPED, bool REVERSED>
