@@ -28,12 +28,18 @@ it = 0
 while time.time() - t0 < budget:
     seed = seed0 + it
     it += 1
-    if time.time() - last_note > 30:
+    if time.time() - last_note > 30 or os.environ.get("FBG_FUZZ_BIG"):
         last_note = time.time()
         print(f"... {it} cases, {time.time() - t0:.0f} s", flush=True)
     rng = np.random.default_rng(seed)
-    m = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 400]))
-    n = int(rng.choice([1, 2, 7, 33, 100, 257, 1000, 3000]))
+    if os.environ.get("FBG_FUZZ_BIG"):
+        # texts of 1.7e7 .. 2.4e7 symbols: above the sizes from which the three-pass sorts and the by-position passes
+        # run by themselves (2^24); a case takes the oracle 10-20 s
+        m = int(rng.choice([40, 200, 1000]))
+        n = int(rng.integers(17_000_000, 24_000_000)) // m
+    else:
+        m = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 400]))
+        n = int(rng.choice([1, 2, 7, 33, 100, 257, 1000, 3000]))
     alphabet = str(rng.choice(["A", "AC", "ACGT", "ACGTN", "ACGTRYKM"]))
     kw = {}
     if rng.random() < 0.5:
@@ -50,7 +56,7 @@ while time.time() - t0 < budget:
     try:
         ign = "N" if (alphabet == "ACGTN" and rng.random() < 0.5) else ""
         tricks_off = bool(rng.random() < 0.3)
-        f = O.compute_f(msa, ignore=ign, disable_tricks=tricks_off)
+        f = O.compute_f(msa, ignore=ign, disable_tricks=tricks_off, threads=8 if os.environ.get("FBG_FUZZ_BIG") else 1)
         try:
             g = eng.elastic_f(msa, ignorechars=ign, disable_efg_tricks=tricks_off)
             assert np.array_equal(g, f), "f"
