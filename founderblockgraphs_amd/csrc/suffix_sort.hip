@@ -589,14 +589,14 @@ __global__ void k_gather_unresolved(const uint32_t *__restrict__ sel, uint64_t c
 
 // key = (group head, rank of the suffix h further on)
 __global__ void k_doubling_keys(const uint32_t *__restrict__ vals, const uint32_t *__restrict__ grp, uint64_t cnt,
-                                const uint4 *__restrict__ rec, uint64_t h, uint64_t N,
+                                const uint4 *__restrict__ rec, uint64_t h, uint64_t N, int nb,
                                 uint64_t *__restrict__ keys)
 {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= cnt) return;
     uint64_t q = (uint64_t)vals[k] + h;
     uint32_t r2 = q < N ? rec[q].x : 0u;   // q < N always holds for unresolved suffixes (unique sentinel)
-    keys[k] = ((uint64_t)grp[k] << 32) | r2;
+    keys[k] = ((uint64_t)grp[k] << nb) | r2;                  // both below 2^nb: 2 nb key bits to sort, not 64
 }
 
 __global__ void k_iota(uint32_t *__restrict__ a, uint64_t cnt)
@@ -920,11 +920,16 @@ int fbg_suffix_sort(fbg_ctx *ctx)
                  *grp_new = gbuf[pp]->as<uint32_t>();
         hipLaunchKernelGGL(k_gather_unresolved, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, sel, ncnt, where_cur,
                            vals_cur, grp_cur, where_new, vals_new, grp_new);
+        int nb = 1;
+        while ((1ull << nb) < N) nb++;
         hipLaunchKernelGGL(k_doubling_keys, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, vals_new, grp_new, ncnt,
-                           rec, h, N, dkeys_in);
+                           rec, h, N, nb, dkeys_in);
         // sort by (group, rank at +h); the sorted positions go back to the same SA slots
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_pairs(tmp, bytes, dkeys_in, dkeys_out, vals_new, valsA, (size_t)ncnt, 0u, 64u, st);
+            if (ncnt >= (1u << 23))
+                return rocprim::radix_sort_pairs<fbg_sort_config>(tmp, bytes, dkeys_in, dkeys_out, vals_new, valsA, (size_t)ncnt, 0u,
+                                                                  (unsigned)(2 * nb), st);
+            return rocprim::radix_sort_pairs(tmp, bytes, dkeys_in, dkeys_out, vals_new, valsA, (size_t)ncnt, 0u, (unsigned)(2 * nb), st);
         }));
         hipLaunchKernelGGL(k_mark_heads, dim3(fbg_blocks(ncnt, 256)), dim3(256), 0, st, dkeys_out, ncnt, where_new, grp_new);
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
