@@ -4,5 +4,5 @@ Product path: libfbg_hip.so (hand-written HIP for gfx950, C ABI in include/fbg_h
 host program built from csrc/host/.  This package is the thin ctypes mirror used by the tests and
 bench.py; it contains no compute and no fallback.
 """
-from .api import (Engine, FbgError, NoSegmentation, as_msa, segment, segment2elasticValid,  # noqa: F401
+from .api import (Engine, FbgError, Group, NoSegmentation, as_msa, segment, segment2elasticValid,  # noqa: F401
                   segment_elastic_minmaxlength)

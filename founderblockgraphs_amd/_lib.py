@@ -25,6 +25,8 @@ SIGNATURES = {
     "fbg_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "fbg_ctx_destroy": (None, [vp]),
     "fbg_last_error": (C.c_char_p, [vp]),
+    "fbg_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "fbg_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "fbg_set_stream": (C.c_int, [vp, vp]),
     "fbg_stage_ms": (C.c_int, [vp, C.c_int, fp, ip]),
     "fbg_device_bytes": (C.c_uint64, [vp]),
@@ -54,7 +56,24 @@ SIGNATURES = {
     "fbg_text_length": (C.c_uint64, [vp]),
     "fbg_index_download": (C.c_int, [vp, u8p, u32p, u32p, u32p, u32p]),
     "fbg_sync": (C.c_int, [vp]),
+    "fbg_group_create": (C.c_int, [C.c_int, ip, C.POINTER(vp)]),
+    "fbg_group_destroy": (None, [vp]),
+    "fbg_group_last_error": (C.c_char_p, [vp]),
+    "fbg_group_size": (C.c_int, [vp]),
+    "fbg_group_member": (vp, [vp, C.c_int]),
+    "fbg_group_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "fbg_group_plan_used": (C.c_int, [vp, ip]),
+    "fbg_group_elastic_f": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.c_int, u64p]),
+    "fbg_group_repeatfree_v": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u64p]),
+    "fbg_group_gapped_v": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64, u64p]),
+    "fbg_group_msa_load_host": (C.c_int, [vp, u8p, C.c_uint64, C.c_uint64]),
+    "fbg_group_msa_synthetic": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                          C.c_uint64, C.c_uint64]),
+    "fbg_group_scan_f": (C.c_int, [vp, u8p, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "fbg_host_alloc": (vp, [C.c_uint64]),
+    "fbg_host_free": (None, [vp]),
 }
+PLANS = ("auto", "partitioned", "columns", "row_pairs")   # FBG_PLAN_*
 
 _LIB = None
 

@@ -65,7 +65,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.fbg_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):      # a group's member belongs to the group
+                self._L.fbg_ctx_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -236,6 +237,31 @@ class Engine:
         self._chk(rc)
         return cnt.value
 
+    def set_option(self, key, value=1):
+        """fbg_set_option: behaviour switch of this context (include/fbg_hip.h lists the keys)."""
+        self._chk(self._L.fbg_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._chk(self._L.fbg_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kv):
+        """Context manager: set the given options, restore the previous values on exit."""
+        eng = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: eng.get_option(k) for k in kv}
+                for k, v in kv.items():
+                    eng.set_option(k, v)
+                return eng
+
+            def __exit__(self_, *exc):
+                for k, v in self_.old.items():
+                    eng.set_option(k, v)
+        return _Scope()
+
     def set_stream(self, stream_handle):
         self._chk(self._L.fbg_set_stream(self._h, C.c_void_p(stream_handle)))
 
@@ -265,6 +291,120 @@ class Engine:
         arrs = [np.empty(N, dtype=np.uint32) for _ in range(4)]
         self._chk(self._L.fbg_index_download(self._h, _u8(T), *[a.ctypes.data_as(_lib.u32p) for a in arrs]))
         return (T, *arrs)
+
+
+class _DeviceArray:
+    """A device pointer dressed up for torch.as_tensor (zero copy): __cuda_array_interface__, version 2."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, count, typestr="<i8"):
+    """torch view (no copy) of `count` elements of engine-owned device memory; valid as long as the engine keeps it."""
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, count, typestr), device="cuda")
+
+
+class Group:
+    """fbg_group: several contexts (one per entry of `devices`; an id may repeat) driven as one engine --
+    include/fbg_hip.h, 'several GPUs as one engine'.  The sweep and block_graph run on member(0)."""
+
+    def __init__(self, devices=None):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        if devices is None:
+            rc = self._L.fbg_group_create(0, None, C.byref(h))
+        else:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._L.fbg_group_create(len(devices), ids, C.byref(h))
+        if rc != FBG_OK:
+            raise FbgError(rc, self._L.fbg_group_last_error(None).decode())
+        self._h = h
+        self._members = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for e in self._members.values():
+                e._h = None                        # owned by the group
+            self._L.fbg_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc == FBG_OK:
+            return
+        msg = self._L.fbg_group_last_error(self._h).decode()
+        raise (NoSegmentation if rc == FBG_ERR_NO_SEGMENTATION else FbgError)(rc, msg)
+
+    def size(self):
+        return int(self._L.fbg_group_size(self._h))
+
+    def member(self, i=0):
+        """Engine view of member i's context (borrowed: closing it is a no-op)."""
+        if i not in self._members:
+            e = Engine.__new__(Engine)
+            e._L = self._L
+            e._h = C.c_void_p(self._L.fbg_group_member(self._h, i))
+            e.device = None
+            e._borrowed = True
+            self._members[i] = e
+        return self._members[i]
+
+    def set_option(self, key, value=1):
+        self._chk(self._L.fbg_group_set_option(self._h, key.encode(), int(value)))
+
+    def plan_used(self):
+        parts = C.c_int(0)
+        plan = self._L.fbg_group_plan_used(self._h, C.byref(parts))
+        return _lib.PLANS[plan], parts.value
+
+    def elastic_f(self, msa, ignorechars="", disable_efg_tricks=False, f=None):
+        msa = as_msa(msa)
+        m, n = msa.shape
+        self.member(0)._msa_rows = m
+        ig, il = _ignore(ignorechars)
+        f = np.zeros(n, dtype=np.uint64) if f is None else np.ascontiguousarray(f, dtype=np.uint64).copy()
+        self._chk(self._L.fbg_group_elastic_f(self._h, _u8(msa), m, n, _u8(ig), il, int(disable_efg_tricks), _u64(f)))
+        return f
+
+    def repeatfree_v(self, msa):
+        msa = as_msa(msa)
+        v = np.empty(msa.shape[1], dtype=np.uint64)
+        self._chk(self._L.fbg_group_repeatfree_v(self._h, _u8(msa), msa.shape[0], msa.shape[1], _u64(v)))
+        return v
+
+    def gapped_v(self, msa):
+        msa = as_msa(msa)
+        v = np.empty(msa.shape[1], dtype=np.uint64)
+        self._chk(self._L.fbg_group_gapped_v(self._h, _u8(msa), msa.shape[0], msa.shape[1], _u64(v)))
+        return v
+
+    def msa_load_host(self, msa):
+        msa = as_msa(msa)
+        self.member(0)._msa_rows = msa.shape[0]
+        self._chk(self._L.fbg_group_msa_load_host(self._h, _u8(msa), msa.shape[0], msa.shape[1]))
+
+    def msa_synthetic(self, m, n, seed=0x5EED0001, seed2=0x5EED0002, gap_fraction=0.0, gap_run=0, seed3=0x5EED0003,
+                      n_fraction=0.0):
+        gthr = int((1 << 64) * (gap_fraction / gap_run)) if gap_run else 0
+        nthr = int((1 << 64) * n_fraction)
+        self.member(0)._msa_rows = m
+        self._chk(self._L.fbg_group_msa_synthetic(self._h, m, n, seed, seed2, gthr, gap_run, seed3, nthr))
+
+    def scan_f(self, ignorechars="", disable_efg_tricks=False):
+        """f of the current MSA -> device pointer (member 0's memory, n uint64 values)."""
+        ig, il = _ignore(ignorechars)
+        p = C.c_void_p()
+        self._chk(self._L.fbg_group_scan_f(self._h, _u8(ig), il, int(disable_efg_tricks), C.byref(p)))
+        return p.value
 
 
 # ---- reference-shaped free functions ---------------------------------------------------------

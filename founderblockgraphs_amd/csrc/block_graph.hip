@@ -263,12 +263,13 @@ int fbg_block_graph(fbg_ctx *ctx, const uint64_t *boundaries, uint64_t nb, uint3
     hipLaunchKernelGGL(k_block_globalize, dim3(fbg_blocks(cells, 256)), dim3(256), 0, st, a);
     unsigned long long h_flag = 0;
     FBG_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, a.flag, 8, hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(node_of, a.node_of, cells * 4, hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(rep_row, a.rep_row, cells * 4, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipMemcpyAsync(first_node, first, (nb + 1) * 8, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipMemcpyAsync(edge_count, a.edge_count, nb * 8, hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(edges, a.edges, cells * 8, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    // the three per-(row, block) arrays are hundreds of MB at a million columns: pinned bounce buffers, several threads
+    FBG_TRY(fbg_download(ctx, node_of, a.node_of, cells * 4));
+    FBG_TRY(fbg_download(ctx, rep_row, a.rep_row, cells * 4));
+    FBG_TRY(fbg_download(ctx, edges, a.edges, cells * 8));
     FBG_HIP_TRY(ctx, hipGetLastError());
     if (h_flag != 0)
         return fbg_fail(ctx, FBG_ERR_HASH_COLLISION, "two different block labels share a 128-bit hash; use the host-side numbering");

@@ -2,7 +2,11 @@
 #include "fbg_internal.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <ctype.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 static std::string g_global_err;
@@ -49,6 +53,86 @@ void fbg_release(fbg_ctx *ctx, DevBuf &b)
     }
 }
 
+// ---- host <-> device transfers -----------------------------------------------------------------------------------
+// hipMemcpy of pageable memory is staged by the runtime through one thread's memcpy: 1 GB of MSA arrives at a
+// fraction of the PCIe rate.  Here up to 8 host threads copy chunks into a ring of pinned slots and queue the DMA
+// of each chunk behind its own copy; a slot is reused once the DMA that last read it has finished (its event).
+#define FBG_STAGE_SLOT (8u << 20)
+#define FBG_STAGE_SLOTS 16
+#define FBG_STAGE_MIN (32u << 20)
+
+static bool host_pointer_is_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }     // plain malloc'ed memory: not known to the runtime
+    return at.type == hipMemoryTypeHost;
+}
+
+static int stager_ready(fbg_ctx *ctx)
+{
+    Stager &s = ctx->stager;
+    if (s.base) return FBG_OK;
+    FBG_HIP_TRY(ctx, hipHostMalloc(&s.base, (size_t)FBG_STAGE_SLOT * FBG_STAGE_SLOTS, hipHostMallocDefault));
+    s.slot_bytes = FBG_STAGE_SLOT; s.nslots = FBG_STAGE_SLOTS;
+    s.ev = new hipEvent_t[s.nslots];
+    for (int i = 0; i < s.nslots; i++) FBG_HIP_TRY(ctx, hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming));
+    FBG_HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    return FBG_OK;
+}
+
+static int staged_copy(fbg_ctx *ctx, void *dst, const void *src, size_t bytes, bool to_device)
+{
+    FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));              // whatever produced / will consume the device side
+    const void *host = to_device ? src : dst;
+    if (bytes < FBG_STAGE_MIN || host_pointer_is_pinned(host)) {
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return FBG_OK;
+    }
+    FBG_TRY(stager_ready(ctx));
+    Stager &s = ctx->stager;
+    const size_t nchunks = (bytes + s.slot_bytes - 1) / s.slot_bytes;
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)std::min<size_t>(std::min<unsigned>(std::max(2u, hw / 2), 8u), nchunks);
+    if (T > s.nslots / 2) T = s.nslots / 2;                           // a slot's previous use has been queued by the time it comes round
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto worker = [&]() {
+        if (hipSetDevice(ctx->device) != hipSuccess) { failed = 1; return; }
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= nchunks || failed) return;
+            const int slot = (int)(c % (size_t)s.nslots);
+            const size_t off = c * s.slot_bytes, len = std::min(s.slot_bytes, bytes - off);
+            uint8_t *pin = static_cast<uint8_t *>(s.base) + (size_t)slot * s.slot_bytes;
+            if (to_device) {
+                if (c >= (size_t)s.nslots && hipEventSynchronize(s.ev[slot]) != hipSuccess) { failed = 1; return; }
+                memcpy(pin, static_cast<const uint8_t *>(src) + off, len);
+                if (hipMemcpyAsync(static_cast<uint8_t *>(dst) + off, pin, len, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
+                    hipEventRecord(s.ev[slot], s.stream) != hipSuccess) { failed = 1; return; }
+            } else {
+                // device -> slot, wait for it, slot -> caller's memory; the thread owns the slot for the whole chunk
+                if (hipMemcpyAsync(pin, static_cast<const uint8_t *>(src) + off, len, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
+                    hipEventRecord(s.ev[slot], s.stream) != hipSuccess || hipEventSynchronize(s.ev[slot]) != hipSuccess) { failed = 1; return; }
+                memcpy(static_cast<uint8_t *>(dst) + off, pin, len);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    if (failed) return fbg_fail(ctx, FBG_ERR_HIP, "staged %s copy of %zu bytes failed: %s", to_device ? "host-to-device" : "device-to-host",
+                                bytes, hipGetErrorString(hipGetLastError()));
+    return FBG_OK;
+}
+
+int fbg_upload(fbg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) { return staged_copy(ctx, d_dst, h_src, bytes, true); }
+int fbg_download(fbg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) { return staged_copy(ctx, h_dst, d_src, bytes, false); }
+
 int fbg_stage_begin(fbg_ctx *ctx, int stage)
 {
     StageTimer &t = ctx->timers[stage];
@@ -70,7 +154,56 @@ int fbg_stage_end(fbg_ctx *ctx, int stage, int launches)
     return FBG_OK;
 }
 
+// option table: key -> member of FbgOptions
+struct OptKey { const char *name; int64_t FbgOptions::*field; };
+static const OptKey g_opt_keys[] = {
+    {"no_ranked", &FbgOptions::no_ranked}, {"no_packed", &FbgOptions::no_packed}, {"force_wide", &FbgOptions::force_wide},
+    {"full_keys", &FbgOptions::full_keys}, {"no_msd_sort", &FbgOptions::no_msd_sort}, {"msd_min", &FbgOptions::msd_min},
+    {"bp_min", &FbgOptions::bp_min}, {"record_scatter", &FbgOptions::record_scatter}, {"lcp_text", &FbgOptions::lcp_text},
+    {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
+    {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
+    {"dp_tile", &FbgOptions::dp_tile},
+};
+
+// The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of
+// every context created afterwards (debugging a deployed binary); without it no variable has any effect.
+static void options_from_env(FbgOptions &o)
+{
+    auto env = [](const std::string &name) -> const char * { return getenv(name.c_str()); };
+    const char *dbg = env("FBG_DEBUG_ENV");
+    if (!dbg || strcmp(dbg, "1") != 0) return;
+    for (const OptKey &k : g_opt_keys) {
+        std::string name = "FBG_";
+        for (const char *c = k.name; *c; c++) name += (char)toupper((unsigned char)*c);
+        if (const char *v = env(name)) o.*(k.field) = *v ? strtoll(v, nullptr, 10) : 1;
+    }
+}
+
 extern "C" {
+
+int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return FBG_ERR_INVALID;
+    for (const OptKey &k : g_opt_keys)
+        if (strcmp(k.name, key) == 0) { ctx->opt.*(k.field) = value; return FBG_OK; }
+    return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_set_option: unknown key '%s'", key);
+}
+
+int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
+{
+    if (!ctx || !key || !value) return FBG_ERR_INVALID;
+    for (const OptKey &k : g_opt_keys)
+        if (strcmp(k.name, key) == 0) { *value = ctx->opt.*(k.field); return FBG_OK; }
+    return FBG_ERR_INVALID;
+}
+
+void *fbg_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void fbg_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int fbg_ctx_create(int device, fbg_ctx **out)
 {
@@ -88,6 +221,7 @@ int fbg_ctx_create(int device, fbg_ctx **out)
     if (e != hipSuccess) return fbg_fail(nullptr, FBG_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
     fbg_ctx *ctx = new fbg_ctx();
     ctx->device = device;
+    options_from_env(ctx->opt);
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -112,6 +246,12 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     for (auto &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
+    }
+    if (ctx->stager.base) {
+        for (int i = 0; i < ctx->stager.nslots; i++) (void)hipEventDestroy(ctx->stager.ev[i]);
+        delete[] ctx->stager.ev;
+        (void)hipStreamDestroy(ctx->stager.stream);
+        (void)hipHostFree(ctx->stager.base);
     }
     if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
     if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
@@ -202,8 +342,7 @@ int fbg_msa_load_host(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n)
     if (!msa) return fbg_fail(ctx, FBG_ERR_INVALID, "null MSA pointer");
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     FBG_TRY(fbg_reserve(ctx, ctx->msa_own, m * n));
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->msa_own.p, msa, m * n, hipMemcpyHostToDevice, ctx->stream));
-    FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    FBG_TRY(fbg_upload(ctx, ctx->msa_own.p, msa, m * n));
     ctx->d_msa = ctx->msa_own.as<uint8_t>(); ctx->m = m; ctx->n = n; ctx->index_valid = false;
     return FBG_OK;
 }

@@ -703,7 +703,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     if (hk[2] != 0) return fbg_fail(ctx, FBG_ERR_INVALID, "f[] has %llu entries outside [x, n]", hk[2]);
     const unsigned long long max_ext = hk[3];
     int R = 0;
-    if (f0 == 0 && !getenv("FBG_DP_LITERAL")) {
+    if (f0 == 0 && !ctx->opt.dp_literal) {
         const unsigned long long bound = 2 * max_ext + 2;   // minmaxlength[j] <= 2*max_ext + 1
         R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 254 ? 4 : bound <= 512 ? 8 : bound <= 1024 ? 16 : 0;
     }
@@ -711,16 +711,16 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     bool tiled = false;
     if (!literal) {
         bool settled = false;
-        if (!getenv("FBG_DP_WAVE")) {
+        if (!ctx->opt.dp_wave) {
             // sweeps that work straight from f (no bucket order needed).  The window that is provably enough
             // (64 R >= 2 max_ext + 2) is rarely needed: start with the smallest one that holds every extension and
             // widen when the sweep reports a value at its limit
             uint8_t *ext7 = ctx->dp_e.as<uint8_t>(), *clen = ctx->dp_f.as<uint8_t>();
             int Rt = 1;
             while (64ull * Rt < max_ext + 2 && Rt < 4) Rt *= 2;
-            if (getenv("FBG_DP_SAFE_WINDOW")) Rt = R;
+            if (ctx->opt.dp_safe_window) Rt = R;
             for (; Rt <= 4 && Rt <= R && !settled; Rt *= 2) {
-                const bool tile = Rt == 1 && getenv("FBG_DP_TILE");
+                const bool tile = Rt == 1 && ctx->opt.dp_tile;
                 FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
                 hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n,
                                    tile ? 127u : 255u, ext7, clen);
@@ -761,7 +761,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             if (!settled) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
         }
         if (!settled) FBG_TRY(build_buckets());        // also zeroes what the abandoned attempts left in count / bcount / mml / bt
-        if (!settled && (R > 4 || getenv("FBG_DP_WAVE"))) {
+        if (!settled && (R > 4 || ctx->opt.dp_wave)) {
             switch (R) {
             case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
             case 2: hipLaunchKernelGGL((k_dp_wave<2>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
@@ -899,7 +899,7 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
     uint32_t *s = ctx->dp_g.as<uint32_t>(), *prev = ctx->dp_h.as<uint32_t>();
     unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
     FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 16 * sizeof(unsigned long long), st));
-    bool literal = getenv("FBG_DP_LITERAL") != nullptr;
+    bool literal = ctx->opt.dp_literal != 0;
     if (!literal) {
         const size_t w = (n + 2) * 4;
         FBG_TRY(fbg_reserve(ctx, ctx->dp_a, w));

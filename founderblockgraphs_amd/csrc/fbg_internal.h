@@ -16,14 +16,33 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Pinned bounce buffers for large host <-> device transfers of pageable memory (ctx.hip: fbg_upload / fbg_download)
+struct Stager {
+    void *base = nullptr;
+    size_t slot_bytes = 0;
+    int nslots = 0;
+    hipEvent_t *ev = nullptr;
+    hipStream_t stream = nullptr;
+};
+
 struct StageTimer {
     hipEvent_t start = nullptr, stop = nullptr;
     bool recorded = false;
     int launches = 0;
 };
 
+// Behaviour switches of one context (fbg_set_option; include/fbg_hip.h lists the keys).  The environment is never
+// consulted by the compute code: fbg_ctx_create copies FBG_<KEY> variables into a new context only when
+// FBG_DEBUG_ENV=1 is set (ctx.hip, the library's one getenv site).
+struct FbgOptions {
+    int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
+            record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
+            dp_safe_window = 0, dp_tile = 0;
+};
+
 struct fbg_ctx {
     int device = 0;
+    FbgOptions opt;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // second stream for work that only raises column maxima (k_tie_simple) beside the candidate kernels
@@ -32,6 +51,7 @@ struct fbg_ctx {
     bool aux_pending = false;
     std::string err;
     uint64_t held_bytes = 0;
+    Stager stager;
 
     // current MSA (row-major m x n bytes, device)
     const uint8_t *d_msa = nullptr;
@@ -98,6 +118,10 @@ int fbg_fail(fbg_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 
 int fbg_reserve(fbg_ctx *ctx, DevBuf &b, size_t bytes);   // grow-only device allocation
+// blocking host <-> device copies; pageable memory of 32 MB and more goes through pinned bounce buffers filled by
+// several host threads (the runtime's own staging of pageable memory is a single-threaded memcpy)
+int fbg_upload(fbg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int fbg_download(fbg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 void fbg_release(fbg_ctx *ctx, DevBuf &b);
 int fbg_stage_begin(fbg_ctx *ctx, int stage);
 int fbg_stage_end(fbg_ctx *ctx, int stage, int launches);

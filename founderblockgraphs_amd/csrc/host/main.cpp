@@ -6,6 +6,7 @@
 // C ABI of include/fbg_hip.h; nothing in this program computes a segmentation on the CPU.
 // Differences that are not part of the output contract are listed in INTEGRATION.md
 // (no <input>.plain / .cst side files, stderr wording of the index-size line).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -85,49 +86,72 @@ int main(int argc, char **argv)
 
     if (opt.threads > 0) set_host_threads((unsigned)opt.threads);
 
-    fbg_ctx *ctx = nullptr;
-    int rc = fbg_ctx_create(0, &ctx);
+    // Which GPUs: FBG_DEVICES="0,1,2,3" names them (an id may repeat: several contexts on one device); otherwise one
+    // GPU for texts it indexes in one piece, and for longer ones every visible GPU -- at most --threads of them, the
+    // reference's own knob for how wide the scan fans out (fbg.cpp:3392-3399).  The group runs the index and the scan
+    // (partitioned over the devices, or in column ranges like compute_f_range); the sweep runs on its first member.
+    std::vector<int> devices;
+    int ndev = 1;
+    if (const char *spec = std::getenv("FBG_DEVICES")) {
+        for (const char *p = spec; *p;) {
+            char *end = nullptr;
+            const long d = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)d);
+            p = *end == ',' ? end + 1 : end;
+        }
+        ndev = (int)devices.size();
+    } else if ((double)msa.m * (double)(msa.n + 1) >= 1073741824.0) {
+        ndev = opt.threads > 0 ? (int)std::min<long>(opt.threads, 64) : 0;       // 0: all visible devices
+    }
+    fbg_group *grp = nullptr;
+    int rc = fbg_group_create(ndev, devices.empty() ? nullptr : devices.data(), &grp);
     if (rc != FBG_OK) {
-        std::cerr << "ERROR: cannot open the GPU engine: " << fbg_last_error(nullptr) << std::endl;
+        std::cerr << "ERROR: cannot open the GPU engine: " << fbg_group_last_error(nullptr) << std::endl;
         return EXIT_FAILURE;
     }
+    fbg_ctx *ctx = fbg_group_member(grp, 0);
+    struct GroupGuard { fbg_group *g; ~GroupGuard() { if (g) fbg_group_destroy(g); } } guard{grp};
+    auto close_engine = [&]() { fbg_group_destroy(grp); guard.g = nullptr; };
+    auto group_failure = [&](const char *what, int code) {
+        std::cerr << "ERROR: " << what << " failed (code " << code << "): " << fbg_group_last_error(grp) << std::endl;
+        return EXIT_FAILURE;
+    };
 
     lap("open the GPU engine");
-    int status = EXIT_SUCCESS;
     std::vector<uint64_t> boundaries;
     if (opt.elastic) {
         std::vector<uint64_t> f(msa.n, 0);                                                                   // 3388
-        rc = fbg_elastic_f(ctx, msa.cells.data(), msa.m, msa.n,
-                           reinterpret_cast<const uint8_t *>(opt.ignore_chars.data()), opt.ignore_chars.size(),
-                           opt.disable_elastic_tricks ? 1 : 0, f.data());
+        rc = fbg_group_elastic_f(grp, msa.cells.data(), msa.m, msa.n,
+                                 reinterpret_cast<const uint8_t *>(opt.ignore_chars.data()), opt.ignore_chars.size(),
+                                 opt.disable_elastic_tricks ? 1 : 0, f.data());
         std::cerr << "MSA index construction complete, index requires "
                   << (double)fbg_device_bytes(ctx) / (1024.0 * 1024.0) << " MiB." << std::endl;              // 3380
-        if (rc == FBG_ERR_NO_SEGMENTATION) { std::cerr << "No valid segmentation found!\n"; fbg_ctx_destroy(ctx); std::exit(1); }
-        if (rc != FBG_OK) { status = engine_failure(ctx, "fbg_elastic_f", rc); fbg_ctx_destroy(ctx); return status; }
+        if (rc == FBG_ERR_NO_SEGMENTATION) { std::cerr << "No valid segmentation found!\n"; close_engine(); std::exit(1); }
+        if (rc != FBG_OK) return group_failure("fbg_group_elastic_f", rc);
         std::cerr << "Computing optimal segmentation..." << std::flush;                                     // 1958
         boundaries.resize(msa.n + 1);
         uint64_t count = 0;
         std::vector<uint64_t> mml(msa.n + 1);
         rc = fbg_minmax_dp(ctx, f.data(), msa.n, boundaries.data(), &count, mml.data(), nullptr);
-        if (rc != FBG_OK) { status = engine_failure(ctx, "fbg_minmax_dp", rc); fbg_ctx_destroy(ctx); return status; }
+        if (rc != FBG_OK) return engine_failure(ctx, "fbg_minmax_dp", rc);
         boundaries.resize(count);
         std::cerr << "done (optimal segment length = " << mml[msa.n] << ")." << std::endl;                   // 2023
     } else if (opt.gap_limit == 1) {
         std::vector<uint64_t> v(msa.n), s(msa.n), prev(msa.n);
-        rc = fbg_repeatfree_v(ctx, msa.cells.data(), msa.m, msa.n, v.data());
-        if (rc != FBG_OK) { status = engine_failure(ctx, "fbg_repeatfree_v", rc); fbg_ctx_destroy(ctx); return status; }
+        rc = fbg_group_repeatfree_v(grp, msa.cells.data(), msa.m, msa.n, v.data());
+        if (rc != FBG_OK) return group_failure("fbg_group_repeatfree_v", rc);
         std::cerr << "MSA index construction complete, index requires "
                   << (double)fbg_device_bytes(ctx) / (1024.0 * 1024.0) << " MiB." << std::endl;
         boundaries.resize(msa.n);
         uint64_t count = 0;
         rc = fbg_repeatfree_dp(ctx, v.data(), msa.n, s.data(), prev.data(), boundaries.data(), &count);
         if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) {
-            status = engine_failure(ctx, "fbg_repeatfree_dp", rc); fbg_ctx_destroy(ctx); return status;
+            return engine_failure(ctx, "fbg_repeatfree_dp", rc);
         }
         std::cerr << "Optimal score: " << s[msa.n - 1] << std::endl;                                        // 646
         if (rc == FBG_ERR_NO_SEGMENTATION) {                                                                 // 648-652
             std::cerr << "No proper segmentation exists.\n";
-            fbg_ctx_destroy(ctx);
             return EXIT_FAILURE;
         }
         boundaries.resize(count);
@@ -140,20 +164,19 @@ int main(int argc, char **argv)
     } else {
         // segment2elasticValid (fbg.cpp:738-935): rows may hold gaps (runs shorter than the limit survived read_msa)
         std::vector<uint64_t> v(msa.n), s(msa.n), prev(msa.n);
-        rc = fbg_gapped_v(ctx, msa.cells.data(), msa.m, msa.n, v.data());
-        if (rc != FBG_OK) { status = engine_failure(ctx, "fbg_gapped_v", rc); fbg_ctx_destroy(ctx); return status; }
+        rc = fbg_group_gapped_v(grp, msa.cells.data(), msa.m, msa.n, v.data());
+        if (rc != FBG_OK) return group_failure("fbg_group_gapped_v", rc);
         std::cerr << "MSA index construction complete, index requires "
                   << (double)fbg_device_bytes(ctx) / (1024.0 * 1024.0) << " MiB." << std::endl;
         boundaries.resize(msa.n);
         uint64_t count = 0;
         rc = fbg_gapped_dp(ctx, v.data(), msa.n, s.data(), prev.data(), boundaries.data(), &count);
         if (rc != FBG_OK && rc != FBG_ERR_NO_SEGMENTATION) {
-            status = engine_failure(ctx, "fbg_gapped_dp", rc); fbg_ctx_destroy(ctx); return status;
+            return engine_failure(ctx, "fbg_gapped_dp", rc);
         }
         std::cerr << "Optimal score: " << s[msa.n - 1] << std::endl;                                        // 848
         if (rc == FBG_ERR_NO_SEGMENTATION) {                                                                 // 850-854
             std::cerr << "No valid segmentation found!\n";
-            fbg_ctx_destroy(ctx);
             return EXIT_FAILURE;
         }
         boundaries.resize(count);
@@ -177,7 +200,7 @@ int main(int argc, char **argv)
         have_graph = rc == FBG_OK;          // otherwise (a hash collision, an input beyond its limits): hash on the host
     }
     lap("graph nodes and edges");
-    fbg_ctx_destroy(ctx);
+    close_engine();
 
     if (!opt.elastic) {
         // The reference goes on to make_efg() with an EMPTY block_indices vector (fbg.cpp:3385,3449) and reads

@@ -317,8 +317,8 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     *ok = 0;
     const uint64_t N = ctx->N;
     const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
-    const uint64_t min_n = getenv("FBG_MSD_MIN") ? strtoull(getenv("FBG_MSD_MIN"), nullptr, 10) : (1ull << 24);   // tests lower it
-    if (!g.packed || !g.compact || N < min_n || rest < 1 || getenv("FBG_NO_MSD_SORT")) return FBG_OK;
+    const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);   // tests lower it
+    if (!g.packed || !g.compact || N < min_n || rest < 1 || ctx->opt.no_msd_sort) return FBG_OK;
     const int fbits = rest < MSD_FN_BITS ? rest : MSD_FN_BITS;
     // without enough bits for the bins the counting in the finish turns quadratic: leave those to rocPRIM
     if (fbits < 6) return FBG_OK;

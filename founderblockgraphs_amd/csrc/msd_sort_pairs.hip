@@ -360,8 +360,8 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
 {
     *ok = 0;
     const uint64_t N = ctx->N;
-    const uint64_t min_n = getenv("FBG_MSD_MIN") ? strtoull(getenv("FBG_MSD_MIN"), nullptr, 10) : (1ull << 24);
-    if (!g.compact || N / nparts < min_n || getenv("FBG_NO_MSD_SORT")) return FBG_OK;
+    const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);
+    if (!g.compact || N / nparts < min_n || ctx->opt.no_msd_sort) return FBG_OK;
     const uint64_t top = g.key_bits >= 64 ? ~0ull : (1ull << g.key_bits);
     const uint64_t span = (nohi ? top : hi) - lo;
     if (span < (1ull << 29) || g.key_bits >= 64) return FBG_OK;       // t needs 28 bits of resolution below the span

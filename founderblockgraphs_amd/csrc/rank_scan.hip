@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, in
 
 struct RankArgs {
     uint32_t magic32;          // floor(2^32 / row_len): umulhi(p, magic32) is p / row_len or one less
-    uint64_t magic64;          // floor(2^64 / row_len) + 1: umul64hi(p, magic64) is p / row_len (wide positions)
+    uint64_t magic64;          // floor(2^64 / row_len): umul64hi(p, magic64) is p / row_len or one less, for every 64-bit p
     uint64_t *keys;            // sorted slots: keys, or packed words key << pb | position
     uint32_t *vals;            // positions in SA order (pairs layout; final once the tie groups are ordered)
     uint64_t pmask;            // packed / wide: (1 << pb) - 1, the position bits of the key word
@@ -113,7 +113,9 @@ template <int L> __device__ __forceinline__ void rs_set_pos(const RankArgs &a, u
 template <int L> __device__ __forceinline__ uint32_t rs_rem(const RankArgs &a, uint64_t p)
 {
     if (L == FBG_SLOTS_WIDE) {
-        const uint64_t c = p - __umul64hi(p, a.magic64) * a.row_len;   // exact while p * row_len < 2^64
+        // p / d - p * floor(2^64 / d) / 2^64 < p / 2^64 < 1: the quotient is at most one short, whatever p and d are
+        uint64_t c = p - __umul64hi(p, a.magic64) * a.row_len;
+        if (c >= a.row_len) c -= a.row_len;
         return p == a.Ntext - 1 ? 0u : (uint32_t)(a.n - c);
     }
     const uint32_t p32 = (uint32_t)p;
@@ -832,7 +834,8 @@ static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *va
     a.N = slots; a.Ntext = ctx->N; a.n = ctx->n; a.row_len = (uint32_t)(ctx->n + 1);
     a.own_lo = 0; a.own_hi = slots; a.first_part = a.last_part = 1; a.part_mode = 0; a.values_only = 0;
     a.magic32 = (uint32_t)((1ull << 32) / (ctx->n + 1));
-    a.magic64 = ~0ull / (ctx->n + 1) + 1;
+    a.magic64 = ~0ull / (ctx->n + 1);     // floor((2^64 - 1) / d) = floor(2^64 / d) unless d divides 2^64, where it is one less:
+                                          // still within the one correction rs_rem applies (d = row_len >= 2)
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>();
     a.cand = nullptr; a.pm = nullptr; a.blk_count = nullptr; a.region = 0;
@@ -875,47 +878,53 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
-    if (getenv("FBG_NO_AUX_STREAM")) {
+    if (ctx->opt.no_aux_stream) {
         RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
     } else {
         FBG_TRY(rs_fork(ctx));
         RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a);
     }
     *launches += 2;
-    // candidate counts per workgroup -> offsets; total and the largest count come back to the host
-    uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
-    FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-        return rocprim::exclusive_scan(tmp, bytes, d_counts, d_offs, 0u, (size_t)(rs_blocks + 1), rocprim::plus<uint32_t>(), st);
-    }));
-    uint32_t *d_max = reinterpret_cast<uint32_t *>(a.counters + 6);
-    FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-        return rocprim::reduce(tmp, bytes, d_counts, d_max, 0u, (size_t)rs_blocks, rocprim::maximum<uint32_t>(), st);
-    }));
-    uint32_t tot = 0, mx = 0;
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot, d_offs + rs_blocks, 4, hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-    const uint64_t T = tot;
-    *T_out = T;
-    if (mx > region) { *T_out = ~0ull; return rs_join(ctx); }
-    if (T > 0) {
-        // candidates in SA order; tie groups first (final order), then the runs
-        FBG_TRY(fbg_reserve(ctx, ctx->dp_a, T * 4));
-        FBG_TRY(fbg_reserve(ctx, ctx->dp_b, T * 4));
-        // regions are in SA order already (workgroup b owns chunks b, b+G, ...: not contiguous) -> compact, then sort
-        uint32_t *sorted = ctx->dp_a.as<uint32_t>();
-        FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
-        uint32_t *flat = ctx->dp_e.as<uint32_t>();
-        hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat);
+    // from here on k_tie_simple may be running on the aux stream: an error return joins it first, so that no caller
+    // ever reuses or frees the buffers under it
+    const int rc_rest = [&]() -> int {
+        // candidate counts per workgroup -> offsets; total and the largest count come back to the host
+        uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
         FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::radix_sort_keys(tmp, bytes, flat, sorted, (size_t)T, 0u, 32u, st);
+            return rocprim::exclusive_scan(tmp, bytes, d_counts, d_offs, 0u, (size_t)(rs_blocks + 1), rocprim::plus<uint32_t>(), st);
         }));
-        a.cand = sorted;
-        a.pm = ctx->dp_b.as<uint32_t>();
-        RS_LAUNCH(k_tie_groups, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
-        RS_LAUNCH(k_tie_big, layout, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
-        *launches += 3;
-    }
+        uint32_t *d_max = reinterpret_cast<uint32_t *>(a.counters + 6);
+        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::reduce(tmp, bytes, d_counts, d_max, 0u, (size_t)rs_blocks, rocprim::maximum<uint32_t>(), st);
+        }));
+        uint32_t tot = 0, mx = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot, d_offs + rs_blocks, 4, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint64_t T = tot;
+        *T_out = T;
+        if (mx > region) { *T_out = ~0ull; return rs_join(ctx); }
+        if (T > 0) {
+            // candidates in SA order; tie groups first (final order), then the runs
+            FBG_TRY(fbg_reserve(ctx, ctx->dp_a, T * 4));
+            FBG_TRY(fbg_reserve(ctx, ctx->dp_b, T * 4));
+            // regions are in SA order already (workgroup b owns chunks b, b+G, ...: not contiguous) -> compact, then sort
+            uint32_t *sorted = ctx->dp_a.as<uint32_t>();
+            FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
+            uint32_t *flat = ctx->dp_e.as<uint32_t>();
+            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat);
+            FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+                return rocprim::radix_sort_keys(tmp, bytes, flat, sorted, (size_t)T, 0u, 32u, st);
+            }));
+            a.cand = sorted;
+            a.pm = ctx->dp_b.as<uint32_t>();
+            RS_LAUNCH(k_tie_groups, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
+            RS_LAUNCH(k_tie_big, layout, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
+            *launches += 3;
+        }
+        return FBG_OK;
+    }();
+    if (rc_rest != FBG_OK) { (void)rs_join(ctx); return rc_rest; }
     return FBG_OK;
 }
 
@@ -941,7 +950,7 @@ static int rs_pick_threshold(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, ui
     FBG_HIP_TRY(ctx, hipMemcpyAsync(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     if (hs[2] * 4 > hs[3]) { *reject = 1; return FBG_OK; }
-    if (!getenv("FBG_RANK_NO_THRESHOLD")) {
+    if (!ctx->opt.rank_no_threshold) {
         const double need = 32.0 / (double)ctx->m * (double)hs[3];    // sampled slots that must lie at or above g_min
         unsigned long long above = 0;
         for (int g = 63; g >= 1; g--) {

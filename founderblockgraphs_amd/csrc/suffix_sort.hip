@@ -656,21 +656,21 @@ int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches)
         if (hist[c] && !(compact && c == '#')) { const double q = (double)hist[c] / (double)N; H -= q * log2(q); }
     if (H < 0.05) H = 0.05;
     int K = (int)ceil((log2((double)N) + 5.0) / H);
-    if (getenv("FBG_FULL_KEYS") || K > 64 / b) K = 64 / b;
+    if (ctx->opt.full_keys || K > 64 / b) K = 64 / b;
     {
         const int passes = (K * b + 8) / 9;                  // 9-bit digits
         const int Kfill = (9 * passes) / b;                  // symbols that fit the same number of passes
         K = Kfill < 64 / b ? Kfill : 64 / b;
     }
     g->compact = compact; g->packed = false; g->wide = false; g->pb = 0;
-    if (N >= (1ull << 32) || (compact && getenv("FBG_FORCE_WIDE"))) {
+    if (N >= (1ull << 32) || (compact && ctx->opt.force_wide)) {
         // positions beyond 32 bits: their high bits ride in the low bits of the key word
         if (!compact) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit positions", (unsigned long long)N);
         int pb = 1;
         while ((1ull << (32 + pb)) < N) pb++;
         g->wide = true; g->pb = pb;
         if (K > (64 - pb) / b) K = (64 - pb) / b;
-    } else if (compact && !getenv("FBG_NO_PACKED")) {
+    } else if (compact && !ctx->opt.no_packed) {
         // one 64-bit word per suffix if the position leaves room for enough symbols (ties up to ~10% are fine:
         // small tie groups are settled inside the scan)
         int pb = 1;
@@ -752,7 +752,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     KeyGeom g;
 
     // ---- gap-free MSAs: compact keys, sort, and the whole extension scan in rank order (rank_scan.hip) -------
-    if (ctx->gapfree && !ctx->have_ignore && !getenv("FBG_NO_RANKED")) {
+    if (ctx->gapfree && !ctx->have_ignore && !ctx->opt.no_ranked) {
         FBG_TRY(fbg_key_setup(ctx, true, &g, &launches));
         bool similar = false;
         FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
@@ -829,8 +829,8 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     }));
     // FBG_BP_MIN lowers the size from which the records travel to their positions in passes (tests); FBG_RECORD_SCATTER
     // keeps the direct scatter
-    const uint64_t bp_min = getenv("FBG_BP_MIN") ? strtoull(getenv("FBG_BP_MIN"), nullptr, 10) : (1ull << 24);
-    const bool by_position = N >= bp_min && N > 2 * BP_LEAF && N <= 1500000000ull && !getenv("FBG_RECORD_SCATTER");
+    const uint64_t bp_min = ctx->opt.bp_min >= 0 ? (uint64_t)ctx->opt.bp_min : (1ull << 24);
+    const bool by_position = N >= bp_min && N > 2 * BP_LEAF && N <= 1500000000ull && !ctx->opt.record_scatter;
     if (by_position) {
         int bits = 0;
         while ((1ull << bits) < N) bits++;
@@ -898,7 +898,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         if (round == 1) {
             // few ties: the key-derived LCPs stand, only the tie groups are patched afterwards;
             // the round-0 keys (keysB) must then survive the doubling rounds
-            ctx->lcp_from_keys = hc <= N / 32 && !getenv("FBG_LCP_TEXT");
+            ctx->lcp_from_keys = hc <= N / 32 && !ctx->opt.lcp_text;
             if (ctx->lcp_from_keys && hc > 0) {
                 dirty_cnt = hc;
                 FBG_TRY(fbg_reserve(ctx, ctx->io_d, hc * 4));
@@ -967,7 +967,7 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     int launches = 0;
     const uint8_t *T = ctx->text.as<uint8_t>();
     KeyGeom g;
-    int pre_ok = ctx->gapfree && !ctx->have_ignore && !getenv("FBG_NO_RANKED");
+    int pre_ok = ctx->gapfree && !ctx->have_ignore && !ctx->opt.no_ranked;
     FBG_TRY(fbg_key_setup(ctx, pre_ok != 0, &g, &launches));
     pre_ok = pre_ok && g.compact;
     ctx->part = part; ctx->nparts = nparts; ctx->part_active = true;

@@ -15,8 +15,9 @@
  * column/row/boundary values are uint64_t because the reference's size_type is
  * (fbg.cpp:47).
  *
- * Limits of this build: text length N = (#non-gap cells) + m + 1 must be < 2^32
- * (32-bit suffix ranks), m <= FBG_MAX_ROWS.  Violations return FBG_ERR_TOO_LARGE.
+ * Limits of this build: one context indexes texts of N = (#non-gap cells) + m + 1 < 2^32 symbols (32-bit suffix
+ * ranks); longer texts (below 2^40) go through a group (fbg_group_*, partitioned index).  m <= FBG_MAX_ROWS on the
+ * record path.  Violations return FBG_ERR_TOO_LARGE.
  * There is no CPU fallback: without a HIP device every compute call fails with
  * FBG_ERR_NO_DEVICE / FBG_ERR_HIP.
  */
@@ -64,6 +65,23 @@ void fbg_ctx_destroy(fbg_ctx *ctx);
 /* Message of the last failing call on this context ("" if none). ctx may be NULL after a
  * failed fbg_ctx_create, in which case a process-wide message is returned. */
 const char *fbg_last_error(const fbg_ctx *ctx);
+/*
+ * Behaviour switches of one context (integers; 0 = default unless stated).  They select between code paths that all
+ * give the same results -- tests use them to reach every path; the environment has no influence on the library
+ * unless FBG_DEBUG_ENV=1 is set, in which case FBG_<KEY IN CAPITALS>=<integer> presets new contexts.
+ *   no_ranked          gap-free MSAs take the record path (text-order scan) instead of the rank-order scan
+ *   no_packed, force_wide, full_keys   slot layout / key length of the round-0 sort
+ *   no_msd_sort        rocPRIM radix sort instead of the three-pass MSD sort
+ *   msd_min, bp_min    text lengths from which the MSD sort / the records-by-position passes are used (-1 = 2^24)
+ *   record_scatter     records reach text order by a scatter instead of the by-position passes
+ *   lcp_text           neighbour LCPs by text comparison even when the keys would do
+ *   no_aux_stream      k_tie_simple on the main stream
+ *   rank_no_threshold  no extension threshold in the rank-order scan
+ *   dp_literal, dp_wave, dp_tile, dp_safe_window   which sweep kernel runs the min-max-length / non-elastic DP
+ * Unknown key: FBG_ERR_INVALID.
+ */
+int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value);
+int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value);
 /* Run all work of this context on an existing hipStream_t (NULL = the context's own). */
 int fbg_set_stream(fbg_ctx *ctx, void *hip_stream);
 /* Device time of a stage during the most recent call that ran it, in ms (HIP events on the
@@ -221,6 +239,54 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
                        uint32_t *lcp_prev, uint32_t *lcp_next);
 /* Block until all work queued on the context's stream has finished. */
 int fbg_sync(fbg_ctx *ctx);
+
+/* ---- several GPUs as one engine (fbg_ctx_create(ndev, dev_ids); 8e) --------------------------------
+ *
+ * Replaces the std::thread fan-out of segment_elastic_minmaxlength_multithread (fbg.cpp:2180-2289): a group holds one
+ * context per entry of dev_ids and drives them from one host thread each.  ndev <= 0 or dev_ids == NULL: all visible
+ * devices (the first ndev of them).  An id may repeat: several contexts on one device -- the way to exercise the
+ * multi-device code on one GPU and to work a text too long for one index off in partitions.  Plans, tried in this
+ * order (fbg_group_plan_used tells which one ran):
+ *   FBG_PLAN_PARTITIONED  key-range partitioned index (fbg_part_*): an all-gather of FBG_PART_HALO_BYTES per
+ *                         partition and an all-reduce(MAX) of n + 1 words; gap-free MSAs without ignore characters,
+ *                         texts of any length below 2^40 symbols (the only way beyond 2^32); partitions may outnumber
+ *                         the members (option "partitions", default: as many as keep a partition below ~1e9
+ *                         suffixes and within device memory), each member then works several off in turn
+ *   FBG_PLAN_COLUMNS      replicated index, member r scans columns [r * ceil(n / W), ...) -- compute_f_range's
+ *                         partition, fbg.cpp:2278-2284 -- one all-gather of f
+ *   FBG_PLAN_ROW_PAIRS    texts of 2^32 symbols and more that the partitioned index declines (elastic f only): one
+ *                         all-reduce(MAX) of f
+ * The exchanges are RCCL collectives (ncclAllGather / ncclAllReduce, one communicator per member) when every member
+ * has its own device, device-to-device copies otherwise or with option "exchange" = 1.  The result lands in member
+ * 0's device memory and, for the host-buffer entry points, in the caller's array; the sweep and fbg_block_graph are
+ * then run on fbg_group_member(g, 0).  Group options: "partitions", "plan" (FBG_PLAN_*), "exchange" (0 auto,
+ * 1 copies, 2 RCCL); any other key goes to every member (fbg_set_option).
+ */
+typedef struct fbg_group fbg_group;
+enum { FBG_PLAN_AUTO = 0, FBG_PLAN_PARTITIONED = 1, FBG_PLAN_COLUMNS = 2, FBG_PLAN_ROW_PAIRS = 3 };
+int fbg_group_create(int ndev, const int *dev_ids, fbg_group **out);
+void fbg_group_destroy(fbg_group *g);
+const char *fbg_group_last_error(const fbg_group *g);     /* g may be NULL after a failed fbg_group_create */
+int fbg_group_size(const fbg_group *g);
+fbg_ctx *fbg_group_member(fbg_group *g, int i);
+int fbg_group_set_option(fbg_group *g, const char *key, int64_t value);
+int fbg_group_plan_used(const fbg_group *g, int *partitions);
+/* the same contracts as fbg_elastic_f / fbg_repeatfree_v / fbg_gapped_v */
+int fbg_group_elastic_f(fbg_group *g, const uint8_t *msa, uint64_t m, uint64_t n, const uint8_t *ignore_chars,
+                        uint64_t ignore_len, int disable_tricks, uint64_t *f);
+int fbg_group_repeatfree_v(fbg_group *g, const uint8_t *msa, uint64_t m, uint64_t n, uint64_t *v);
+int fbg_group_gapped_v(fbg_group *g, const uint8_t *msa, uint64_t m, uint64_t n, uint64_t *v);
+/* staged: the MSA onto every member's device (once per device), then f of all columns into member 0's memory;
+ * *d_f (n values, device memory of member 0) stays valid until the next call on the group */
+int fbg_group_msa_load_host(fbg_group *g, const uint8_t *msa, uint64_t m, uint64_t n);
+int fbg_group_msa_synthetic(fbg_group *g, uint64_t m, uint64_t n, uint64_t seed, uint64_t seed2, uint64_t gap_start_threshold,
+                            uint32_t gap_run_len, uint64_t seed3, uint64_t n_threshold);
+int fbg_group_scan_f(fbg_group *g, const uint8_t *ignore_chars, uint64_t ignore_len, int disable_tricks, uint64_t **d_f);
+
+/* Pinned host memory: an MSA (or an output array) allocated here moves over PCIe by DMA straight from / into the
+ * caller's pages; any other host memory is accepted too and goes through the library's own pinned bounce buffers. */
+void *fbg_host_alloc(uint64_t bytes);
+void fbg_host_free(void *p);
 
 #ifdef __cplusplus
 }

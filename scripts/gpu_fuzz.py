@@ -49,9 +49,9 @@ while time.time() - t0 < budget:
         kw["gap_p"] = float(rng.choice([0.01, 0.05, 0.3])); kw["gap_run"] = int(rng.choice([1, 4, 20]))
     msa = random_msa(rng, m, n, alphabet=alphabet, **kw)
     env = ENVS[int(rng.integers(len(ENVS)))]
-    for k in ALL_KEYS:
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    for e in [eng] + parts:                               # fbg_set_option: the library does not read the environment
+        for k in ALL_KEYS:
+            e.set_option(k[4:].lower(), int(env.get(k, -1 if k in ("FBG_MSD_MIN", "FBG_BP_MIN") else 0)))
     tag = f"seed={seed} m={m} n={n} alphabet={alphabet} kw={kw} env={env}"
     try:
         ign = "N" if (alphabet == "ACGTN" and rng.random() < 0.5) else ""

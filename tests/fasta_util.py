@@ -33,3 +33,15 @@ def read_fasta(path, elastic=True, gap_limit=1):
     if not rows:
         return None, ids
     return np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), expected).copy(), ids
+
+
+def write_fasta(path, msa, ids, width=None):
+    with open(path, "wb") as fh:
+        for i, row in enumerate(msa):
+            fh.write(b">" + ids[i].encode() + b"\n")
+            s = row.tobytes()
+            if width:
+                for k in range(0, len(s), width):
+                    fh.write(s[k:k + width] + b"\n")
+            else:
+                fh.write(s + b"\n")

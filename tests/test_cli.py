@@ -101,16 +101,7 @@ def test_length_mismatch_warning(tmp_path):
 
 # ---- GPU: end-to-end bytes -----------------------------------------------------------------------
 
-def write_fasta(path, msa, ids, width=None):
-    with open(path, "wb") as fh:
-        for i, row in enumerate(msa):
-            fh.write(b">" + ids[i].encode() + b"\n")
-            s = row.tobytes()
-            if width:
-                for k in range(0, len(s), width):
-                    fh.write(s[k:k + width] + b"\n")
-            else:
-                fh.write(s + b"\n")
+from fasta_util import write_fasta  # noqa: E402
 
 
 @pytest.mark.gpu

@@ -3,7 +3,7 @@ oracle (oracle/fbg_oracle.c) on the same inputs.  Integer work: exact equality, 
 import numpy as np
 import pytest
 
-from conftest import random_msa
+from conftest import fbg_options, random_msa
 from oracle import pyoracle as O
 
 pytestmark = pytest.mark.gpu
@@ -308,14 +308,11 @@ def test_full_size_properties(engine):
     ends = torch.cat([b[:-1], torch.tensor([n - 1], device="cuda")])
     assert bool((d_f[starts] <= ends).all())             # every block is semi-repeat-free
     assert int((ends - starts + 1).max()) == int(d_mml[n])
-    os.environ["FBG_DP_LITERAL"] = "1"                   # statement-by-statement sweep of fbg.cpp:1968-2014
-    try:
+    with fbg_options(engine, {"FBG_DP_LITERAL": "1"}):   # statement-by-statement sweep of fbg.cpp:1968-2014
         d_b2 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         d_mml2 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         d_bt2 = torch.empty(n + 1, dtype=torch.int64, device="cuda")
         cnt2 = engine.minmax_dp_device(d_f.data_ptr(), n, d_b2.data_ptr(), d_mml2.data_ptr(), d_bt2.data_ptr())
-    finally:
-        del os.environ["FBG_DP_LITERAL"]
     assert cnt2 == cnt and torch.equal(d_mml, d_mml2) and torch.equal(d_bt, d_bt2) and torch.equal(d_b[:cnt], d_b2[:cnt])
     del d, d_g
     # C2: 64 x 100,000 non-elastic
@@ -404,9 +401,7 @@ def test_alternative_paths_stay_bit_identical(engine, env):
     rng = np.random.default_rng(4242)
     cases = [random_msa(rng, 20, 900, similar=0.96), random_msa(rng, 64, 400), random_msa(rng, 7, 1500, alphabet="AC", similar=0.99),
              random_msa(rng, 15, 700, gap_p=0.02, gap_run=5, n_p=0.01)]
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with fbg_options(engine, env):
         for msa in cases:
             f = O.compute_f(msa, ignore="N")
             g = engine.elastic_f(msa, ignorechars="N")
@@ -423,12 +418,6 @@ def test_alternative_paths_stay_bit_identical(engine, env):
                 gs, gprev, gbb = engine.repeatfree_dp(gv)
                 assert np.array_equal(gs, s) and np.array_equal(gprev, prev)
                 assert (bb is None) == (gbb is None) and (bb is None or np.array_equal(gbb, bb))
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 def _partitioned(engines, n, reversed=False):
@@ -566,18 +555,10 @@ def test_rank_scan_sampled_regime_matches_oracle(engine, env):
     rng = np.random.default_rng(99)
     a = random_msa(rng, 150, 30000)
     b = random_msa(rng, 150, 30000, similar=0.6)
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
+    with fbg_options(engine, env):
         for msa in (a, b):
             assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))
             assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa))
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 @pytest.mark.parametrize("alphabet", ["A", "AC", "ACGT", "ACGTN"])
@@ -609,8 +590,9 @@ def test_partitioned_index_wide_layout():
     import torch
     from founderblockgraphs_amd import Engine
     rng = np.random.default_rng(314)
-    os.environ["FBG_FORCE_WIDE"] = "1"
     engines = [Engine() for _ in range(3)]
+    for e in engines:
+        e.set_option("force_wide", 1)
     try:
         for (m, n, kw) in [(24, 500, {}), (50, 300, dict(alphabet="AC")), (40, 400, dict(similar=0.5))]:
             msa = random_msa(rng, m, n, **kw)
@@ -624,7 +606,6 @@ def test_partitioned_index_wide_layout():
             engines[0].sync()
             assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa))
     finally:
-        del os.environ["FBG_FORCE_WIDE"]
         for e in engines:
             e.close()
 
@@ -684,8 +665,7 @@ def test_msd_sort_gives_the_suffix_array(engine):
     rng = np.random.default_rng(123)
     msa = random_msa(rng, 48, 24000)
     T, SA, ISA, LCP = O.msa_index(msa)
-    os.environ["FBG_MSD_MIN"] = "1"
-    try:
+    with fbg_options(engine, {"FBG_MSD_MIN": "1"}):
         engine.msa_load_host(msa)
         engine.index_build()
         gT, gSA, gISA, gPL, gPR = engine.index_download()
@@ -693,25 +673,19 @@ def test_msd_sort_gives_the_suffix_array(engine):
         lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
         assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA])
         assert np.array_equal(engine.elastic_f(msa), O.compute_f(msa))
-    finally:
-        del os.environ["FBG_MSD_MIN"]
     m, n = 1000, 1_000_000
     d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
     engine.msa_synthetic(d.data_ptr(), m, n)
     engine.msa_set_device(d.data_ptr(), m, n)
     fs = []
     for env in ({}, {"FBG_NO_MSD_SORT": "1"}):
-        os.environ.update(env)
-        try:
+        with fbg_options(engine, env):
             engine.index_build()
             d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
             torch.cuda.synchronize()
             engine.scan_f(0, n, d_f.data_ptr())
             engine.sync()
             fs.append(d_f)
-        finally:
-            for k in env:
-                del os.environ[k]
     assert torch.equal(fs[0], fs[1])
 
 
@@ -777,8 +751,10 @@ def test_partitioned_index_msd_sort_of_pairs(P, layout):
     env = {"FBG_FULL_KEYS": "1", "FBG_MSD_MIN": "1"}
     if layout == "wide":
         env["FBG_FORCE_WIDE"] = "1"
-    os.environ.update(env)
     engines = [Engine() for _ in range(P)]
+    for e in engines:
+        for k, v in env.items():
+            e.set_option(k[4:].lower(), int(v))
     try:
         for (m, n, kw) in [(24, 500, {}), (50, 300, dict(alphabet="AC")), (9, 2500, dict(alphabet="ACGTN")), (40, 400, dict(similar=0.5))]:
             msa = random_msa(rng, m, n, **kw)
@@ -792,8 +768,6 @@ def test_partitioned_index_msd_sort_of_pairs(P, layout):
             engines[0].sync()
             assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa))
     finally:
-        for k in env:
-            del os.environ[k]
         for e in engines:
             e.close()
 
@@ -810,19 +784,12 @@ def test_msd_sort_capacity_fallback_is_seamless(engine, alphabet):
     msa = random_msa(rng, m, n, alphabet=alphabet)
     got = []
     for env in ({}, {"FBG_NO_MSD_SORT": "1"}):
-        os.environ.update(env)
-        try:
+        with fbg_options(engine, env):
             got.append(engine.elastic_f(msa))
-        finally:
-            for k in env:
-                del os.environ[k]
     assert np.array_equal(got[0], got[1])
     small = msa[:40, :4000]
-    os.environ["FBG_MSD_MIN"] = "1"
-    try:
+    with fbg_options(engine, {"FBG_MSD_MIN": "1"}):
         assert np.array_equal(engine.elastic_f(small), O.compute_f(small))
-    finally:
-        del os.environ["FBG_MSD_MIN"]
 
 
 # ---- non-elastic mode with gaps: segment2elasticValid (fbg.cpp:738-866) ------------------------------------
@@ -932,9 +899,7 @@ def test_records_by_position_passes(engine):
     against the oracle with the passes forced on small texts, and a gapped MSA large enough to take them by itself."""
     import os
     rng = np.random.default_rng(31)
-    old = {k: os.environ.get(k) for k in ("FBG_BP_MIN", "FBG_NO_RANKED")}
-    os.environ.update({"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"})
-    try:
+    with fbg_options(engine, {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"}):
         for (m, n, kw) in [(7, 1300, dict(gap_p=0.03, gap_run=5)), (33, 257, dict(similar=0.95)), (3, 3000, dict(alphabet="AC", similar=0.99)),
                            (65, 1290, dict(alphabet="ACGTN")), (2, 4097, {}), (9, 70000, dict(gap_p=0.01, gap_run=3))]:
             msa = random_msa(rng, m, n, **kw)
@@ -947,12 +912,6 @@ def test_records_by_position_passes(engine):
             lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
             assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA]), (m, n)
             assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1]), (m, n)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
     msa = random_msa(rng, 24, 800000, gap_p=0.05 / 16, gap_run=16, n_p=0.001)      # 1.9 * 10^7 symbols > 2^24
     assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), O.compute_f(msa, ignore="N", threads=8))
 
