@@ -54,8 +54,28 @@ def synth_msa_host(m, n_total, cols, seed=SEED):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[(h >> np.uint64(62)).astype(np.int64)]
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(m, n_total, sample_cols):
-    """Oracle (CPU restatement, 1 thread = the reference's default --threads=-1) on a column prefix."""
+    """Oracle (CPU restatement) on a column prefix, both legs of SURVEY.md 8(d): 1 thread = the reference's default
+    --threads=-1 (fbg.cpp:3392-3393), and T threads = all host cores with the reference's partition (ranges of
+    floor(n/T)+1 columns, fbg.cpp:2278-2284; index build and sweep stay single-threaded there as here)."""
     from oracle import pyoracle as O
     lib = None
     try:   # the reference builds with -march=native (Makefile:3); rebuild the port that way on this host
@@ -65,16 +85,124 @@ def cpu_baseline(m, n_total, sample_cols):
     except Exception:
         lib = O.lib()
     msa = synth_msa_host(m, n_total, sample_cols)
-    t = {}
-    t0 = time.perf_counter()
-    f = O.compute_f(msa, threads=1, timings=t, library=lib)
-    O.minmax_dp(f, library=lib)
-    dt = time.perf_counter() - t0
+    legs = {}
+    for threads in (1, host_cores()):
+        t = {}
+        t0 = time.perf_counter()
+        f = O.compute_f(msa, threads=threads, timings=t, library=lib)
+        O.minmax_dp(f, library=lib)
+        dt = time.perf_counter() - t0
+        legs[threads] = (dt, t)
+        if host_cores() == 1:
+            break
+    dt1, t1 = legs[1]
+    T = max(legs)
+    dtT, tT = legs[T]
     return {
-        "value": sample_cols / dt, "unit": "columns/s", "cores": 1, "kind": "port",
+        "value": sample_cols / dt1, "unit": "columns/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
         "sample": f"first {sample_cols} columns of the same {m}-row synthetic MSA, elastic, "
-                  f"index {t.get('index_s', 0):.2f}s + scan {t.get('scan_s', 0):.2f}s + DP, {dt:.2f}s total",
+                  f"index {t1.get('index_s', 0):.2f}s + scan {t1.get('scan_s', 0):.2f}s + DP, {dt1:.2f}s total",
+        "threaded": {"value": sample_cols / dtT, "unit": "columns/s", "cores": T,
+                     "sample": f"same sample, scan over {T} threads (column ranges of floor(n/T)+1): index {tT.get('index_s', 0):.2f}s "
+                               f"+ scan {tT.get('scan_s', 0):.2f}s + DP, {dtT:.2f}s total"},
     }
+
+
+def boundary_and_latency(F, torch, dev, m, n, d_msa):
+    """What the JSON `value` does not show: (a) the host-buffer boundary -- fbg_elastic_f + fbg_minmax_dp,
+    what INTEGRATION.md binds: MSA and f cross PCIe -- first call of a fresh context (workspaces allocated) and later
+    calls, from pageable memory and from memory of fbg_host_alloc; (b) the latency of ONE job with the sweep not
+    overlapped with a next job's index build."""
+    import ctypes as C
+    from founderblockgraphs_amd import _lib
+    out = {}
+    host = d_msa.view(m, n).cpu().numpy()                  # pageable
+    with F.Engine(dev) as eng:
+        ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            f = eng.elastic_f(host)
+            eng.minmax_dp(f)
+            ms.append(1e3 * (time.perf_counter() - t0))
+        out["boundary_ms"] = {"first_call": ms[0], "warm": min(ms[1:]), "host_memory": "pageable (library stages it through pinned buffers)"}
+        L = _lib.lib()
+        p = L.fbg_host_alloc(m * n)
+        if p:
+            pinned = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(m, n))
+            np.copyto(pinned, host)
+            ms = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                f = eng.elastic_f(pinned)
+                eng.minmax_dp(f)
+                ms.append(1e3 * (time.perf_counter() - t0))
+            out["boundary_ms"]["warm_pinned"] = min(ms)
+            del pinned
+            L.fbg_host_free(C.c_void_p(p))
+        del host
+        # one job, start to boundaries on the device, nothing overlapped
+        d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        eng.msa_set_device(d_msa.data_ptr(), m, n)
+        ms = []
+        for _ in range(3):
+            d_f.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.index_build()
+            eng.scan_f(0, n, d_f.data_ptr())
+            eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+            eng.sync()
+            ms.append(1e3 * (time.perf_counter() - t0))
+        out["latency_ms"] = min(ms[1:])
+    return out
+
+
+def other_workloads(F, torch, dev):
+    """The inputs that leave the headline's fast path, so that the JSON line shows them next to it (not part of
+    `value`): similar rows (star phylogeny, one iid ancestor, every cell substituted with p = 0.01) and BASELINE config 5
+    (gap runs + N, --ignore-chars=N)."""
+    res = []
+
+    def run(name, m, n, d, ignore=""):
+        with F.Engine(dev) as eng:
+            d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+            d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            eng.msa_set_device(d.data_ptr(), m, n)
+            best, stages, blocks = None, None, None
+            for _ in range(3):
+                d_f.zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.index_build(ignorechars=ignore)
+                eng.scan_f(0, n, d_f.data_ptr())
+                blocks = eng.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr())
+                eng.sync()
+                dt = time.perf_counter() - t0
+                if best is None or dt < best:
+                    best, stages = dt, {k: round(v[0], 3) for k, v in eng.stage_ms().items()}
+            res.append({"workload": name, "rows": m, "cols": n, "ms_per_step": 1e3 * best, "columns_per_s": n / best,
+                        "blocks": blocks, "stages_ms": stages})
+
+    m, n = 1000, 200_000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    anc = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.uint8)
+    d = torch.empty((m, n), dtype=torch.uint8, device="cuda")
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    for i0 in range(0, m, 50):
+        i1 = min(m, i0 + 50)
+        mut = torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.01
+        sub = torch.randint(0, 4, (i1 - i0, n), device="cuda", generator=g, dtype=torch.uint8)
+        d[i0:i1] = lut[torch.where(mut, sub, anc.expand(i1 - i0, n)).long()]
+    run("star phylogeny 1000 x 200000, p = 0.01 (similar rows), --elastic", m, n, d.reshape(-1))
+    del d
+    m, n = 256, 2_000_000
+    d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+    with F.Engine(dev) as eng:
+        eng.msa_synthetic(d.data_ptr(), m, n, gap_fraction=0.05, gap_run=16, n_fraction=0.001)
+        eng.sync()
+    run("BASELINE config 5: synthetic 256 x 2000000, 5% gap runs of 16 + 0.1% N, --elastic --ignore-chars=N", m, n, d, ignore="N")
+    return res
 
 
 def measured_traffic(m, n, kernel):
@@ -99,6 +227,7 @@ def main():
     ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-cols", type=int, default=40_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip boundary_ms / latency_ms / other_workloads (N=1 extras outside the timed region)")
     ap.add_argument("--force-row-pairs", type=int, default=0, help="debug: use the row-group-pair plan with this many rows per pair text")
     ap.add_argument("--replicated-index", action="store_true", help="N>1: every rank builds the whole index (column shards) instead of one key range of it")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL, default) | gloo (debug: several ranks on one GPU)")
@@ -119,10 +248,12 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
+        # a rank that dies leaves the others in a collective: bounded, so that the job ends with an error instead of hanging
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=timedelta(seconds=300))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timedelta(seconds=300))
 
     from founderblockgraphs_amd import distributed as D
     m, n = args.rows, args.cols_per_gpu * world
@@ -312,6 +443,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(m, n, min(args.cpu_sample_cols, n))
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            if sweeper is not None:
+                sweeper.eng.release_scratch()
+            out.update(boundary_and_latency(F, torch, dev, m, n, whole_msa()))
+            bufs.clear()
+            eng.release_scratch()
+            out["other_workloads"] = other_workloads(F, torch, dev)
         print(json.dumps(out), flush=True)
     if sweeper is not None:
         sweeper.pool.shutdown()

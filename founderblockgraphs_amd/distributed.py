@@ -36,14 +36,40 @@ def all_gather_columns(f_local, n, rank, world, group=None):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)])
 
 
+class RankFailed(RuntimeError):
+    """Some rank's engine call failed: raised on EVERY rank, after the collective that carried the flag."""
+
+
+def agree(error, world, group=None, device="cpu"):
+    """All ranks learn whether any of them caught an exception during the phase that just ended (one all-reduce of a
+    single word) and raise together -- a rank that raised alone would leave the others waiting in the next collective
+    until the process group's timeout."""
+    if world > 1:
+        flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        failed = bool(flag.item())
+    else:
+        failed = error is not None
+    if error is not None:
+        raise error
+    if failed:
+        raise RankFailed("another rank failed in this phase; see its log")
+
+
 def segment_columns_sharded(n, scan_shard, sweep, rank=None, world=None, group=None):
     """scan_shard(x0, x1) -> 1-D integer tensor with f[x0..x1); sweep(f_full) -> boundaries (rank 0 only).
     Returns (f_full, boundaries or None)."""
     world = dist.get_world_size(group) if world is None else world
     rank = dist.get_rank(group) if rank is None else rank
     x0, x1 = shard_range(n, rank, world)
-    f_local = scan_shard(x0, x1)
-    assert f_local.numel() == x1 - x0
+    error, f_local = None, None
+    try:
+        f_local = scan_shard(x0, x1)
+        if f_local.numel() != x1 - x0:
+            raise ValueError(f"scan_shard returned {f_local.numel()} values for columns [{x0}, {x1})")
+    except Exception as e:          # noqa: BLE001 -- carried to every rank below
+        error = e
+    agree(error, world, group, device=f_local.device if f_local is not None else "cpu")
     f_full = all_gather_columns(f_local, n, rank, world, group)
     boundaries = sweep(f_full) if rank == 0 else None
     return f_full, boundaries
@@ -131,27 +157,64 @@ def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=Fal
             torch.cuda.current_stream().synchronize()
         engine.sync()
 
+    # Failure agreement is folded into the two collectives of the path: a rank whose engine call raised sends a blob
+    # whose verdict word has its top bit set / a column-maxima array whose verdict word is 2; every rank checks the
+    # gathered / reduced words and raises, instead of one rank raising alone and the others hanging in the collective.
+    ERR_BIT = 1 << 63
+    tail_word = (PART_HALO_BYTES - 16) // 8                 # the blob's verdict word (u64), see k_halo_export
+
+    def tails():
+        return blobs.view(torch.int64).view(world, PART_HALO_BYTES // 8)[:, tail_word].cpu()
+
     fence()
-    engine.part_index_build(rank, world, blob.data_ptr(), reversed)   # verdict travels inside the blob
+    error = None
+    try:
+        engine.part_index_build(rank, world, blob.data_ptr(), reversed)   # verdict travels inside the blob
+    except Exception as e:          # noqa: BLE001
+        error = e
+        blob.zero_()
+        blob.view(torch.int64)[tail_word] = -(1 << 63)      # ERR_BIT as a signed word
     fence()
     if world > 1:
         dist.all_gather_into_tensor(blobs, blob, group=group)
     else:
         blobs.copy_(blob)
     fence()
-    engine.part_scan(blobs.data_ptr(), gmax.data_ptr())               # verdict travels in gmax[n]
+    if error is not None:
+        raise error
+    if bool((tails() < 0).any()):
+        raise RankFailed("fbg_part_index_build failed on another rank; see its log")
+    try:
+        engine.part_scan(blobs.data_ptr(), gmax.data_ptr())           # verdict travels in gmax[n]
+    except Exception as e:          # noqa: BLE001
+        error = e
+        gmax.zero_()
+        gmax[n] = 2
     fence()
     if world > 1:
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
     fence()
+    if error is not None:
+        raise error
+    if int(gmax[n].item()) >= 2:
+        raise RankFailed("fbg_part_scan failed on another rank; see its log")
     verdict = engine.part_finish(gmax.data_ptr())
     if verdict == 2:
         # some column's maximum did not clear the scan's threshold (every rank sees the same reduced maxima and takes
         # this branch together): exact re-scan without threshold, reduce once more
-        engine.part_rescan(gmax.data_ptr())
+        try:
+            engine.part_rescan(gmax.data_ptr())
+        except Exception as e:      # noqa: BLE001
+            error = e
+            gmax.zero_()
+            gmax[n] = 2
         fence()
         if world > 1:
             dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
         fence()
+        if error is not None:
+            raise error
+        if int(gmax[n].item()) >= 2:
+            raise RankFailed("fbg_part_rescan failed on another rank; see its log")
         verdict = engine.part_finish(gmax.data_ptr())
     return verdict == 1
