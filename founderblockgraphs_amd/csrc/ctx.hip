@@ -162,7 +162,7 @@ static const OptKey g_opt_keys[] = {
     {"bp_min", &FbgOptions::bp_min}, {"record_scatter", &FbgOptions::record_scatter}, {"lcp_text", &FbgOptions::lcp_text},
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
-    {"dp_tile", &FbgOptions::dp_tile},
+    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan},
 };
 
 // The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of
@@ -241,7 +241,8 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
                       &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->xbits, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
                       &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->msd_w, &ctx->msd_v, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
-                      &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep};
+                      &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d,
+                      &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     for (auto &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
@@ -302,7 +303,8 @@ int fbg_release_scratch(fbg_ctx *ctx)
     const bool sorted_in_A = ctx->ranked && ctx->rk_keys == ctx->keysA.as<uint64_t>();
     DevBuf *bufs[] = {sorted_in_A ? &ctx->keysB : &ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list, &ctx->msd_w, &ctx->msd_v,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
-                      &ctx->dp_g, &ctx->dp_h};
+                      &ctx->dp_g, &ctx->dp_h, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d, &ctx->ps_e, &ctx->ps_f,
+                      &ctx->ps_g, &ctx->ps_h};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     return FBG_OK;
 }

@@ -10,6 +10,7 @@
 // The sweep itself is inherently sequential (step j reads minmaxlength[] of earlier columns); one
 // lane walks it with all state in device memory, exactly the statements of fbg.cpp:1968-2014.
 #include "fbg_internal.h"
+#include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 #define DP_NONE 0xffffffffu
@@ -24,8 +25,10 @@ __global__ void k_dp_keys(const uint64_t *__restrict__ f, uint64_t n, uint32_t *
     if (fx > n || fx < x) { atomicAdd(bad, 1ull); fx = fx > n ? n : x; }   // f[x] in [x, n] by construction
     e[x] = (uint32_t)(fx + 1);
     atomicAdd(&hist[fx + 1], 1u);
-    // longest minimal extension f[x]+1-x, reduced per wave then one atomic
-    unsigned long long ext = fx + 1 - x;
+    // longest minimal extension f[x]+1-x, reduced per wave then one atomic.  A column with f[x] = n (a row runs out of
+    // symbols; only without the elastic tricks, fbg.cpp:1659-1663) can start no block at all -- its entry would be read
+    // at step n+1 -- and does not count
+    unsigned long long ext = fx < n ? fx + 1 - x : 0;
     for (int d = 32; d >= 1; d >>= 1) ext = max(ext, (unsigned long long)__shfl_down(ext, d, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(bad + 1, ext);
 }
@@ -453,8 +456,10 @@ __global__ __launch_bounds__(256) void k_dp_compose(uint8_t *__restrict__ Wt, ui
 template <int R>
 __global__ __launch_bounds__(64) void k_dp_expand(const uint8_t *__restrict__ Wt, const uint8_t *__restrict__ Sg,
                                                   uint32_t n, uint32_t nblocks, uint32_t F, uint32_t *__restrict__ mml,
-                                                  unsigned long long *__restrict__ flag)
+                                                  unsigned long long *__restrict__ flag, uint32_t first_valid)
 {
+    // first_valid = f[0] + 1: no block ends before that step, and the reference's sweep leaves its running S there:
+    // minmaxlength[j] = n + j, backtrack[j] = -1 (fbg.cpp:1967, 2007-2010 with backtrack_S still size_type(-1))
     constexpr uint32_t WN = 64 * R;
     __shared__ uint8_t s_state[WN];
     const uint32_t lane = threadIdx.x;
@@ -477,19 +482,23 @@ __global__ __launch_bounds__(64) void k_dp_expand(const uint8_t *__restrict__ Wt
             }
             const uint32_t j = WN * b + 1 + t;
             if (j <= n) {
-                mml[j] = acc;
-                if (acc >= (R == 1 ? 64u : 255u)) flag[4] = 1;
+                if (j < first_valid) mml[j] = n + j;
+                else {
+                    mml[j] = acc;
+                    if (acc >= (R == 1 ? 64u : 255u)) flag[4] = 1;
+                }
             }
         }
     }
 }
 
 __global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restrict__ ext7, uint32_t n, uint32_t window,
-                        uint32_t *__restrict__ bt, unsigned long long *__restrict__ flag)
+                        uint32_t *__restrict__ bt, unsigned long long *__restrict__ flag, uint32_t first_valid)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n) return;
     if (j == 0) { bt[0] = 0; return; }
+    if (j < first_valid) { bt[j] = DP_NONE; return; }
     const uint32_t L = mml[j];
     uint32_t best_age = 0;                    // youngest count_solutions-kind candidate (age <= its value == L)
     bool s_kind = false;                      // candidate of age L with a smaller value: the S / backtrack_S branch
@@ -498,6 +507,7 @@ __global__ void k_dp_bt(const uint32_t *__restrict__ mml, const uint8_t *__restr
         const uint32_t x = j - a;
         if (ext7[x] > a) continue;            // block [x, j) not valid yet: f[x]+1 > j
         const uint32_t v = mml[x];
+        if (v > n) continue;                  // a column before first_valid: no solution ends there (fbg.cpp:1973)
         if (a > v) { if (a == L) s_kind = true; }
         else if (v == L && best_age == 0) best_age = a;
     }
@@ -703,15 +713,20 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     if (hk[2] != 0) return fbg_fail(ctx, FBG_ERR_INVALID, "f[] has %llu entries outside [x, n]", hk[2]);
     const unsigned long long max_ext = hk[3];
     int R = 0;
-    if (f0 == 0 && !ctx->opt.dp_literal) {
+    // f[0] > 0 (only without the elastic tricks): nothing ends before step f[0] + 1, where the sweep stands exactly as
+    // it does after step 1 otherwise (S = f[0] + 1, I = f[0], no counts: the invariant of the derivation above holds
+    // from there on); the steps before it keep the running S of fbg.cpp:1967 and are filled in closed form.  The wave
+    // sweep (k_dp_wave) starts from column 0 being a candidate at once and keeps its f[0] = 0 condition.
+    const uint32_t first_valid = (uint32_t)std::min<uint64_t>(f0 + 1, n + 1);
+    if (f0 < n && !ctx->opt.dp_literal) {
         const unsigned long long bound = 2 * max_ext + 2;   // minmaxlength[j] <= 2*max_ext + 1
-        R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 254 ? 4 : bound <= 512 ? 8 : bound <= 1024 ? 16 : 0;
+        R = bound <= 64 ? 1 : bound <= 128 ? 2 : bound <= 254 ? 4 : (f0 == 0 && bound <= 512) ? 8 : (f0 == 0 && bound <= 1024) ? 16 : 0;
     }
     bool literal = R == 0;
     bool tiled = false;
     if (!literal) {
         bool settled = false;
-        if (!ctx->opt.dp_wave) {
+        if (!ctx->opt.dp_wave || f0 != 0) {
             // sweeps that work straight from f (no bucket order needed).  The window that is provably enough
             // (64 R >= 2 max_ext + 2) is rarely needed: start with the smallest one that holds every extension and
             // widen when the sweep reports a value at its limit
@@ -720,7 +735,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             while (64ull * Rt < max_ext + 2 && Rt < 4) Rt *= 2;
             if (ctx->opt.dp_safe_window) Rt = R;
             for (; Rt <= 4 && Rt <= R && !settled; Rt *= 2) {
-                const bool tile = Rt == 1 && ctx->opt.dp_tile;
+                const bool tile = Rt == 1 && ctx->opt.dp_tile && f0 == 0;
                 FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
                 hipLaunchKernelGGL(k_dp_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n,
                                    tile ? 127u : 255u, ext7, clen);
@@ -745,13 +760,13 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext7, (const uint8_t *)nullptr, (uint32_t)n, nblocks, Wt);             \
         hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
         hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);        \
-        hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc);    \
+        hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc, first_valid);    \
     } while (0)
                     if (Rt == 1) FBG_DP_PIPE(1);
                     else if (Rt == 2) FBG_DP_PIPE(2);
                     else FBG_DP_PIPE(4);
 #undef FBG_DP_PIPE
-                    hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, WN, bt, sc);
+                    hipLaunchKernelGGL(k_dp_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext7, (uint32_t)n, WN, bt, sc, first_valid);
                 }
                 FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
                 FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -761,7 +776,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             if (!settled) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
         }
         if (!settled) FBG_TRY(build_buckets());        // also zeroes what the abandoned attempts left in count / bcount / mml / bt
-        if (!settled && (R > 4 || ctx->opt.dp_wave)) {
+        if (!settled && f0 == 0 && (R > 4 || ctx->opt.dp_wave)) {
             switch (R) {
             case 1: hipLaunchKernelGGL((k_dp_wave<1>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
             case 2: hipLaunchKernelGGL((k_dp_wave<2>), dim3(1), dim3(64), 0, st, bstart, items, (uint32_t)n, mml, bt, sc); break;
@@ -935,7 +950,7 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
         hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext1, amin, (uint32_t)n, nblocks, Wt);  \
         hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
         hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, sp, sc);         \
-        hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, sp, sc + 8); \
+        hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, sp, sc + 8, 0u); \
     } while (0)
             if (R == 1) FBG_NE_PIPE(1);
             else if (R == 2) FBG_NE_PIPE(2);

@@ -37,7 +37,7 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0;
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0;
 };
 
 struct fbg_ctx {
@@ -97,6 +97,7 @@ struct fbg_ctx {
     DevBuf msd_w, msd_v;       // sub-bucket stretches of the MSD sort of 12-byte slots (msd_sort_pairs.hip)
     DevBuf dp_a, dp_b, dp_c, dp_d, dp_e, dp_f, dp_g, dp_h, io_a, io_b, io_c, io_d;
     DevBuf bt_up, bt_dep;      // binary-lifting tables of the parallel backtrack
+    DevBuf ps_a, ps_b, ps_c, ps_d, ps_e, ps_f, ps_g, ps_h;   // group / run tables of the scan for similar rows (pure_scan.hip)
 
     StageTimer timers[FBG_STAGE_COUNT];
 };
@@ -145,6 +146,7 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len);  /
 int fbg_suffix_sort(fbg_ctx *ctx);                                            // suffix_sort.hip
 int fbg_neighbour_lcp(fbg_ctx *ctx);                                          // lcp.hip
 int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);       // rank_scan.hip
+int fbg_pure_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);       // pure_scan.hip
 int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out);
 int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
 #define FBG_STAGE_RANKSCAN FBG_STAGE_TILE

@@ -1,0 +1,348 @@
+// pure_scan.hip -- the extension scan in suffix-array order for SIMILAR rows (gap-free MSAs, no ignore characters).
+//
+// compute_f (fbg.cpp:1610-1694) asks, for row i at column x, for the deepest ancestor of the leaf that still has an
+// uncoloured leaf below it: g = 1 + the longest match of the row's suffix with ANY text position that is not the
+// pointer of a row at column x.  When the rows resemble each other -- a pangenome -- the suffixes of
+// one column agree with each other for hundreds of symbols, and a suffix sorter that resolves them against each other
+// (prefix doubling: seven and more rounds of global sorts) answers a question nobody asked: matches between the rows of
+// one column never count.  What counts is the longest match with another COLUMN, and that is short (about log_sigma of
+// the text length) unless the sequence itself repeats.  So, after ONE sort by a K-symbol key:
+//
+//   * suffixes with equal keys form a group; a group whose members all sit in one column is "pure": its inner order
+//     is irrelevant and every member has the same extension, 1 + the number of leading symbols its key shares with
+//     the nearest group (on either side) that holds a suffix of another column -- pure groups of the same column in
+//     between belong to the same run of coloured leaves (fbg.cpp:1633-1641) and are skipped.  No text access;
+//   * a group with members from several columns is "mixed": its members match each other in at least K symbols and
+//     nobody else that far, so a member's extension is 1 + its longest match with a member of another column: text
+//     comparison inside the group, all pairs (these are the repeats of the sequence itself, and chance);
+//   * keys use the compact coding (suffix_sort.hip): a suffix with fewer than K symbols left in its row ("short") has
+//     zeros where its row has ended.  Key-derived matches are clamped to the symbols both suffixes really have; a pure
+//     group next to a mixed group with a short member compares its text with that group's members instead.
+//
+// The work is done on a table of groups (one streaming pass over the sorted slots builds it), then on the runs of that
+// table: similar rows have far fewer groups than suffixes (a star phylogeny of 1000 rows, 1 % substitutions: 20 times
+// fewer).  Declines (record path, suffix_sort.hip) when the mixed groups are too large or too many -- long repeats.
+#include "rank_common.h"
+#include <rocprim/rocprim.hpp>
+
+#define PS_THREADS 256
+#define PS_ITEMS 8
+#define PS_TILE (PS_THREADS * PS_ITEMS)
+#define PS_MIXED 1u
+#define PS_SHORT 2u
+#define PS_MAX_GROUP 8192            // members of a mixed group (held in LDS)
+#define PS_LIST_CAP (1u << 21)
+
+struct PsArgs {
+    RankArgs r;
+    uint32_t *tile_heads;            // heads per tile -> exclusive offsets
+    uint32_t *gstart, *grem, *gflags;   // groups: first slot (gstart[G] = N), symbols left of the first member, PS_*
+    uint64_t G;
+    uint32_t *rtile;                 // run heads per tile of groups -> exclusive offsets
+    uint32_t *rstart, *rid;          // runs: first group (rstart[R] = G); run of every group
+    uint64_t R;
+    uint32_t *mixed;                 // mixed groups
+    uint2 *slow;                     // (pure group, boundary group that is mixed with a short member)
+    unsigned long long *counters;    // [0] mixed groups, [1] slow entries, [2] sum of (mixed size)^2, [3] decline flag
+};
+
+// exclusive prefix of one count per thread over the workgroup; *total = sum
+__device__ __forceinline__ uint32_t ps_block_excl(uint32_t v, uint32_t *total, uint32_t *lds)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < PS_THREADS / 64; k++) { const uint32_t s = lds[k]; if (k < w) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ---- groups: maximal stretches of equal keys --------------------------------------------------------------------
+template <int L, bool FILL> __global__ __launch_bounds__(PS_THREADS) void k_ps_groups(PsArgs a)
+{
+    __shared__ uint32_t lds[PS_THREADS / 64];
+    const uint64_t N = a.r.N;
+    const uint64_t k0 = (uint64_t)blockIdx.x * PS_TILE + (uint64_t)threadIdx.x * PS_ITEMS;
+    uint64_t key[PS_ITEMS + 1];
+    uint32_t rem[PS_ITEMS + 1];
+    // slot k0 - 1 first (the tile's left neighbour for its first thread)
+    {
+        const bool ok = k0 > 0 && k0 - 1 < N;
+        const uint64_t w = ok ? a.r.keys[k0 - 1] : 0ull;
+        key[0] = w >> a.r.pb;
+        rem[0] = (FILL && ok) ? rs_rem<L>(a.r, rs_pos_of<L>(a.r, w, (L != FBG_SLOTS_PACKED) ? a.r.vals[k0 - 1] : 0u)) : 0u;
+    }
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++) {
+        const uint64_t k = k0 + j;
+        const bool ok = k < N;
+        const uint64_t w = ok ? a.r.keys[k] : 0ull;
+        key[j + 1] = w >> a.r.pb;
+        rem[j + 1] = (FILL && ok) ? rs_rem<L>(a.r, rs_pos_of<L>(a.r, w, (L != FBG_SLOTS_PACKED) ? a.r.vals[k] : 0u)) : 0u;
+        if (ok && (k == 0 || key[j + 1] != key[j])) heads |= 1u << j;
+    }
+    uint32_t total;
+    const uint32_t before = ps_block_excl((uint32_t)__popc(heads), &total, lds);
+    if (!FILL) {
+        if (threadIdx.x == 0) a.tile_heads[blockIdx.x] = total;
+        return;
+    }
+    // group of an item = heads in earlier tiles + heads up to and including it - 1
+    uint32_t gid = a.tile_heads[blockIdx.x] + before - 1;     // group of the slot before the thread's first (wraps for slot 0: unused)
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++) {
+        const uint64_t k = k0 + j;
+        if (k >= N) break;
+        if ((heads >> j) & 1u) {
+            gid++;
+            a.gstart[gid] = (uint32_t)k;
+            a.grem[gid] = rem[j + 1];
+        } else if (rem[j + 1] != rem[j]) {
+            atomicOr(&a.gflags[gid], PS_MIXED);              // rare with similar rows: no contention to speak of
+        }
+        if (rem[j + 1] < (uint32_t)a.r.K) atomicOr(&a.gflags[gid], PS_SHORT);
+    }
+}
+
+// ---- runs: maximal stretches of pure groups of one column -------------------------------------------------------
+__device__ __forceinline__ bool ps_run_head(const PsArgs &a, uint64_t g)
+{
+    if (g == 0) return true;
+    return ((a.gflags[g] | a.gflags[g - 1]) & PS_MIXED) || a.grem[g] != a.grem[g - 1];
+}
+
+template <bool FILL> __global__ __launch_bounds__(PS_THREADS) void k_ps_runs(PsArgs a)
+{
+    __shared__ uint32_t lds[PS_THREADS / 64];
+    const uint64_t g0 = (uint64_t)blockIdx.x * PS_TILE + (uint64_t)threadIdx.x * PS_ITEMS;
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++)
+        if (g0 + j < a.G && ps_run_head(a, g0 + j)) heads |= 1u << j;
+    uint32_t total;
+    const uint32_t before = ps_block_excl((uint32_t)__popc(heads), &total, lds);
+    if (!FILL) {
+        if (threadIdx.x == 0) a.rtile[blockIdx.x] = total;
+        return;
+    }
+    uint32_t run = a.rtile[blockIdx.x] + before - 1;
+#pragma unroll
+    for (int j = 0; j < PS_ITEMS; j++) {
+        const uint64_t g = g0 + j;
+        if (g >= a.G) break;
+        if ((heads >> j) & 1u) { run++; a.rstart[run] = (uint32_t)g; }
+        a.rid[g] = run;
+    }
+}
+
+// ---- values of the pure groups; lists of the rest ---------------------------------------------------------------
+template <int L> __global__ void k_ps_values(PsArgs a)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.G) return;
+    const uint32_t fl = a.gflags[g], s0 = a.gstart[g];
+    if (fl & PS_MIXED) {
+        const unsigned long long s = a.gstart[g + 1] - s0;
+        const unsigned long long e = atomicAdd(&a.counters[0], 1ull);
+        if (e < PS_LIST_CAP) a.mixed[e] = (uint32_t)g; else a.counters[3] = 1;
+        atomicAdd(&a.counters[2], s * s);
+        if (s > PS_MAX_GROUP) a.counters[3] = 1;
+        return;
+    }
+    const uint32_t rem = a.grem[g];
+    if (rem == 0) return;                                      // '#' / sentinel: never a row pointer
+    const uint64_t key = rs_key<L>(a.r, s0);
+    const uint32_t col = rs_col_of_rem(a.r, rem);
+    const uint32_t run = a.rid[g];
+    const uint64_t lb = a.rstart[run], rb = a.rstart[run + 1];
+    // the two groups that bound the run: each holds a suffix of another column (a mixed group, or a pure group of
+    // another column -- a pure group of this column would belong to the run)
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        if (side == 0 ? lb == 0 : rb >= a.G) continue;         // nothing beyond: the extension from this side is 1
+        const uint64_t h = side == 0 ? lb - 1 : rb;
+        const uint32_t flh = a.gflags[h];
+        const uint64_t keyh = rs_key<L>(a.r, a.gstart[h]);
+        uint32_t lcp = min(rs_key_lcp(key, keyh, a.r.b, a.r.key_bits), rem);
+        if (flh & PS_MIXED) {
+            if (flh & PS_SHORT) {                              // which of its members reach how far: by their text
+                const unsigned long long e = atomicAdd(&a.counters[1], 1ull);
+                if (e < PS_LIST_CAP) a.slow[e] = make_uint2((uint32_t)g, (uint32_t)h); else a.counters[3] = 1;
+                continue;
+            }
+        } else {
+            lcp = min(lcp, a.grem[h]);                         // '#' / sentinel: 0
+        }
+        rs_update(a.r, col, lcp + 1);
+    }
+    rs_update(a.r, col, 1u);
+}
+
+// one workgroup per mixed group: every member against every member of another column
+template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs a, uint32_t count)
+{
+    __shared__ uint32_t spos[PS_MAX_GROUP], srem[PS_MAX_GROUP];
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t g = a.mixed[e];
+        const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
+        if (s > PS_MAX_GROUP) continue;                        // flagged by k_ps_values
+        const uint32_t from = (a.gflags[g] & PS_SHORT) ? 0u : (uint32_t)a.r.K;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < s; i += PS_THREADS) {
+            const uint64_t p = rs_pos<L>(a.r, (uint64_t)s0 + i);
+            spos[i] = (uint32_t)p;
+            srem[i] = rs_rem<L>(a.r, p);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < s; i += PS_THREADS) {
+            const uint32_t rem = srem[i];
+            if (rem == 0) continue;
+            const uint64_t p = spos[i];
+            uint32_t best = 0;
+            for (uint32_t q = 0; q < s; q++) {
+                if (srem[q] == rem) continue;                  // same column: coloured together
+                best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
+            }
+            rs_update(a.r, rs_col_of_rem(a.r, rem), fbg_clamp_lcp(best) + 1);
+        }
+    }
+}
+
+// a pure group beside a mixed group with a short member: its text against that group's members of other columns
+template <int L> __global__ void k_ps_slow(PsArgs a, uint32_t count)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const uint2 gh = a.slow[e];
+    const uint64_t p = rs_pos<L>(a.r, a.gstart[gh.x]);
+    const uint32_t rem = a.grem[gh.x];
+    uint32_t best = 0;
+    for (uint64_t k = a.gstart[gh.y]; k < a.gstart[gh.y + 1]; k++) {
+        const uint64_t q = rs_pos<L>(a.r, k);
+        if (rs_rem<L>(a.r, q) == rem) continue;
+        best = max(best, fbg_extend_match(a.r.T, p, q, 0));
+    }
+    rs_update(a.r, rs_col_of_rem(a.r, rem), fbg_clamp_lcp(best) + 1);
+}
+
+template <class F> static int ps_with_tmp(fbg_ctx *ctx, F &&call)
+{
+    size_t bytes = 0;
+    hipError_t e = call(nullptr, bytes);
+    if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim size query: %s", hipGetErrorString(e));
+    FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+    size_t have = ctx->tmp.cap;
+    e = call(ctx->tmp.p, have);
+    if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim call: %s", hipGetErrorString(e));
+    return FBG_OK;
+}
+
+#define PS_LAUNCH(kernel, layout, grid, block, st, ...)                                                              \
+    do {                                                                                                             \
+        if ((layout) == FBG_SLOTS_PACKED) hipLaunchKernelGGL((kernel<FBG_SLOTS_PACKED>), grid, block, 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<FBG_SLOTS_PAIRS>), grid, block, 0, st, __VA_ARGS__);                              \
+    } while (0)
+#define PS_LAUNCH_GROUPS(layout, fill, grid, st, a)                                                                             \
+    do {                                                                                                                        \
+        if ((layout) == FBG_SLOTS_PACKED) { if (fill) hipLaunchKernelGGL((k_ps_groups<FBG_SLOTS_PACKED, true>), grid, dim3(PS_THREADS), 0, st, a);  \
+                                            else hipLaunchKernelGGL((k_ps_groups<FBG_SLOTS_PACKED, false>), grid, dim3(PS_THREADS), 0, st, a); }    \
+        else { if (fill) hipLaunchKernelGGL((k_ps_groups<FBG_SLOTS_PAIRS, true>), grid, dim3(PS_THREADS), 0, st, a);                             \
+               else hipLaunchKernelGGL((k_ps_groups<FBG_SLOTS_PAIRS, false>), grid, dim3(PS_THREADS), 0, st, a); }                               \
+    } while (0)
+
+// Called by fbg_suffix_sort after the round-0 sort of the compact keys, when the slot-level scan (rank_scan.hip) is
+// not the way (similar rows).  *done = 1: the column maxima are complete (ctx->ranked); 0: continue with the record path.
+int fbg_pure_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &geom, int *done)
+{
+    *done = 0;
+    const uint64_t N = ctx->N, n = ctx->n;
+    const int layout = rs_layout(geom);
+    if (layout == FBG_SLOTS_WIDE || N >= (1ull << 32)) return FBG_OK;     // 32-bit slot indices in the group table
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
+    int launches = 0;
+    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    PsArgs a;
+    rs_args_init(ctx, a.r, keys, vals, N, layout, geom.pb, geom.b, geom.key_bits, geom.K);
+    a.counters = ctx->scalars.as<unsigned long long>() + 40;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 4 * sizeof(unsigned long long), st));
+    // groups
+    const unsigned tiles = fbg_blocks(N, PS_TILE);
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, ((size_t)tiles + 1) * 4));
+    a.tile_heads = ctx->ps_a.as<uint32_t>();
+    a.gstart = a.grem = a.gflags = nullptr; a.G = 0;
+    PS_LAUNCH_GROUPS(layout, false, dim3(tiles), st, a);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.tile_heads + tiles, 0, 4, st));
+    FBG_TRY(ps_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::exclusive_scan(tmp, bytes, a.tile_heads, a.tile_heads, 0u, (size_t)tiles + 1, rocprim::plus<uint32_t>(), st);
+    }));
+    uint32_t G32 = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&G32, a.tile_heads + tiles, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    launches += 2;
+    const uint64_t G = G32;
+    a.G = G;
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (G + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, (G + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_d, (G + 1) * 4));
+    a.gstart = ctx->ps_b.as<uint32_t>(); a.grem = ctx->ps_c.as<uint32_t>(); a.gflags = ctx->ps_d.as<uint32_t>();
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.gflags, 0, (G + 1) * 4, st));
+    PS_LAUNCH_GROUPS(layout, true, dim3(tiles), st, a);
+    const uint32_t N32 = (uint32_t)N;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(a.gstart + G, &N32, 4, hipMemcpyHostToDevice, st));
+    // runs
+    const unsigned gtiles = fbg_blocks(G, PS_TILE);
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_e, ((size_t)gtiles + 1) * 4));
+    a.rtile = ctx->ps_e.as<uint32_t>();
+    a.rstart = a.rid = nullptr; a.R = 0;
+    hipLaunchKernelGGL((k_ps_runs<false>), dim3(gtiles), dim3(PS_THREADS), 0, st, a);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.rtile + gtiles, 0, 4, st));
+    FBG_TRY(ps_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::exclusive_scan(tmp, bytes, a.rtile, a.rtile, 0u, (size_t)gtiles + 1, rocprim::plus<uint32_t>(), st);
+    }));
+    uint32_t R32 = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&R32, a.rtile + gtiles, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));               // (also: N32 above lives on this frame)
+    launches += 3;
+    a.R = R32;
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_f, ((size_t)R32 + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_g, (G + 1) * 4));
+    a.rstart = ctx->ps_f.as<uint32_t>(); a.rid = ctx->ps_g.as<uint32_t>();
+    hipLaunchKernelGGL((k_ps_runs<true>), dim3(gtiles), dim3(PS_THREADS), 0, st, a);
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(a.rstart + R32, &G32, 4, hipMemcpyHostToDevice, st));
+    // values, lists
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)PS_LIST_CAP * 12));
+    a.mixed = ctx->ps_h.as<uint32_t>();
+    a.slow = reinterpret_cast<uint2 *>(ctx->ps_h.as<uint32_t>() + PS_LIST_CAP);
+    PS_LAUNCH(k_ps_values, layout, dim3(fbg_blocks(G, 256)), dim3(256), st, a);
+    unsigned long long h[4];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    launches += 2;
+    // long repeats: all-pairs text comparison inside the mixed groups would take longer than the record path
+    const unsigned long long budget = std::max<unsigned long long>(2 * N, 1ull << 24);
+    if (h[3] != 0 || h[2] > budget) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+    if (h[0] > 0) {
+        PS_LAUNCH(k_ps_mixed, layout, dim3((unsigned)std::min<unsigned long long>(h[0], 256 * 32)), dim3(PS_THREADS), st, a, (uint32_t)h[0]);
+        launches++;
+    }
+    if (h[1] > 0) {
+        PS_LAUNCH(k_ps_slow, layout, dim3(fbg_blocks(h[1], 64)), dim3(64), st, a, (uint32_t)h[1]);
+        launches++;
+    }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    ctx->n_exc = 0;
+    ctx->ranked = true;
+    ctx->part_active = false;
+    rs_remember(ctx, keys, vals, geom);
+    *done = 1;
+    return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+}

@@ -37,112 +37,7 @@
 #include "text_cmp.h"
 #include <rocprim/rocprim.hpp>
 
-#define RS_TG 4    // tie groups up to this size are settled inside the scan
-
-// number of equal leading symbols of two different K-symbol keys (b bits per symbol)
-__device__ __forceinline__ uint32_t rs_key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
-{
-    const uint64_t d = a ^ c;
-    const uint32_t bits = (uint32_t)(__clzll((long long)d) - (64 - key_bits));
-    const uint32_t inv_b = (65536u + (uint32_t)b - 1) / (uint32_t)b;   // hoisted: b is uniform
-    return (bits * inv_b) >> 16;
-}
-
-struct RankArgs {
-    uint32_t magic32;          // floor(2^32 / row_len): umulhi(p, magic32) is p / row_len or one less
-    uint64_t magic64;          // floor(2^64 / row_len): umul64hi(p, magic64) is p / row_len or one less, for every 64-bit p
-    uint64_t *keys;            // sorted slots: keys, or packed words key << pb | position
-    uint32_t *vals;            // positions in SA order (pairs layout; final once the tie groups are ordered)
-    uint64_t pmask;            // packed / wide: (1 << pb) - 1, the position bits of the key word
-    int pb;
-    const uint8_t *T;
-    uint64_t N, n;             // N: number of SA slots in keys[] / vals[]
-    uint64_t Ntext;            // text length (position Ntext-1 is the sentinel)
-    uint64_t own_lo, own_hi;   // slots this launch owns; the rest are halo copies of the neighbouring partitions
-    int first_part, last_part; // partition holds the globally first / last suffix (no neighbour beyond)
-    int part_mode;             // >1 partitions: slots next to a partition edge are re-examined once the halos are in
-    int values_only;           // second pass for columns the threshold starved: no lists, no threshold
-    uint32_t row_len;          // n + 1
-    uint32_t g_min;            // extensions below this cannot be a column maximum (sampled; verified afterwards)
-    int b, key_bits, K, reversed;
-    uint32_t *gmax;            // per column: max over rows of g (0 = no row pointer seen)
-    uint32_t *cand;            // SA slots that need the run treatment (see header)
-    uint32_t *blk_count;       // k_rank_scan: candidates found by each workgroup (its private region of cand[])
-    uint32_t region;           // capacity of one workgroup's region
-    uint32_t *ties;            // heads of the small tie groups, same per-workgroup regions
-    uint32_t *tie_count;
-    uint32_t tie_region;
-    uint32_t *pm;              // scratch parallel to cand: prefix minima of the forward walk
-    uint32_t *big;             // tie groups too long for one thread: (head slot, size) pairs, counters[5] of them
-    unsigned long long *counters;   // [1] fallback flag
-};
-
-struct Slot {
-    uint64_t key;
-    uint64_t pos;
-    uint32_t col;              // MSA column of the position, n for '#' / sentinel (never a row pointer without gaps)
-    uint32_t rem;              // symbols left in the row from this position on (0 for '#' / sentinel)
-};
-
-// MSA column of a row pointer with `rem` symbols left; n for '#' / sentinel (never a row pointer without gaps)
-__device__ __forceinline__ uint32_t rs_col_of_rem(const RankArgs &a, uint32_t rem)
-{
-    return rem == 0 ? (uint32_t)a.n : (a.reversed ? rem - 1 : (uint32_t)a.n - rem);
-}
-// slot layouts (FBG_SLOTS_*): the key is always word >> pb (pb = 0 for plain pairs)
-template <int L> struct PosT { typedef uint32_t type; };
-template <> struct PosT<FBG_SLOTS_WIDE> { typedef uint64_t type; };
-template <int L> __device__ __forceinline__ uint64_t rs_key(const RankArgs &a, uint64_t k) { return a.keys[k] >> a.pb; }
-template <int L> __device__ __forceinline__ uint64_t rs_pos_of(const RankArgs &a, uint64_t w, uint32_t v)
-{
-    if (L == FBG_SLOTS_PACKED) return w & a.pmask;
-    if (L == FBG_SLOTS_WIDE) return ((w & a.pmask) << 32) | v;
-    return v;
-}
-template <int L> __device__ __forceinline__ uint64_t rs_pos(const RankArgs &a, uint64_t k)
-{
-    return rs_pos_of<L>(a, L == FBG_SLOTS_PAIRS ? 0ull : a.keys[k], L == FBG_SLOTS_PACKED ? 0u : a.vals[k]);
-}
-template <int L> __device__ __forceinline__ void rs_set_pos(const RankArgs &a, uint64_t k, uint64_t p)
-{
-    if (L == FBG_SLOTS_PACKED) a.keys[k] = (a.keys[k] & ~a.pmask) | p;
-    else if (L == FBG_SLOTS_WIDE) { a.keys[k] = (a.keys[k] & ~a.pmask) | (p >> 32); a.vals[k] = (uint32_t)p; }
-    else a.vals[k] = (uint32_t)p;
-}
-// symbols left in the row of text position p (0 for '#' / sentinel)
-template <int L> __device__ __forceinline__ uint32_t rs_rem(const RankArgs &a, uint64_t p)
-{
-    if (L == FBG_SLOTS_WIDE) {
-        // p / d - p * floor(2^64 / d) / 2^64 < p / 2^64 < 1: the quotient is at most one short, whatever p and d are
-        uint64_t c = p - __umul64hi(p, a.magic64) * a.row_len;
-        if (c >= a.row_len) c -= a.row_len;
-        return p == a.Ntext - 1 ? 0u : (uint32_t)(a.n - c);
-    }
-    const uint32_t p32 = (uint32_t)p;
-    uint32_t c = p32 - __umulhi(p32, a.magic32) * a.row_len;           // p mod (n+1), possibly one row_len too much
-    if (c >= a.row_len) c -= a.row_len;
-    return p32 == (uint32_t)(a.Ntext - 1) ? 0u : (uint32_t)a.n - c;
-}
-template <int L> __device__ __forceinline__ Slot rs_slot(const RankArgs &a, uint64_t k)
-{
-    Slot s;
-    const uint64_t w = a.keys[k];
-    s.key = w >> a.pb;
-    s.pos = rs_pos_of<L>(a, w, L == FBG_SLOTS_PACKED ? 0u : a.vals[k]);
-    s.rem = rs_rem<L>(a, s.pos);
-    s.col = rs_col_of_rem(a, s.rem);
-    return s;
-}
-template <int L> __device__ __forceinline__ uint32_t rs_col(const RankArgs &a, uint64_t k)
-{
-    return rs_col_of_rem(a, rs_rem<L>(a, rs_pos<L>(a, k)));
-}
-
-__device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint32_t g)
-{
-    // stale reads are only ever too small (values grow monotonically): never skips a needed update
-    if (a.gmax[col] < g) atomicMax(&a.gmax[col], g);
-}
+#include "rank_common.h"
 
 // one wave-aggregated append per list: a single update per wave of the workgroup's counter (LDS; it goes to
 // global memory once, when the workgroup is done)
@@ -822,34 +717,6 @@ static int rs_join(fbg_ctx *ctx)
     FBG_HIP_TRY(ctx, hipEventRecord(ctx->aux_join, ctx->aux));
     FBG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_join, 0));
     return FBG_OK;
-}
-
-static int rs_layout(const KeyGeom &g) { return g.packed ? FBG_SLOTS_PACKED : g.wide ? FBG_SLOTS_WIDE : FBG_SLOTS_PAIRS; }
-
-static void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint32_t *vals, uint64_t slots, int layout, int pb, int b,
-                         int key_bits, int K)
-{
-    a.keys = keys; a.vals = vals; a.T = ctx->text.as<uint8_t>();
-    a.pb = layout != FBG_SLOTS_PAIRS ? pb : 0; a.pmask = layout != FBG_SLOTS_PAIRS ? (1ull << pb) - 1 : 0;
-    a.N = slots; a.Ntext = ctx->N; a.n = ctx->n; a.row_len = (uint32_t)(ctx->n + 1);
-    a.own_lo = 0; a.own_hi = slots; a.first_part = a.last_part = 1; a.part_mode = 0; a.values_only = 0;
-    a.magic32 = (uint32_t)((1ull << 32) / (ctx->n + 1));
-    a.magic64 = ~0ull / (ctx->n + 1);     // floor((2^64 - 1) / d) = floor(2^64 / d) unless d divides 2^64, where it is one less:
-                                          // still within the one correction rs_rem applies (d = row_len >= 2)
-    a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
-    a.gmax = ctx->gmax.as<uint32_t>();
-    a.cand = nullptr; a.pm = nullptr; a.blk_count = nullptr; a.region = 0;
-    a.ties = nullptr; a.tie_count = nullptr; a.tie_region = 0;
-    a.big = ctx->big_groups.as<uint32_t>();
-    a.counters = ctx->scalars.as<unsigned long long>() + 32;
-    a.g_min = 0;
-}
-
-static void rs_remember(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g)
-{
-    ctx->rk_keys = keys; ctx->sa_ptr = vals;
-    ctx->rk_layout = rs_layout(g); ctx->rk_pb = g.pb;
-    ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
 }
 
 // k_rank_scan over the owned slots, the small tie groups, then the candidates: compacted, sorted, tie groups put

@@ -756,34 +756,36 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         FBG_TRY(fbg_key_setup(ctx, true, &g, &launches));
         bool similar = false;
         FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
-        if (!similar) {
-            // packed slots of a large text: three-pass MSD sort fused with the key packing (msd_sort.hip); else, or when
-            // its optimistic bucket capacities do not hold, pack and sort with rocPRIM's onesweep
-            uint64_t *sorted = nullptr;
-            int msd_ok = 0;
-            FBG_TRY(fbg_msd_sort(ctx, g, &sorted, &msd_ok, &launches));
-            if (!msd_ok) {
-                FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
-                FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
-                if (!g.packed) {
-                    FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
-                    FBG_TRY(fbg_reserve(ctx, ctx->valsB, N * 4));
-                }
-                PackArgs pa;
-                pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = g.b; pa.K = g.K; pa.pb = g.pb;
-                pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
-                pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
-                launch_pack(ctx, g, false, pa);
-                launches++;
-                FBG_TRY(sort_slots(ctx, g, N, 0));
-                sorted = ctx->keysB.as<uint64_t>();
+        // packed slots of a large text: three-pass MSD sort fused with the key packing (msd_sort.hip); else, or when
+        // its optimistic bucket capacities do not hold, pack and sort with rocPRIM's onesweep
+        uint64_t *sorted = nullptr;
+        int msd_ok = 0;
+        FBG_TRY(fbg_msd_sort(ctx, g, &sorted, &msd_ok, &launches));
+        if (!msd_ok) {
+            FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
+            FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
+            if (!g.packed) {
+                FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
+                FBG_TRY(fbg_reserve(ctx, ctx->valsB, N * 4));
             }
-            int done = 0;
-            FBG_TRY(fbg_rank_scan_try(ctx, sorted, g.packed ? nullptr : ctx->valsB.as<uint32_t>(), g, &done));
-            if (done) {
-                FBG_HIP_TRY(ctx, hipGetLastError());
-                return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
-            }
+            PackArgs pa;
+            pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = g.b; pa.K = g.K; pa.pb = g.pb;
+            pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
+            pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
+            launch_pack(ctx, g, false, pa);
+            launches++;
+            FBG_TRY(sort_slots(ctx, g, N, 0));
+            sorted = ctx->keysB.as<uint64_t>();
+        }
+        uint32_t *svals = g.packed ? nullptr : ctx->valsB.as<uint32_t>();
+        int done = 0;
+        // rows that differ: the scan slot by slot (rank_scan.hip).  Rows that resemble each other (judged from key twins in a
+        // sample, or by the slot-level scan itself, which gives up where a quarter of the slots tie): group by group
+        if (!similar && ctx->opt.pure_scan != 1) FBG_TRY(fbg_rank_scan_try(ctx, sorted, svals, g, &done));
+        if (!done && ctx->opt.pure_scan != -1) FBG_TRY(fbg_pure_scan_try(ctx, sorted, svals, g, &done));
+        if (done) {
+            FBG_HIP_TRY(ctx, hipGetLastError());
+            return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
         }
     }
 

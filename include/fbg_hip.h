@@ -75,6 +75,7 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   msd_min, bp_min    text lengths from which the MSD sort / the records-by-position passes are used (-1 = 2^24)
  *   record_scatter     records reach text order by a scatter instead of the by-position passes
  *   lcp_text           neighbour LCPs by text comparison even when the keys would do
+ *   pure_scan          1: gap-free MSAs always take the group-level scan for similar rows (pure_scan.hip), -1: never
  *   no_aux_stream      k_tie_simple on the main stream
  *   rank_no_threshold  no extension threshold in the rank-order scan
  *   dp_literal, dp_wave, dp_tile, dp_safe_window   which sweep kernel runs the min-max-length / non-elastic DP

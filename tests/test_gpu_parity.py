@@ -380,6 +380,9 @@ ALT_PATHS = [
     {"FBG_NO_RANKED": "1", "FBG_LCP_TEXT": "1"},     # ... with Kasai text comparison instead of key-derived LCPs
     {"FBG_FULL_KEYS": "1"},                          # 64-bit keys instead of entropy-sized ones
     {"FBG_RANK_NO_THRESHOLD": "1"},                  # rank-order scan without the sampled threshold
+    {"FBG_PURE_SCAN": "1"},                          # group-level scan for similar rows (pure_scan.hip) whatever the input
+    {"FBG_PURE_SCAN": "1", "FBG_NO_PACKED": "1"},    # ... on (key, position) pairs
+    {"FBG_PURE_SCAN": "1", "FBG_MSD_MIN": "1"},      # ... behind the three-pass MSD sort
     {"FBG_NO_PACKED": "1"},                          # rank-order scan on (key, position) pairs instead of packed words
     {"FBG_NO_PACKED": "1", "FBG_FULL_KEYS": "1"},
     {"FBG_FORCE_WIDE": "1"},                         # ... on wide pairs (the layout for texts beyond 2^32 symbols)
@@ -546,8 +549,9 @@ def test_partitioned_index_full_size():
             e.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}, {"FBG_MSD_MIN": "1"}],
-                         ids=["packed", "pairs", "wide", "nothreshold", "msdsort"])
+@pytest.mark.parametrize("env", [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"}, {"FBG_MSD_MIN": "1"},
+                                 {"FBG_PURE_SCAN": "1"}],
+                         ids=["packed", "pairs", "wide", "nothreshold", "msdsort", "purescan"])
 def test_rank_scan_sampled_regime_matches_oracle(engine, env):
     """Texts above 2^22 symbols use the sampled threshold and regime test of the rank-order scan: f and v must
     still be the oracle's, for iid rows and for rows with shared stretches (ties, runs, short suffixes)."""
@@ -561,10 +565,17 @@ def test_rank_scan_sampled_regime_matches_oracle(engine, env):
             assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa))
 
 
+@pytest.mark.parametrize("pure", [0, 1], ids=["slots", "groups"])
 @pytest.mark.parametrize("alphabet", ["A", "AC", "ACGT", "ACGTN"])
-def test_rank_scan_short_rows_and_heavy_ties(engine, alphabet):
+def test_rank_scan_short_rows_and_heavy_ties(engine, alphabet, pure):
     """Rows shorter than a key, tiny alphabets, repeated rows: every suffix is 'short' or tied.  Index arrays and
-    f / v against the oracle (exercises the separator coding, tie ordering from the suffix start, runs)."""
+    f / v against the oracle (exercises the separator coding, tie ordering from the suffix start, runs) -- with the
+    slot-level scan and with the group-level one (pure_scan.hip: mixed groups, short members, the key-0 group)."""
+    with fbg_options(engine, {"FBG_PURE_SCAN": str(pure)}):
+        _short_rows_and_heavy_ties(engine, alphabet)
+
+
+def _short_rows_and_heavy_ties(engine, alphabet):
     rng = np.random.default_rng(len(alphabet))
     for (m, n, kw) in [(3, 1, {}), (4, 2, {}), (6, 5, {}), (9, 13, {}), (12, 40, {}), (5, 200, dict(similar=0.9)),
                        (40, 30, dict(similar=0.7)), (70, 64, {}), (8, 700, dict(similar=0.98))]:
@@ -582,6 +593,26 @@ def test_rank_scan_short_rows_and_heavy_ties(engine, alphabet):
         if exp[0] != n:                                  # otherwise the engine reports "no valid segmentation"
             assert np.array_equal(engine.elastic_f(msa, disable_efg_tricks=True), exp)
         assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa)), (alphabet, m, n)
+
+
+@pytest.mark.parametrize("shape", [(200, 20000, 0.01), (1000, 4000, 0.002), (60, 60000, 0.05)], ids=["star200", "star1000", "star60"])
+def test_similar_rows_group_scan_matches_oracle(engine, shape):
+    """Star phylogeny (one iid ancestor, every cell substituted with probability p): the sample sends these to the
+    group-level scan (pure_scan.hip) by itself; f and the sweep against the oracle.  A repeat is planted in the ancestor
+    so that mixed groups (members from two columns) of hundreds of suffixes exist too."""
+    m, n, p = shape
+    rng = np.random.default_rng(m)
+    anc = rng.integers(0, 4, n)
+    anc[n // 2:n // 2 + 300] = anc[n // 5:n // 5 + 300]           # a 300-symbol repeat
+    cells = np.where(rng.random((m, n)) < p, rng.integers(0, 4, (m, n)), anc)
+    msa = np.frombuffer(b"ACGT", dtype=np.uint8)[cells]
+    f = O.compute_f(msa, threads=8)
+    g = engine.elastic_f(msa)
+    assert np.array_equal(g, f), np.flatnonzero(g != f)[:10]
+    mml, bt, b = O.minmax_dp(f)
+    gb, gmml, gbt = engine.minmax_dp(g, full=True)
+    assert np.array_equal(gb, b) and np.array_equal(gmml, mml) and np.array_equal(gbt, bt)
+    assert np.array_equal(engine.repeatfree_v(msa), O.segment_v(msa))
 
 
 def test_partitioned_index_wide_layout():
