@@ -66,10 +66,19 @@ def cpu_model():
 
 
 def host_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota if there is one."""
     try:
-        return len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
 
 
 def cpu_baseline(m, n_total, sample_cols):

@@ -210,6 +210,7 @@ int fbg_block_graph(fbg_ctx *ctx, const uint64_t *boundaries, uint64_t nb, uint3
         return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_block_graph: bad arguments");
     const uint64_t m = ctx->m, n = ctx->n;
     if (m * nb >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_block_graph: more than 2^32 (row, block) cells");
+    if (m > FBG_MAX_ROWS) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_block_graph: more than %d rows (the labels of a block are grouped in LDS)", FBG_MAX_ROWS);
     for (uint64_t j = 0; j < nb; j++)
         if (boundaries[j] > n || (j && boundaries[j] <= boundaries[j - 1]))
             return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_block_graph: boundaries must increase and end at most at n");

@@ -237,7 +237,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->prow, &ctx->igrow, &ctx->rec,
+    DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->segtab, &ctx->exc_scratch, &ctx->prow, &ctx->igrow, &ctx->rec,
                       &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->xbits, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
                       &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->msd_w, &ctx->msd_v, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
@@ -321,8 +321,6 @@ static int check_dims(fbg_ctx *ctx, uint64_t m, uint64_t n)
     if (!ctx) return FBG_ERR_INVALID;
     if (m == 0 || n == 0) return fbg_fail(ctx, FBG_ERR_INVALID, "empty MSA (m=%llu, n=%llu)",
                                           (unsigned long long)m, (unsigned long long)n);
-    if (m > FBG_MAX_ROWS)
-        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "m=%llu exceeds FBG_MAX_ROWS=%d", (unsigned long long)m, FBG_MAX_ROWS);
     // whether a text beyond 32-bit positions can be indexed depends on the path taken: fbg_build_text decides
     if (n >= (1ull << 31) || m * (n + 1) + 1 >= (1ull << 40))
         return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "MSA of %llu x %llu cells is beyond this engine (n < 2^31, text < 2^40)",

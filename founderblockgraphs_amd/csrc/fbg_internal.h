@@ -69,6 +69,7 @@ struct fbg_ctx {
     uint32_t mp = 0;           // rows padded to a multiple of 64 (column-tile pitch)
     DevBuf text;               // N + 64 bytes, zero padded
     DevBuf pos, tot;           // u32[m]
+    DevBuf segtab;             // u32[3][m][segments]: per 65536-column segment of a row: non-gap cells, prefix, first ignore column
     DevBuf prow;               // u32[m*n]: text pointer of cell (i,x), row-major (gapped MSAs only)
     DevBuf igrow;              // u32[m*n]: first ignore-char column >= x, row-major (ignore chars only)
     DevBuf rec;                // uint4[N] by text position: {rank, lcp-prev | hint<<31, lcp-next | hint<<31, 0}
@@ -80,6 +81,7 @@ struct fbg_ctx {
     bool ranked = false;
     DevBuf gmax, excol, xslot; // u32[n+1]: column maxima of g, exception flags, exception slots
     DevBuf xbits;              // bitmap of the exception columns
+    DevBuf exc_scratch;        // per-workgroup column state of k_scan_exceptions_big (MSAs of more than 4096 rows)
     DevBuf exc;                // uint4[n_exc * m]: (rank, lcp_prev, lcp_next) of the rows of the exception columns
     uint32_t n_exc = 0;
     uint64_t *rk_keys = nullptr; // sorted slots: keys (pairs layout, positions in sa_ptr) or key << rk_pb | position (packed)

@@ -185,7 +185,30 @@ template <int L> __global__ void k_ps_values(PsArgs a)
     rs_update(a.r, col, 1u);
 }
 
-// one workgroup per mixed group: every member against every member of another column
+// Nearest group beyond g (dir = -1: to the left, +1: to the right) that holds a suffix of another column than the
+// one with `rem` symbols left: pure groups of that column are coloured along with it and skipped.  Returns the clamped
+// number of symbols a suffix of group g with `rem` symbols left shares with the best member of that group; 0 if none.
+template <int L> __device__ uint32_t ps_outside_match(const PsArgs &a, uint64_t g, uint64_t key, uint32_t rem, int dir)
+{
+    for (uint64_t h = g;;) {
+        if (dir < 0) { if (h == 0) return 0; h--; } else { h++; if (h >= a.G) return 0; }
+        const uint32_t flh = a.gflags[h];
+        if (!(flh & PS_MIXED) && a.grem[h] == rem) continue;
+        uint32_t reach = a.grem[h];                            // most symbols left among its members of other columns
+        if (flh & PS_MIXED) {
+            reach = 0;
+            for (uint64_t k = a.gstart[h]; k < a.gstart[h + 1]; k++) {
+                const uint32_t rq = rs_rem<L>(a.r, rs_pos<L>(a.r, k));
+                if (rq != rem) reach = max(reach, rq);
+            }
+        }
+        return min(min(rs_key_lcp(key, rs_key<L>(a.r, a.gstart[h]), a.r.b, a.r.key_bits), rem), reach);
+    }
+}
+
+// one workgroup per mixed group: every member against every member of another column.  A group with a short member
+// (fewer than K symbols left in its row: the keys agree only up to the separator coding) looks beyond the group too:
+// its members' real matches inside may be shorter than what the neighbouring groups offer.
 template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs a, uint32_t count)
 {
     __shared__ uint32_t spos[PS_MAX_GROUP], srem[PS_MAX_GROUP];
@@ -193,7 +216,9 @@ template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs
         const uint32_t g = a.mixed[e];
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
         if (s > PS_MAX_GROUP) continue;                        // flagged by k_ps_values
-        const uint32_t from = (a.gflags[g] & PS_SHORT) ? 0u : (uint32_t)a.r.K;
+        const bool has_short = (a.gflags[g] & PS_SHORT) != 0;
+        const uint32_t from = has_short ? 0u : (uint32_t)a.r.K;
+        const uint64_t key = rs_key<L>(a.r, s0);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < s; i += PS_THREADS) {
             const uint64_t p = rs_pos<L>(a.r, (uint64_t)s0 + i);
@@ -210,6 +235,7 @@ template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs
                 if (srem[q] == rem) continue;                  // same column: coloured together
                 best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
             }
+            if (has_short) best = max(best, max(ps_outside_match<L>(a, g, key, rem, -1), ps_outside_match<L>(a, g, key, rem, +1)));
             rs_update(a.r, rs_col_of_rem(a.r, rem), fbg_clamp_lcp(best) + 1);
         }
     }

@@ -25,7 +25,7 @@
 
 #define ST_THREADS 256
 #define SC_THREADS 256
-#define SC_MAX_RPT 16            // rows per thread: m <= SC_THREADS * SC_MAX_RPT = 4096
+#define SC_MAX_RPT 16            // rows per thread of the LDS kernel: m <= SC_THREADS * SC_MAX_RPT = 4096 (more: k_scan_exceptions_big)
 #define SC_EMPTY 0xffffffffu
 #define SC_NONE 0xffffu
 
@@ -237,16 +237,129 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_exceptions(ScanArgs a, uint
     }
 }
 
+// The same for MSAs of more than SC_THREADS * SC_MAX_RPT rows: a column no longer fits one workgroup's LDS, so the hash
+// set, the running minima and the jump pointers live in a scratch region of global memory per workgroup (L2-resident:
+// a few hundred KB), row indices are 32 bits wide, and pointer jumping ping-pongs between two copies instead of
+// keeping a row's new state in registers.  Exception columns are rare (hinted columns only): latency, not bandwidth.
+#define SCB_NONE 0xffffffffu
+__global__ __launch_bounds__(SC_THREADS) void k_scan_exceptions_big(ScanArgs a, uint64_t ncols, uint32_t *__restrict__ scratch,
+                                                                    uint64_t scratch_words)
+{
+    __shared__ unsigned long long red[SC_THREADS / 64];
+    const uint32_t tid = threadIdx.x, Hm = a.H - 1;
+    const uint64_t m = a.m;
+    uint32_t *base = scratch + (uint64_t)blockIdx.x * scratch_words;
+    uint32_t *hkey = base;                                 // H
+    uint32_t *hrow = hkey + a.H;                           // H
+    uint32_t *rk = hrow + a.H;                             // m
+    uint32_t *pp = rk + m;                                 // m
+    uint32_t *vL[2] = {pp + m, pp + 2 * m}, *vR[2] = {pp + 3 * m, pp + 4 * m};
+    uint32_t *pL[2] = {pp + 5 * m, pp + 6 * m}, *pR[2] = {pp + 7 * m, pp + 8 * m};
+    for (uint64_t c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const uint64_t x = a.xlist[c];
+        if (x < a.x0 || x >= a.x1) continue;
+        __syncthreads();
+        for (uint32_t s = tid; s < a.H; s += SC_THREADS) hkey[s] = SC_EMPTY;
+        __syncthreads();
+        for (uint64_t i = tid; i < m; i += SC_THREADS) {
+            const uint32_t p = cell_ptr(a, i, x);
+            const uint4 r4 = a.exc ? a.exc[c * a.m + i] : a.rec[p];
+            uint32_t r = r4.x;
+            vL[0][i] = r4.y & FBG_LCP_MASK;
+            vR[0][i] = r4.z & FBG_LCP_MASK;
+            pp[i] = p;
+            if (row_active(a, i, x, p)) {
+                uint32_t s = sc_hash(r, a.logH);
+                for (;;) {
+                    const uint32_t prev = atomicCAS(&hkey[s], SC_EMPTY, r);
+                    if (prev == SC_EMPTY) { hrow[s] = (uint32_t)i; break; }
+                    s = (s + 1) & Hm;
+                }
+            } else {
+                r = SC_EMPTY;
+            }
+            rk[i] = r;
+        }
+        __syncthreads();
+        int anylink = 0;
+        for (uint64_t i = tid; i < m; i += SC_THREADS) {
+            const uint32_t r = rk[i];
+            uint32_t l = SCB_NONE, rr = SCB_NONE;
+            if (r != SC_EMPTY) {
+                if (r > 0) {
+                    const uint32_t key = r - 1;
+                    for (uint32_t s = sc_hash(key, a.logH);; s = (s + 1) & Hm) {
+                        const uint32_t k = hkey[s];
+                        if (k == key) { l = hrow[s]; break; }
+                        if (k == SC_EMPTY) break;
+                    }
+                }
+                if ((uint64_t)r + 1 < a.N) {
+                    const uint32_t key = r + 1;
+                    for (uint32_t s = sc_hash(key, a.logH);; s = (s + 1) & Hm) {
+                        const uint32_t k = hkey[s];
+                        if (k == key) { rr = hrow[s]; break; }
+                        if (k == SC_EMPTY) break;
+                    }
+                }
+            }
+            pL[0][i] = l; pR[0][i] = rr;
+            anylink |= l != SCB_NONE;
+        }
+        anylink = __syncthreads_or(anylink);
+        int cur = 0;
+        while (anylink) {
+            int more = 0;
+            for (uint64_t i = tid; i < m; i += SC_THREADS) {
+                const uint32_t pa = pL[cur][i], pb = pR[cur][i];
+                uint32_t nl = vL[cur][i], nr = vR[cur][i], na = pa, nb = pb;
+                if (pa != SCB_NONE) { nl = min(nl, vL[cur][pa]); na = pL[cur][pa]; more |= na != SCB_NONE; }
+                if (pb != SCB_NONE) { nr = min(nr, vR[cur][pb]); nb = pR[cur][pb]; more |= nb != SCB_NONE; }
+                vL[cur ^ 1][i] = nl; vR[cur ^ 1][i] = nr; pL[cur ^ 1][i] = na; pR[cur ^ 1][i] = nb;
+            }
+            cur ^= 1;
+            anylink = __syncthreads_or(more);
+        }
+        unsigned long long best = 0;
+        for (uint64_t i = tid; i < m; i += SC_THREADS) {
+            if (rk[i] == SC_EMPTY) continue;
+            const unsigned long long g = (unsigned long long)max(vL[cur][i], vR[cur][i]) + 1;
+            best = max(best, a.mode == FBG_SCAN_V ? g : row_extent(a, i, x, pp[i], g));
+        }
+        for (int d = 32; d >= 1; d >>= 1) best = max(best, (unsigned long long)__shfl_down(best, d, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < SC_THREADS / 64; k++) best = max(best, red[k]);
+            write_column(a, x, best);
+        }
+    }
+}
+
+// k_scan_exceptions over `ncols` listed columns: in LDS while a column fits, else through global scratch
+static int launch_exceptions(fbg_ctx *ctx, ScanArgs &a, uint64_t ncols)
+{
+    hipStream_t st = ctx->stream;
+    const size_t lds = (size_t)a.H * 6 + (size_t)a.m * 20;
+    if (a.m <= (uint64_t)SC_THREADS * SC_MAX_RPT && lds <= 150 * 1024) {
+        if (lds > 64 * 1024)
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_scan_exceptions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_scan_exceptions, dim3(fbg_blocks(ncols, 1, 256 * 8)), dim3(SC_THREADS), lds, st, a, ncols);
+        return FBG_OK;
+    }
+    const unsigned blocks = fbg_blocks(ncols, 1, 512);
+    const uint64_t words = 2ull * a.H + 10ull * a.m;
+    FBG_TRY(fbg_reserve(ctx, ctx->exc_scratch, (size_t)blocks * words * 4));
+    hipLaunchKernelGGL(k_scan_exceptions_big, dim3(blocks), dim3(SC_THREADS), 0, st, a, ncols, ctx->exc_scratch.as<uint32_t>(), words);
+    return FBG_OK;
+}
+
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out)
 {
-    if (ctx->m > (uint64_t)SC_THREADS * SC_MAX_RPT)
-        return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel supports m <= %d rows (got %llu)", SC_THREADS * SC_MAX_RPT,
-                        (unsigned long long)ctx->m);
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SCAN));
     int launches = 0;
     if (x1 > x0 && ctx->ranked) {
         // rank-order index: column maxima are ready, only the exception columns need the per-column kernel
-        hipStream_t st = ctx->stream;
         FBG_TRY(fbg_rank_finish(ctx, x0, x1, mode, disable_tricks, d_out));
         launches++;
         if (ctx->n_exc > 0) {
@@ -261,12 +374,7 @@ int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disab
             uint32_t logH = 7;
             while ((1u << logH) < 2 * ctx->m) logH++;
             a.H = 1u << logH; a.logH = logH;
-            const size_t lds = (size_t)a.H * 6 + (size_t)a.m * 20;
-            if (lds > 150 * 1024) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel LDS budget exceeded (%zu bytes)", lds);
-            if (lds > 64 * 1024)
-                FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_scan_exceptions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_scan_exceptions, dim3(fbg_blocks(ctx->n_exc, 1, 256 * 8)), dim3(SC_THREADS), lds, st, a,
-                               (uint64_t)ctx->n_exc);
+            FBG_TRY(launch_exceptions(ctx, a, (uint64_t)ctx->n_exc));
             launches++;
         }
         FBG_HIP_TRY(ctx, hipGetLastError());
@@ -294,11 +402,7 @@ int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disab
         FBG_HIP_TRY(ctx, hipMemcpyAsync(&nx, xcount, sizeof(nx), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         if (nx > 0) {
-            const size_t lds = (size_t)a.H * 6 + (size_t)a.m * 20;
-            if (lds > 150 * 1024) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "scan kernel LDS budget exceeded (%zu bytes)", lds);
-            if (lds > 64 * 1024)
-                FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_scan_exceptions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_scan_exceptions, dim3(fbg_blocks(nx, 1, 256 * 8)), dim3(SC_THREADS), lds, st, a, (uint64_t)nx);
+            FBG_TRY(launch_exceptions(ctx, a, (uint64_t)nx));
             launches++;
         }
         FBG_HIP_TRY(ctx, hipGetLastError());

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
                                                           const uint8_t *__restrict__ is_ignore,
                                                           uint32_t *__restrict__ tot,
                                                           unsigned long long *__restrict__ scalars,
-                                                          unsigned long long *__restrict__ hist)
+                                                          unsigned long long *__restrict__ hist,
+                                                          uint32_t *__restrict__ segcnt)
 {
     __shared__ uint32_t red[2][TB_THREADS / 64];
     __shared__ uint32_t sh[256];
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
         uint32_t a = 0, b = 0;
         for (int k = 0; k < TB_THREADS / 64; k++) { a += red[0][k]; b += red[1][k]; }
         atomicAdd(&tot[i], a);
+        segcnt[i * gridDim.x + blockIdx.x] = a;                         // non-gap cells of this segment: k_seg_offsets
         atomicAdd(&scalars[0], (unsigned long long)((x_hi > x_lo ? x_hi - x_lo : 0) - a));
         if (b) atomicAdd(&scalars[1], (unsigned long long)b);
     }
@@ -205,25 +207,37 @@ __global__ void k_row_offsets(const uint32_t *__restrict__ tot, uint64_t m, uint
     if (threadIdx.x == 63) scalars[2] = inc + 1;
 }
 
+// segoff[i][s] = non-gap cells of row i before segment s (rows with gaps are written segment by segment)
+__global__ void k_seg_offsets(const uint32_t *__restrict__ segcnt, uint64_t m, uint32_t nseg, uint32_t *__restrict__ segoff)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < nseg; q++) { segoff[i * nseg + q] = run; run += segcnt[i * nseg + q]; }
+}
+
 template <bool GAPPED, bool REVERSED>
 __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__restrict__ msa, uint64_t n,
                                                            const uint32_t *__restrict__ pos,
                                                            const uint32_t *__restrict__ tot,
                                                            uint8_t *__restrict__ T, uint32_t *__restrict__ prow,
-                                                           uint32_t *__restrict__ colT)
+                                                           uint32_t *__restrict__ colT, const uint32_t *__restrict__ segoff)
 {
+    // blockIdx.y = row; blockIdx.x = segment of RC_SEG columns (gapped rows: the segment's first text position comes
+    // from segoff) or the whole row (gridDim.x = 1, segoff = nullptr)
     __shared__ uint32_t lds4[TB_THREADS / 64];
-    const uint64_t i = blockIdx.x;
+    const uint64_t i = blockIdx.y;
     const uint8_t *row = msa + i * n;
     const uint32_t p0 = pos[i];
-    uint32_t carry = 0;
-    for (uint64_t base = 0; base < n; base += TB_CHUNK) {
+    const uint64_t x_lo = segoff ? (uint64_t)blockIdx.x * RC_SEG : 0, x_hi = segoff ? min(n, x_lo + RC_SEG) : n;
+    uint32_t carry = segoff ? segoff[i * gridDim.x + blockIdx.x] : 0u;
+    for (uint64_t base = x_lo; base < x_hi; base += TB_CHUNK) {
         const uint64_t x0 = base + (uint64_t)threadIdx.x * TB_ITEMS;
         uint8_t c[TB_ITEMS];
         uint32_t cnt = 0;
 #pragma unroll
         for (int k = 0; k < TB_ITEMS; k++) {
-            c[k] = x0 + k < n ? row[x0 + k] : (uint8_t)'-';
+            c[k] = x0 + k < x_hi ? row[x0 + k] : (uint8_t)'-';
             cnt += c[k] != '-';
         }
         if (GAPPED) {
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__rest
             uint32_t off = carry + block_excl_scan(cnt, &total, lds4);
 #pragma unroll
             for (int k = 0; k < TB_ITEMS; k++) {
-                if (x0 + k < n) {
+                if (x0 + k < x_hi) {
                     prow[i * n + x0 + k] = p0 + off;      // pos_i + rank_i(x)
                     if (c[k] != '-') { T[p0 + off] = c[k]; colT[p0 + off] = (uint32_t)(x0 + k); off++; }
                 }
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__rest
                 if (x0 + k < n) T[p0 + (REVERSED ? (n - 1 - (x0 + k)) : (x0 + k))] = c[k];
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && x_hi == n) {
         T[p0 + tot[i]] = '#';
         if (GAPPED) colT[p0 + tot[i]] = (uint32_t)n;
     }
@@ -285,23 +299,50 @@ __global__ __launch_bounds__(TB_THREADS) void k_copy_rows(const uint8_t *__restr
     }
 }
 
-// igrow[i*n + x] = smallest column c >= x with is_ignore[msa[i][c]], or n (fbg.cpp:1669-1670)
+// first ignore column of every segment of RC_SEG columns (n: none): the carries of k_ignore_sweep
+__global__ __launch_bounds__(TB_THREADS) void k_ignore_segmin(const uint8_t *__restrict__ msa, uint64_t n,
+                                                              const uint8_t *__restrict__ is_ignore, uint32_t *__restrict__ segmin)
+{
+    __shared__ uint32_t wmin[TB_THREADS / 64];
+    const uint64_t i = blockIdx.y;
+    const uint8_t *row = msa + i * n;
+    const uint64_t x_lo = (uint64_t)blockIdx.x * RC_SEG, x_hi = min(n, x_lo + RC_SEG);
+    uint32_t first = (uint32_t)n;
+    for (uint64_t x = x_lo + threadIdx.x; x < x_hi; x += TB_THREADS)
+        if (is_ignore[row[x]]) { first = (uint32_t)x; break; }          // ascending per thread: its first hit is its smallest
+    for (int d = 32; d >= 1; d >>= 1) first = min(first, (uint32_t)__shfl_down(first, d, 64));
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = first;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < TB_THREADS / 64; k++) first = min(first, wmin[k]);
+        segmin[i * gridDim.x + blockIdx.x] = first;
+    }
+}
+
+// igrow[i*n + x] = smallest column c >= x with is_ignore[msa[i][c]], or n (fbg.cpp:1669-1670).  blockIdx.y = row,
+// blockIdx.x = segment of RC_SEG columns, swept right to left; what lies to the right of the segment comes from segmin
 __global__ __launch_bounds__(TB_THREADS) void k_ignore_sweep(const uint8_t *__restrict__ msa, uint64_t n,
                                                              const uint8_t *__restrict__ is_ignore,
+                                                             const uint32_t *__restrict__ segmin,
                                                              uint32_t *__restrict__ igrow)
 {
     __shared__ uint32_t wmin[TB_THREADS / 64];
-    const uint64_t i = blockIdx.x;
+    const uint64_t i = blockIdx.y;
     const uint8_t *row = msa + i * n;
+    const uint64_t x_lo = (uint64_t)blockIdx.x * RC_SEG, x_hi = min(n, x_lo + RC_SEG);
     uint32_t carry = (uint32_t)n;  // first ignore column to the right of the current chunk
-    const uint64_t nchunks = (n + TB_CHUNK - 1) / TB_CHUNK;
+    for (uint32_t q = blockIdx.x + 1; q < gridDim.x; q++) {
+        const uint32_t v = segmin[i * gridDim.x + q];
+        if (v < (uint32_t)n) { carry = v; break; }
+    }
+    const uint64_t nchunks = (x_hi - x_lo + TB_CHUNK - 1) / TB_CHUNK;
     for (uint64_t ch = nchunks; ch-- > 0;) {
-        const uint64_t x0 = ch * TB_CHUNK + (uint64_t)threadIdx.x * TB_ITEMS;
+        const uint64_t x0 = x_lo + ch * TB_CHUNK + (uint64_t)threadIdx.x * TB_ITEMS;
         uint32_t loc[TB_ITEMS];
         uint32_t first = 0xffffffffu;  // first ignore column among this thread's items
 #pragma unroll
         for (int k = TB_ITEMS - 1; k >= 0; k--) {
-            if (x0 + k < n && is_ignore[row[x0 + k]]) first = (uint32_t)(x0 + k);
+            if (x0 + k < x_hi && is_ignore[row[x0 + k]]) first = (uint32_t)(x0 + k);
             loc[k] = first;
         }
         // suffix-min across threads: value for thread t = min(first of threads > t)
@@ -324,7 +365,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_ignore_sweep(const uint8_t *__re
         uint32_t right = min(ex, after);
 #pragma unroll
         for (int k = 0; k < TB_ITEMS; k++)
-            if (x0 + k < n) igrow[i * n + x0 + k] = min(loc[k], right);
+            if (x0 + k < x_hi) igrow[i * n + x0 + k] = min(loc[k], right);
         __syncthreads();
         carry = chunk_min;
     }
@@ -356,8 +397,11 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ctx->small.as<uint8_t>() + 4096);
     FBG_HIP_TRY(ctx, hipMemsetAsync(d_hist, 0, 2048, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->tot.p, 0, m * 4, st));
-    hipLaunchKernelGGL(k_row_count, dim3((unsigned)((n + RC_SEG - 1) / RC_SEG), (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
-                       n, d_is_ignore, ctx->tot.as<uint32_t>(), sc, d_hist);
+    const unsigned nseg = (unsigned)((n + RC_SEG - 1) / RC_SEG);
+    FBG_TRY(fbg_reserve(ctx, ctx->segtab, (size_t)m * nseg * 4 * 3));   // per (row, segment): non-gap cells, their prefix, first ignore column
+    uint32_t *segcnt = ctx->segtab.as<uint32_t>(), *segoff = segcnt + (size_t)m * nseg, *segmin = segoff + (size_t)m * nseg;
+    hipLaunchKernelGGL(k_row_count, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
+                       n, d_is_ignore, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt);
     hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(64), 0, st, ctx->tot.as<uint32_t>(), m,
                        ctx->pos.as<uint32_t>(), sc);
     launches += 2;
@@ -389,11 +433,13 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     if (!ctx->gapfree) {
         FBG_TRY(fbg_reserve(ctx, ctx->prow, m * n * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->colT, ctx->N * 4));
-        hipLaunchKernelGGL((k_write_text<true, false>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
-                           pos, tot, T, ctx->prow.as<uint32_t>(), ctx->colT.as<uint32_t>());
+        hipLaunchKernelGGL(k_seg_offsets, dim3(fbg_blocks(m, 64)), dim3(64), 0, st, segcnt, m, nseg, segoff);
+        hipLaunchKernelGGL((k_write_text<true, false>), dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
+                           pos, tot, T, ctx->prow.as<uint32_t>(), ctx->colT.as<uint32_t>(), (const uint32_t *)segoff);
+        launches++;
     } else if (ctx->reversed) {
-        hipLaunchKernelGGL((k_write_text<false, true>), dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
-                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        hipLaunchKernelGGL((k_write_text<false, true>), dim3(1, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
+                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);
     } else {
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + CR_SEG - 1) / CR_SEG), (unsigned)m), dim3(TB_THREADS), 0, st,
                            ctx->d_msa, n, m, T);
@@ -406,9 +452,10 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     }
     if (ctx->have_ignore) {
         FBG_TRY(fbg_reserve(ctx, ctx->igrow, m * n * 4));
-        hipLaunchKernelGGL(k_ignore_sweep, dim3((unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,
-                           ctx->igrow.as<uint32_t>());
-        launches++;
+        hipLaunchKernelGGL(k_ignore_segmin, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore, segmin);
+        hipLaunchKernelGGL(k_ignore_sweep, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,
+                           (const uint32_t *)segmin, ctx->igrow.as<uint32_t>());
+        launches += 2;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
     return fbg_stage_end(ctx, FBG_STAGE_TEXT, launches);

@@ -16,8 +16,8 @@
  * (fbg.cpp:47).
  *
  * Limits of this build: one context indexes texts of N = (#non-gap cells) + m + 1 < 2^32 symbols (32-bit suffix
- * ranks); longer texts (below 2^40) go through a group (fbg_group_*, partitioned index).  m <= FBG_MAX_ROWS on the
- * record path.  Violations return FBG_ERR_TOO_LARGE.
+ * ranks); longer texts (below 2^40) go through a group (fbg_group_*, partitioned index); n < 2^31.  Violations return
+ * FBG_ERR_TOO_LARGE.
  * There is no CPU fallback: without a HIP device every compute call fails with
  * FBG_ERR_NO_DEVICE / FBG_ERR_HIP.
  */
@@ -44,7 +44,8 @@ enum {
     FBG_ERR_HASH_COLLISION = 7   /* fbg_block_graph only: use the caller's own label numbering instead */
 };
 
-#define FBG_MAX_ROWS 4096   /* scan kernel: one workgroup holds a whole column in LDS */
+#define FBG_MAX_ROWS 4096   /* fbg_block_graph only: one workgroup groups the labels of a block in LDS (more rows:
+                               FBG_ERR_TOO_LARGE, number the labels on the host).  The segmentation itself has no row limit. */
 
 /* stage ids for fbg_stage_ms() */
 enum {
