@@ -207,10 +207,12 @@ __global__ void k_msd_widen(const uint32_t *__restrict__ count2, unsigned long l
 
 // `have` slots (the first n_a from in_a, the rest from in_b) -> out, sorted: bins on key bits inside LDS, then every slot
 // counts the smaller slots of its bin (the words are distinct)
+#define MSD_BIG_BIN 192                        // a bin with more slots is split on its low key bits instead of counted through
+#define MSD_LOW_BITS 10                        // ... when at most this many key bits lie below the bin bits
 template <int CAP, int THREADS>
 __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, const uint64_t *in_a,
                                                 uint32_t n_a, const uint64_t *in_b, uint32_t have, uint64_t *out, int fshift,
-                                                uint32_t fmask)
+                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds)
 {
     constexpr int ITEMS = CAP / THREADS;
     for (int i = threadIdx.x; i < MSD_FN_BINS; i += THREADS) cnt[i] = 0;
@@ -254,12 +256,65 @@ __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, ui
         if (j < have) buf[loff[(uint32_t)(w[r] >> fshift) & fmask] + rk[r]] = w[r];
     }
     __syncthreads();
+    // A bin of a few slots: every slot counts the smaller slots of its bin.  Similar rows put hundreds of EQUAL keys
+    // into one bin (all rows of a column), where that count is quadratic: such a bin is split once more, on the key bits
+    // below the bin bits (lowbits of them), by a histogram in LDS; equal keys keep the order in which they arrive --
+    // nothing downstream depends on the order of equal keys.
+    uint32_t nbig = 0;
+    if (lowbits >= 1 && lowbits <= MSD_LOW_BITS) {
+        if (threadIdx.x == 0) *nbig_lds = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < MSD_FN_BINS; i += THREADS)
+            if (cnt[i] > MSD_BIG_BIN) { const uint32_t e = atomicAdd(nbig_lds, 1u); biglist[e] = (uint16_t)i; }   // at most CAP / MSD_BIG_BIN of them
+        __syncthreads();
+        nbig = *nbig_lds;
+    }
+    const uint32_t lowmask = (1u << (lowbits > 0 ? lowbits : 1)) - 1;
+    for (uint32_t e = 0; e < nbig; e++) {                        // uniform over the workgroup
+        const uint32_t bbin = biglist[e], b0 = loff[bbin];
+        for (uint32_t i = threadIdx.x; i <= lowmask; i += THREADS) sub[i] = 0;
+        __syncthreads();
+        uint32_t idx[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * THREADS;
+            idx[r] = 0;
+            if (j < have && ((uint32_t)(w[r] >> fshift) & fmask) == bbin) idx[r] = atomicAdd(&sub[(uint32_t)(w[r] >> (fshift - lowbits)) & lowmask], 1u);
+        }
+        __syncthreads();
+        {   // exclusive scan of the (at most 2^MSD_LOW_BITS) counts: consecutive entries per thread
+            constexpr int PER = (1 << MSD_LOW_BITS) / THREADS > 0 ? (1 << MSD_LOW_BITS) / THREADS : 1;
+            const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            uint32_t c[PER], tot = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const uint32_t i = threadIdx.x * PER + q; c[q] = i <= lowmask ? sub[i] : 0u; tot += c[q]; }
+            uint32_t inc = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+            if (lane == 63) wsum[wv] = inc;
+            __syncthreads();
+            uint32_t pre = inc - tot;
+            for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const uint32_t i = threadIdx.x * PER + q; if (i <= lowmask) sub[i] = pre; pre += c[q]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * THREADS;
+            if (j < have && ((uint32_t)(w[r] >> fshift) & fmask) == bbin)
+                rk[r] = b0 + sub[(uint32_t)(w[r] >> (fshift - lowbits)) & lowmask] + idx[r];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
         if (j < have) {
             const uint32_t bin = (uint32_t)(w[r] >> fshift) & fmask;
             const uint32_t b0 = loff[bin], c = cnt[bin];
+            if (nbig && c > MSD_BIG_BIN) continue;                // placed by its bin's histogram above
+            if (lowbits == 0 && c > MSD_BIG_BIN) { rk[r] = b0 + rk[r]; continue; }   // no key bits left: the bin's keys are equal
             uint32_t smaller = 0;
             for (uint32_t q = 0; q < c; q++) smaller += buf[b0 + q] < w[r] ? 1u : 0u;
             rk[r] = b0 + smaller;
@@ -284,10 +339,14 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
     __shared__ uint64_t buf[MSD_FN_CAP];
     __shared__ uint32_t cnt[MSD_FN_BINS], loff[MSD_FN_BINS];
     __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
+    __shared__ uint32_t sub[1 << MSD_LOW_BITS];
+    __shared__ uint16_t biglist[MSD_FN_CAP / MSD_BIG_BIN + 1];
+    __shared__ uint32_t nbig_lds;
     const uint32_t have = a.count2[blockIdx.x];
     if (have == 0 || have > MSD_FN_CAP) return;                // the larger ones: k_msd_finish_big
     const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
-    msd_finish_body<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, in, have, in, have, a.out + a.off[blockIdx.x], fshift, fmask);
+    msd_finish_body<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, in, have, in, have, a.out + a.off[blockIdx.x], fshift, fmask,
+                                                fshift - a.pb, sub, biglist, &nbig_lds);
 }
 
 // sub-buckets whose stretch overflowed: the arena (sorted by sub-bucket) holds the slots beyond MSD_FN_CAP.  One
@@ -299,6 +358,9 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
     __shared__ uint64_t buf[MSD_BIG_CAP];
     __shared__ uint32_t cnt[MSD_FN_BINS], loff[MSD_FN_BINS];
     __shared__ uint32_t wsum[MSD_BIG_THREADS / 64];
+    __shared__ uint32_t sub[1 << MSD_LOW_BITS];
+    __shared__ uint16_t biglist[MSD_BIG_CAP / MSD_BIG_BIN + 1];
+    __shared__ uint32_t nbig_lds;
     const uint32_t e = blockIdx.x;
     if (e >= entries) return;
     const uint32_t sb = sb_sorted[e];
@@ -306,7 +368,7 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
     const uint32_t have = a.count2[sb];
     if (have > MSD_BIG_CAP || have <= MSD_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
     msd_finish_body<MSD_BIG_CAP, MSD_BIG_THREADS>(buf, cnt, loff, wsum, a.buf2 + (uint64_t)sb * MSD_FN_CAP, MSD_FN_CAP, w_sorted + e, have,
-                                                  a.out + a.off[sb], fshift, fmask);
+                                                  a.out + a.off[sb], fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
 }
 
 // Sorts the packed slots of the current text by their key bits.  *ok = 0: a capacity was exceeded (keys spread

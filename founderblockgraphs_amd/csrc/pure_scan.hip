@@ -212,6 +212,8 @@ template <int L> __device__ uint32_t ps_outside_match(const PsArgs &a, uint64_t 
 template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs a, uint32_t count)
 {
     __shared__ uint32_t spos[PS_MAX_GROUP], srem[PS_MAX_GROUP];
+    __shared__ uint16_t other[PS_MAX_GROUP];
+    __shared__ uint32_t n_other;
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
         const uint32_t g = a.mixed[e];
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
@@ -226,14 +228,32 @@ template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs
             srem[i] = rs_rem<L>(a.r, p);
         }
         __syncthreads();
+        // The usual mixed group is one column's rows plus a stray suffix or two from elsewhere: the members outside the
+        // majority column (the column two of three probes agree on) are listed, a member of the majority column meets
+        // only those, and only a listed member meets everybody -- |group| * |strays| comparisons instead of |group|^2
+        const uint32_t ra = srem[0], rb = srem[s / 2], rc = srem[s - 1];
+        const uint32_t major = (ra == rb || ra == rc) ? ra : rb;
+        if (threadIdx.x == 0) n_other = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < s; i += PS_THREADS)
+            if (srem[i] != major) { const uint32_t e2 = atomicAdd(&n_other, 1u); other[e2] = (uint16_t)i; }
+        __syncthreads();
+        const uint32_t no = n_other;
         for (uint32_t i = threadIdx.x; i < s; i += PS_THREADS) {
             const uint32_t rem = srem[i];
             if (rem == 0) continue;
             const uint64_t p = spos[i];
             uint32_t best = 0;
-            for (uint32_t q = 0; q < s; q++) {
-                if (srem[q] == rem) continue;                  // same column: coloured together
-                best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
+            if (rem == major) {
+                for (uint32_t k = 0; k < no; k++) {
+                    const uint32_t q = other[k];
+                    best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
+                }
+            } else {
+                for (uint32_t q = 0; q < s; q++) {
+                    if (srem[q] == rem) continue;              // same column: coloured together
+                    best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
+                }
             }
             if (has_short) best = max(best, max(ps_outside_match<L>(a, g, key, rem, -1), ps_outside_match<L>(a, g, key, rem, +1)));
             rs_update(a.r, rs_col_of_rem(a.r, rem), fbg_clamp_lcp(best) + 1);

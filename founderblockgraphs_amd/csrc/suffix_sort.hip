@@ -972,6 +972,13 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     int pre_ok = ctx->gapfree && !ctx->have_ignore && !ctx->opt.no_ranked;
     FBG_TRY(fbg_key_setup(ctx, pre_ok != 0, &g, &launches));
     pre_ok = pre_ok && g.compact;
+    if (pre_ok) {
+        // similar rows tie almost everywhere: not for the slot-level scan of the partitions (every rank draws the same
+        // sample and declines alike); the caller builds the whole index, whose group-level scan is made for them
+        bool similar = false;
+        FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
+        if (similar) pre_ok = 0;
+    }
     ctx->part = part; ctx->nparts = nparts; ctx->part_active = true;
     uint64_t count = 0;
     // splitters: quantiles of a sorted key sample -- the same on every rank, ties never straddle a boundary
