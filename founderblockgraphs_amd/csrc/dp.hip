@@ -733,14 +733,14 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             // (64 R >= 2 max_ext + 2) is rarely needed: start with the smallest one that holds every extension and
             // widen when the sweep reports a value at its limit
             uint8_t *ext7 = ctx->dp_e.as<uint8_t>(), *clen = ctx->dp_f.as<uint8_t>();
-            // The smallest window first, whatever the extensions: columns whose minimal extension does not fit the window
-            // are no candidates inside it, and a block longer than the window is not looked at -- both cost more than the
-            // window, so as long as every minmaxlength found stays BELOW the window (the flag k_dp_expand raises otherwise)
-            // no such block could have improved on it and the values are the reference's.  (Induction over j: the first
-            // column where the windowed value exceeds the true one would need a true optimum through a dead candidate or a
-            // long block, i.e. a true value above the window, yet the windowed value is below it and never smaller than
-            // the true one.)
+            // Exactness of a window: columns whose minimal extension does not fit it are no candidates inside it, and a
+            // block longer than the window is not looked at -- both cost more than the window, so as long as every
+            // minmaxlength found stays BELOW the window (the flag k_dp_expand raises otherwise) no such block could have
+            // improved on it and the values are the reference's.  (Induction over j: the first column where the windowed
+            // value exceeds the true one would need a true optimum through a dead candidate or a long block, i.e. a true
+            // value above the window, yet the windowed value is below it and never smaller than the true one.)
             int Rt = 1;
+            while (64ull * Rt < max_ext + 2 && Rt < 4) Rt *= 2;
             if (ctx->opt.dp_safe_window) Rt = R;
             for (; Rt <= 4 && Rt <= R && !settled; Rt *= 2) {
                 const bool tile = Rt == 1 && ctx->opt.dp_tile && f0 == 0;

@@ -247,11 +247,12 @@ template <int L> __global__ __launch_bounds__(PS_THREADS) void k_ps_mixed(PsArgs
             if (rem == major) {
                 for (uint32_t k = 0; k < no; k++) {
                     const uint32_t q = other[k];
+                    if (srem[q] == 0) continue;
                     best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
                 }
             } else {
                 for (uint32_t q = 0; q < s; q++) {
-                    if (srem[q] == rem) continue;              // same column: coloured together
+                    if (srem[q] == rem || srem[q] == 0) continue;   // same column: coloured together; '#': shares nothing
                     best = max(best, fbg_extend_match(a.r.T, p + from, (uint64_t)spos[q] + from, 0) + from);
                 }
             }
@@ -272,7 +273,8 @@ template <int L> __global__ void k_ps_slow(PsArgs a, uint32_t count)
     uint32_t best = 0;
     for (uint64_t k = a.gstart[gh.y]; k < a.gstart[gh.y + 1]; k++) {
         const uint64_t q = rs_pos<L>(a.r, k);
-        if (rs_rem<L>(a.r, q) == rem) continue;
+        const uint32_t rq = rs_rem<L>(a.r, q);
+        if (rq == rem || rq == 0) continue;                    // same column; '#' / sentinel: shares nothing
         best = max(best, fbg_extend_match(a.r.T, p, q, 0));
     }
     rs_update(a.r, rs_col_of_rem(a.r, rem), fbg_clamp_lcp(best) + 1);

@@ -571,6 +571,56 @@ __global__ void k_fix_dirty(const uint32_t *__restrict__ dirty, uint64_t cnt, co
     rec[p].z = ln;
 }
 
+// indices of the set flags (bytes), ascending: per tile of 16 KiB of flags a count, an exclusive scan of the counts
+// (small), then every tile writes its indices at its offset.  (rocPRIM's select over a byte array took 5 ms for
+// 5 * 10^8 flags: these two passes read 1 byte per element at full width, 0.3 ms.)
+#define FC_THREADS 256
+#define FC_TILE (FC_THREADS * 64)
+template <bool WRITE>
+__global__ __launch_bounds__(FC_THREADS) void k_flag_compact(const uint8_t *__restrict__ flags, uint64_t cnt, uint32_t *__restrict__ tile_cnt,
+                                                             uint32_t *__restrict__ sel)
+{
+    __shared__ uint32_t lds[FC_THREADS / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * FC_TILE + (uint64_t)threadIdx.x * 64;
+    // 64 flags per thread: four 16-byte loads (flags[] is allocated in whole tiles)
+    uint32_t bits[2] = {0, 0};
+    const uint4 *src = reinterpret_cast<const uint4 *>(flags + base);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (base + 16 * q < cnt) v = src[q];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool set = ((w4[i >> 2] >> (8 * (i & 3))) & 0xffu) != 0 && base + 16 * q + i < cnt;
+            bits[(16 * q + i) >> 5] |= (set ? 1u : 0u) << ((16 * q + i) & 31);
+        }
+    }
+    const uint32_t mine = (uint32_t)__popc(bits[0]) + (uint32_t)__popc(bits[1]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (int k = 0; k < FC_THREADS / 64; k++) { if (k < w) pre += lds[k]; tot += lds[k]; }
+    if (!WRITE) {
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+        return;
+    }
+    uint32_t at = tile_cnt[blockIdx.x] + pre + inc - mine;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t b = bits[h];
+        while (b) {
+            const int i = __ffs((int)b) - 1;
+            b &= b - 1;
+            sel[at++] = (uint32_t)(base + 32 * h + i);
+        }
+    }
+}
+
 struct KeepIdx { uint32_t r, p, g; };
 
 // compact the unresolved members: (SA index, position, group head) triples in SA order
@@ -801,7 +851,6 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     uint32_t *grp = nullptr;
     uint4 *rec = nullptr;
     uint8_t *flags = nullptr;
-    unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
     uint32_t *sa = valsB;                     // the sorted positions ARE the suffix array
     ctx->sa_ptr = sa;
     ColTest ct;
@@ -819,7 +868,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         FBG_TRY(sort_slots(ctx, g, N, 0));
     }
     FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->flags, N));
+    FBG_TRY(fbg_reserve(ctx, ctx->flags, (N + FC_TILE - 1) / FC_TILE * FC_TILE));   // whole tiles: k_flag_compact loads 16 bytes at a time
     FBG_TRY(fbg_reserve(ctx, ctx->rec, N * 16));
     grp = ctx->grp.as<uint32_t>();
     rec = ctx->rec.as<uint4>();
@@ -890,13 +939,23 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     uint64_t *dkeys_in = keysA, *dkeys_out = nullptr;
     for (int round = 1;; round++) {
         // select unresolved members of the current list
-        FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::select(tmp, bytes, rocprim::counting_iterator<uint32_t>(0), flags, sel, d_count, (size_t)cnt, st);
-        }));
         unsigned long long hc = 0;
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(&hc, d_count, sizeof(hc), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        launches += 1;
+        {
+            const unsigned ftiles = fbg_blocks(cnt, FC_TILE);
+            FBG_TRY(fbg_reserve(ctx, ctx->ps_a, ((size_t)ftiles + 1) * 4));
+            uint32_t *tile_cnt = ctx->ps_a.as<uint32_t>();
+            hipLaunchKernelGGL((k_flag_compact<false>), dim3(ftiles), dim3(FC_THREADS), 0, st, flags, cnt, tile_cnt, sel);
+            FBG_HIP_TRY(ctx, hipMemsetAsync(tile_cnt + ftiles, 0, 4, st));
+            FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+                return rocprim::exclusive_scan(tmp, bytes, tile_cnt, tile_cnt, 0u, (size_t)ftiles + 1, rocprim::plus<uint32_t>(), st);
+            }));
+            hipLaunchKernelGGL((k_flag_compact<true>), dim3(ftiles), dim3(FC_THREADS), 0, st, flags, cnt, tile_cnt, sel);
+            uint32_t h32 = 0;
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(&h32, tile_cnt + ftiles, 4, hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            hc = h32;
+        }
+        launches += 3;
         if (round == 1) {
             // few ties: the key-derived LCPs stand, only the tie groups are patched afterwards;
             // the round-0 keys (keysB) must then survive the doubling rounds

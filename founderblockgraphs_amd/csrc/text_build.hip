@@ -400,8 +400,9 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     const unsigned nseg = (unsigned)((n + RC_SEG - 1) / RC_SEG);
     FBG_TRY(fbg_reserve(ctx, ctx->segtab, (size_t)m * nseg * 4 * 3));   // per (row, segment): non-gap cells, their prefix, first ignore column
     uint32_t *segcnt = ctx->segtab.as<uint32_t>(), *segoff = segcnt + (size_t)m * nseg, *segmin = segoff + (size_t)m * nseg;
+    // (the kernel can count the ignore cells too; nobody asks for that number, and without it rows take the word-wide path)
     hipLaunchKernelGGL(k_row_count, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
-                       n, d_is_ignore, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt);
+                       n, (const uint8_t *)nullptr, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt);
     hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(64), 0, st, ctx->tot.as<uint32_t>(), m,
                        ctx->pos.as<uint32_t>(), sc);
     launches += 2;
