@@ -162,6 +162,7 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
 int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip
 int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
                       uint64_t *count, int *ok, int *launches);                                       // msd_sort_pairs.hip                        // suffix_sort.hip
+int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches);                      // msd_sort_pairs.hip
 int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks,
                      uint64_t *d_out);                                        // scan.hip
 int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_boundaries,

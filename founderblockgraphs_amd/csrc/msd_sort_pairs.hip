@@ -8,6 +8,15 @@
 // partitions, so that it collects about 4096 slots of its range before it regroups and writes them.  Passes 2 and 3
 // are those of msd_sort.hip with a second array riding along.  Capacities are optimistic in the same way; a flag
 // sends the caller back to k_pack<FILTER> + rocPRIM.
+//
+// MODE 1 (fbg_sample_sort_pairs): the same three passes for the record path's whole text, whose keys are NOT spread
+// evenly (order-preserving 3-bit codes of a 5- or 7-letter alphabet use a fraction of the key space: 27 leading bits
+// carry 18 bits of entropy, and a linear bucket function sends everything to a few buckets).  Buckets and sub-buckets
+// are then the 512 * 512 quantiles of a sorted sample of 2^22 keys (a sample sort): a slot's bucket is the number of
+// grid keys G[512], G[1024], ... not above its key (binary search in LDS), its sub-bucket likewise within the bucket's
+// 511 inner grid keys, and the finish bins the keys of a sub-bucket linearly between its two grid keys.  Equal keys go
+// the same way at every level; a key so frequent that it swallows grid points overflows a capacity and sends the caller
+// to rocPRIM like any other overflow.
 #include "fbg_internal.h"
 #include "msd_keys.h"
 #include <rocprim/rocprim.hpp>
@@ -37,11 +46,33 @@ struct PpArgs {
     uint64_t *wout; uint32_t *vout;
     uint32_t *arena_sb; uint64_t *arena_w; uint32_t *arena_v; unsigned long long *arena_count;
     unsigned long long *flag;
+    const uint64_t *grid;                      // MODE 1: G[PP_NB * PP_NB] quantiles of the key sample (G[0] is not used: below every key)
+    uint64_t top;                              // MODE 1: 2^key_bits, the end of the last sub-bucket's key range
 };
 
 // t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
 __device__ __forceinline__ uint32_t pp_t28(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
 #define PP_FBINS 1024
+
+// MODE 1: number of grid keys sp[1..511] not above the key (sp[0] counts as below every key): 9 steps, no branches
+__device__ __forceinline__ uint32_t pp_rank511(const uint64_t *sp, uint64_t key)
+{
+    uint32_t at = 0;
+#pragma unroll
+    for (uint32_t step = 256; step >= 1; step >>= 1)
+        if (sp[at + step] <= key) at += step;
+    return at;
+}
+
+// the digit of regrouped slot j: the last d with loff[d] <= j (its successor starts beyond j, so it is not empty)
+__device__ __forceinline__ uint32_t pp_digit_of_slot(const uint32_t *loff, uint32_t j)
+{
+    uint32_t at = 0;
+#pragma unroll
+    for (uint32_t step = 256; step >= 1; step >>= 1)
+        if (loff[at + step] <= j) at += step;
+    return at;
+}
 
 // scan of PP_NB counts (one per thread) + run reservation, as msd_scan_and_reserve
 __device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *loff, unsigned long long *gbase, uint32_t *wsum,
@@ -67,7 +98,7 @@ __device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *lof
 // cnt (zeroed by the caller), offsets in loff
 template <int CAP, class Digit>
 __device__ __forceinline__ void pp_regroup(uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t have, Digit digit, uint64_t *w, uint32_t *v,
-                                           uint32_t *rk)
+                                           uint32_t *rk, uint32_t *dg)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
 #pragma unroll
@@ -75,13 +106,15 @@ __device__ __forceinline__ void pp_regroup(uint64_t *sw, uint32_t *sv, uint32_t 
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         w[r] = j < have ? sw[j] : ~0ull;
         v[r] = j < have ? sv[j] : 0u;
-        rk[r] = j < have ? atomicAdd(&cnt[digit(w[r])], 1u) : 0u;
+        dg[r] = j < have ? digit(w[r]) : 0u;
+        rk[r] = j < have ? atomicAdd(&cnt[dg[r]], 1u) : 0u;
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
+template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
 {
+    __shared__ uint64_t sp[MODE == 1 ? PP_NB : 1];         // MODE 1: the bucket splitters G[512 j]
     __shared__ uint64_t sw[PP_STAGE];
     __shared__ uint32_t sv[PP_STAGE];
     __shared__ uint8_t tile[PP_TILE + 64];
@@ -93,6 +126,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
     if (threadIdx.x < 256) cd[threadIdx.x] = a.code[threadIdx.x];
     cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) staged = 0;
+    if (MODE == 1) sp[threadIdx.x] = threadIdx.x ? a.grid[(size_t)PP_NB * threadIdx.x] : 0ull;
     const int lane = threadIdx.x & 63;
     const uint64_t base0 = (uint64_t)blockIdx.x * a.nparts * PP_TILE;
     uint64_t raw = 0, raw2 = 0;
@@ -136,12 +170,13 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
     const uint32_t have = min(staged, (uint32_t)PP_STAGE);
     uint64_t w[PP_STAGE / PP_THREADS];
     uint32_t v[PP_STAGE / PP_THREADS], rk[PP_STAGE / PP_THREADS];
-    pp_regroup<PP_STAGE>(sw, sv, cnt, have, [&](uint64_t x) { return pp_t28(a, x) >> 19; }, w, v, rk);
+    uint32_t dg[PP_STAGE / PP_THREADS];
+    pp_regroup<PP_STAGE>(sw, sv, cnt, have, [&](uint64_t x) { return MODE == 1 ? pp_rank511(sp, x >> a.pb) : pp_t28(a, x) >> 19; }, w, v, rk, dg);
     pp_scan_and_reserve(cnt, loff, gbase, wsum, a.count1, nullptr);
 #pragma unroll
     for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[pp_t28(a, w[r]) >> 19] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
 #pragma unroll
@@ -149,7 +184,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_split(PpArgs a)
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
             const uint64_t x = sw[j];
-            const uint32_t d = pp_t28(a, x) >> 19;
+            const uint32_t d = MODE == 1 ? pp_digit_of_slot(loff, j) : pp_t28(a, x) >> 19;
             const uint64_t at = gbase[d] + (j - loff[d]);
             if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; if (!a.packed) a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
             else *a.flag = 1;
@@ -174,8 +209,9 @@ __global__ void k_pp_tiles(const unsigned long long *__restrict__ count1, uint64
     *total = sum;
 }
 
-__global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
+template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
 {
+    __shared__ uint64_t sp[MODE == 1 ? PP_NB : 1];         // MODE 1: the inner grid keys of this tile's bucket
     __shared__ uint64_t sw[PP_TILE];
     __shared__ uint32_t sv[PP_TILE];
     __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
@@ -190,9 +226,10 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
     const uint64_t *inw = a.w1 + (uint64_t)seg * a.cap1 + first;
     const uint32_t *inv = a.v1 + (uint64_t)seg * a.cap1 + first;
     cnt[threadIdx.x] = 0;
+    if (MODE == 1) sp[threadIdx.x] = threadIdx.x ? a.grid[(size_t)PP_NB * seg + threadIdx.x] : 0ull;
     __syncthreads();
     uint64_t w[MSD_ITEMS];
-    uint32_t v[MSD_ITEMS], rk[MSD_ITEMS];
+    uint32_t v[MSD_ITEMS], rk[MSD_ITEMS], dg[MSD_ITEMS];
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
@@ -202,14 +239,15 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        rk[r] = j < have ? atomicAdd(&cnt[(pp_t28(a, w[r]) >> 10) & (PP_NB - 1)], 1u) : 0u;
+        dg[r] = j < have ? (MODE == 1 ? pp_rank511(sp, w[r] >> a.pb) : (pp_t28(a, w[r]) >> 10) & (PP_NB - 1)) : 0u;
+        rk[r] = j < have ? atomicAdd(&cnt[dg[r]], 1u) : 0u;
     }
     __syncthreads();
     pp_scan_and_reserve(cnt, loff, gbase, wsum, nullptr, a.count2 + (size_t)seg * PP_NB);
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[(pp_t28(a, w[r]) >> 10) & (PP_NB - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
 #pragma unroll
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
             const uint64_t x = sw[j];
-            const uint32_t d = (pp_t28(a, x) >> 10) & (PP_NB - 1);
+            const uint32_t d = MODE == 1 ? pp_digit_of_slot(loff, j) : (pp_t28(a, x) >> 10) & (PP_NB - 1);
             const uint64_t at = gbase[d] + (j - loff[d]);
             const uint64_t sb = (uint64_t)seg * PP_NB + d;
             if (at < PP_FN_CAP) { a.w2[sb * PP_FN_CAP + at] = x; if (!a.packed) a.v2[sb * PP_FN_CAP + at] = sv[j]; }
@@ -238,12 +276,26 @@ __global__ void k_pp_widen(const uint32_t *__restrict__ count2, unsigned long lo
 
 // slots (first n_a from a, the rest from b) -> out, sorted by (word, low position): bins on the last 9 bits of t
 // inside LDS, then every slot counts the smaller slots of its bin
-template <int CAP>
+template <int CAP, int MODE>
 __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t *loff, uint32_t *wsum,
                                                const uint64_t *wa, const uint32_t *va, uint32_t n_a, const uint64_t *wb,
-                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout)
+                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint32_t sb)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
+    // MODE 1: the keys of sub-bucket sb lie in [G[sb], G[sb + 1]); bins are linear in between (monotone in the key:
+    // conversion to double and a multiplication by a positive constant both are)
+    uint64_t klo = 0;
+    double kscale = 0.0;
+    if (MODE == 1) {
+        klo = sb ? a.grid[sb] : 0ull;
+        const uint64_t khi = sb + 1 < (uint32_t)(PP_NB * PP_NB) ? a.grid[sb + 1] : a.top;
+        kscale = khi > klo ? (double)PP_FBINS / (double)(khi - klo) : 0.0;
+    }
+    auto bin_of = [&](uint64_t word) -> uint32_t {
+        if (MODE == 1) return min((uint32_t)(PP_FBINS - 1), (uint32_t)((double)((word >> a.pb) - klo) * kscale));
+        return pp_t28(a, word) & (PP_FBINS - 1);
+    };
+    uint32_t bn[ITEMS];
     cnt[2 * threadIdx.x] = 0; cnt[2 * threadIdx.x + 1] = 0;    // PP_FBINS bins, two per thread
     __syncthreads();
     uint64_t w[ITEMS];
@@ -257,7 +309,8 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        rk[r] = j < have ? atomicAdd(&cnt[pp_t28(a, w[r]) & (PP_FBINS - 1)], 1u) : 0u;
+        bn[r] = j < have ? bin_of(w[r]) : 0u;
+        rk[r] = j < have ? atomicAdd(&cnt[bn[r]], 1u) : 0u;
     }
     __syncthreads();
     {
@@ -277,14 +330,14 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[pp_t28(a, w[r]) & (PP_FBINS - 1)] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[bn[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
-            const uint32_t bin = pp_t28(a, w[r]) & (PP_FBINS - 1);
+            const uint32_t bin = bn[r];
             const uint32_t b0 = loff[bin], c = cnt[bin];
             uint32_t smaller = 0;
             for (uint32_t q = 0; q < c; q++) {
@@ -308,7 +361,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     }
 }
 
-__global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a)
+template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a)
 {
     __shared__ uint64_t sw[PP_FN_CAP];
     __shared__ uint32_t sv[PP_FN_CAP];
@@ -318,10 +371,11 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a)
     if (have == 0 || have > PP_FN_CAP) return;                 // the larger ones: k_pp_finish_big
     const uint64_t *wa = a.w2 + (uint64_t)blockIdx.x * PP_FN_CAP;
     const uint32_t *va = a.v2 + (uint64_t)blockIdx.x * PP_FN_CAP;
-    pp_finish_body<PP_FN_CAP>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[blockIdx.x], a.vout + a.off[blockIdx.x]);
+    pp_finish_body<PP_FN_CAP, MODE>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[blockIdx.x], a.vout + a.off[blockIdx.x],
+                                    blockIdx.x);
 }
 
-__global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
+template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
                                                               const uint32_t *__restrict__ idx_sorted, uint32_t entries,
                                                               uint64_t *__restrict__ gw, uint32_t *__restrict__ gv)
 {
@@ -336,8 +390,8 @@ __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const ui
     if (e > 0 && sb_sorted[e - 1] == sb) return;
     const uint32_t have = a.count2[sb];
     if (have > PP_BIG_CAP || have <= PP_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
-    pp_finish_body<PP_BIG_CAP>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
-                               gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb]);
+    pp_finish_body<PP_BIG_CAP, MODE>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
+                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], sb);
 }
 
 __global__ void k_pp_gather(const uint32_t *__restrict__ idx_sorted, const uint64_t *__restrict__ aw, const uint32_t *__restrict__ av,
@@ -353,25 +407,16 @@ __global__ void k_pp_iota(uint32_t *__restrict__ idx, uint32_t n)
     if (e < n) idx[e] = e;
 }
 
-// Packs, filters and sorts the slots of key range [lo, hi) of the current text into out_w / out_v (count of them
-// in *count).  *ok = 0: not done (a capacity was exceeded, or the sizes do not suit this sort): nothing usable.
-int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
-                      uint64_t *count, int *ok, int *launches)
+// The three passes.  a: key range / bucket function filled in by the caller; est: slots expected.  *ok = 0: not done
+// (a capacity was exceeded): nothing usable.
+template <int MODE>
+static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int nparts, uint64_t out_offset, uint64_t *count, int *ok,
+                   int *launches)
 {
-    *ok = 0;
     const uint64_t N = ctx->N;
-    const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);
-    if (!g.compact || N / nparts < min_n || ctx->opt.no_msd_sort) return FBG_OK;
-    const uint64_t top = g.key_bits >= 64 ? ~0ull : (1ull << g.key_bits);
-    const uint64_t span = (nohi ? top : hi) - lo;
-    if (span < (1ull << 29) || g.key_bits >= 64) return FBG_OK;       // t needs 28 bits of resolution below the span
-    const unsigned __int128 one = 1;
-    const uint64_t mul = (uint64_t)((one << 92) / span);               // < 2^64 since span > 2^28
     hipStream_t st = ctx->stream;
-    const uint64_t est = N / nparts + N / (64 * (uint64_t)nparts) + 65536;   // the partitions are quantiles of a sample: sizes within a percent
     const uint64_t cap1 = est / PP_NB + est / (4 * PP_NB) + 65536;
     const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
-    if (est / nsub + est / (8 * nsub) + 64 > PP_FN_CAP) return FBG_OK;
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)PP_NB * cap1 * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsA, (size_t)PP_NB * cap1 * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->msd_w, (size_t)nsub * PP_FN_CAP * 8));
@@ -382,10 +427,8 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)PP_ARENA * 4 * 5));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_e, (size_t)PP_ARENA * 8 * 2));
     unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;      // [0] flag, [1] arena count, [2] total
-    PpArgs a;
     a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = (g.wide || g.packed) ? g.pb : 0; a.nparts = nparts;
     a.wide = g.wide ? 1 : 0; a.packed = g.packed ? 1 : 0;
-    a.lo = lo; a.hi = hi; a.mul = mul; a.nohi = nohi;
     a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
     a.count1 = ctx->dp_a.as<unsigned long long>();
     uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + PP_NB * 8);
@@ -402,7 +445,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 24, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, PP_NB * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
-    hipLaunchKernelGGL(k_pp_pack_split, dim3(fbg_blocks(N, (uint64_t)PP_TILE * nparts)), dim3(PP_THREADS), 0, st, a);
+    hipLaunchKernelGGL((k_pp_pack_split<MODE>), dim3(fbg_blocks(N, (uint64_t)PP_TILE * nparts)), dim3(PP_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_pp_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag + 2, flag);
     uint32_t tiles2 = 0;
     unsigned long long h3[3] = {0, 0, 0};
@@ -415,7 +458,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, (total + 2 * out_offset) * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsB, (total + 2 * out_offset) * 4));
     a.wout = ctx->keysB.as<uint64_t>() + out_offset; a.vout = ctx->valsB.as<uint32_t>() + out_offset;
-    hipLaunchKernelGGL(k_pp_split, dim3(tiles2), dim3(PP_THREADS), 0, st, a);
+    hipLaunchKernelGGL((k_pp_split<MODE>), dim3(tiles2), dim3(PP_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_pp_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);
     {
         size_t bytes = 0;
@@ -426,7 +469,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
         e = rocprim::exclusive_scan(ctx->tmp.p, have, wide, off, 0ull, (size_t)nsub, rocprim::plus<unsigned long long>(), st);
         if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k_pp_finish, dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a);
+    hipLaunchKernelGGL((k_pp_finish<MODE>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a);
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 4;
@@ -444,7 +487,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
         uint64_t *gw = a.arena_w + PP_ARENA;
         uint32_t *gv = a_idx;                                  // the iota is consumed by the sort
         hipLaunchKernelGGL(k_pp_gather, dim3(fbg_blocks(entries, 256)), dim3(256), 0, st, idx_sorted, a.arena_w, a.arena_v, entries, gw, gv);
-        hipLaunchKernelGGL(k_pp_finish_big, dim3(entries), dim3(PP_THREADS), 0, st, a, sb_sorted, idx_sorted, entries, gw, gv);
+        hipLaunchKernelGGL((k_pp_finish_big<MODE>), dim3(entries), dim3(PP_THREADS), 0, st, a, sb_sorted, idx_sorted, entries, gw, gv);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 4;
@@ -453,5 +496,89 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     FBG_HIP_TRY(ctx, hipGetLastError());
     *count = total;
     *ok = 1;
+    return FBG_OK;
+}
+
+// Packs, filters and sorts the slots of key range [lo, hi) of the current text into keysB / valsB at out_offset (count
+// of them in *count).  *ok = 0: not done (a capacity was exceeded, or the sizes do not suit this sort): nothing usable.
+int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
+                      uint64_t *count, int *ok, int *launches)
+{
+    *ok = 0;
+    const uint64_t N = ctx->N;
+    const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);
+    if (!g.compact || N / nparts < min_n || ctx->opt.no_msd_sort) return FBG_OK;
+    const uint64_t top = g.key_bits >= 64 ? ~0ull : (1ull << g.key_bits);
+    const uint64_t span = (nohi ? top : hi) - lo;
+    if (span < (1ull << 29) || g.key_bits >= 64) return FBG_OK;       // t needs 28 bits of resolution below the span
+    const unsigned __int128 one = 1;
+    const uint64_t est = N / nparts + N / (64 * (uint64_t)nparts) + 65536;   // the partitions are quantiles of a sample: sizes within a percent
+    const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
+    if (est / nsub + est / (8 * nsub) + 64 > PP_FN_CAP) return FBG_OK;
+    PpArgs a;
+    a.lo = lo; a.hi = hi; a.mul = (uint64_t)((one << 92) / span); a.nohi = nohi;      // mul < 2^64 since span > 2^28
+    a.grid = nullptr; a.top = top;
+    return pp_sort<0>(ctx, g, a, est, nparts, out_offset, count, ok, launches);
+}
+
+// keys of every stride-th text position, as k_pack builds them without the compact coding (general alphabet)
+__global__ void k_ss_sample(const uint8_t *__restrict__ T, uint64_t N, const uint8_t *__restrict__ code, int b, int K, uint64_t stride,
+                            uint64_t S, uint64_t *__restrict__ out)
+{
+    __shared__ uint8_t cd[256];
+    if (threadIdx.x < 256) cd[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const uint64_t p = i * stride;
+    uint64_t key = 0;
+    for (int k = 0; k < K; k++) key = (key << b) | (p + k < N ? (uint64_t)cd[T[p + k]] : 0ull);
+    out[i] = key;
+}
+
+__global__ void k_ss_grid(const uint64_t *__restrict__ sorted, uint64_t S, uint64_t *__restrict__ grid)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (uint64_t)PP_NB * PP_NB) grid[t] = sorted[t * S / ((uint64_t)PP_NB * PP_NB)];
+}
+
+// The record path's round-0 sort (suffix_sort.hip): all N (key, position) pairs of the current text, keys in the
+// order-preserving code of any alphabet, into keysB / valsB.  Sample sort: see the head of this file.
+int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches)
+{
+    *ok = 0;
+    const uint64_t N = ctx->N;
+    const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);
+    const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
+    // sub-bucket sizes follow the sample (2^22 keys, 16 per sub-bucket: +-25 %): they must fit their stretches twice over
+    if (g.compact || g.packed || g.wide || N < min_n || N >= (1ull << 32) || ctx->opt.no_msd_sort || g.key_bits >= 64) return FBG_OK;
+    if (2 * (N / nsub) + 64 > PP_FN_CAP) return FBG_OK;
+    hipStream_t st = ctx->stream;
+    uint64_t S = 1ull << 22;
+    while (S > N / 4 && S > 256) S >>= 1;                  // small texts (tests): a coarser grid, buckets stay far below capacity
+    if (N / S == 0) return FBG_OK;
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, S * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, S * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_d, nsub * 8));
+    uint64_t *smp = ctx->ps_b.as<uint64_t>(), *srt = ctx->ps_c.as<uint64_t>(), *grid = ctx->ps_d.as<uint64_t>();
+    hipLaunchKernelGGL(k_ss_sample, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, ctx->text.as<uint8_t>(), N, g.d_code, g.b, g.K, N / S, S, smp);
+    {
+        size_t bytes = 0;
+        hipError_t e = rocprim::radix_sort_keys(nullptr, bytes, smp, srt, (size_t)S, 0u, (unsigned)g.key_bits, st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim sort size query: %s", hipGetErrorString(e));
+        FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+        size_t have = ctx->tmp.cap;
+        e = rocprim::radix_sort_keys(ctx->tmp.p, have, smp, srt, (size_t)S, 0u, (unsigned)g.key_bits, st);
+        if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_keys: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_ss_grid, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, srt, S, grid);
+    *launches += 3;
+    PpArgs a;
+    a.lo = 0; a.hi = 0; a.mul = 0; a.nohi = 1;
+    a.grid = grid; a.top = 1ull << g.key_bits;
+    uint64_t count = 0;
+    const uint64_t est = N + N / 64 + 65536;
+    FBG_TRY(pp_sort<1>(ctx, g, a, est, 1, 0, &count, ok, launches));
+    if (*ok && count != N) { *ok = 0; }
     return FBG_OK;
 }

@@ -859,13 +859,24 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     ct.n = (uint32_t)ctx->n;
     ct.last = (uint32_t)(N - 1);
     {
-        PackArgs pa;
-        pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = b; pa.K = K; pa.pb = 0;
-        pa.keys = keysA; pa.vals = valsA;
-        pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
-        launch_pack(ctx, g, false, pa);
-        launches++;
-        FBG_TRY(sort_slots(ctx, g, N, 0));
+        // three passes of a sample sort fused with the key packing (msd_sort_pairs.hip) where the sizes suit it; else,
+        // or when a capacity does not hold, pack and sort with rocPRIM's onesweep
+        int ss_ok = 0;
+        FBG_TRY(fbg_sample_sort_pairs(ctx, g, &ss_ok, &launches));
+        if (!ss_ok) {
+            PackArgs pa;
+            pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = b; pa.K = K; pa.pb = 0;
+            pa.keys = keysA; pa.vals = valsA;
+            pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
+            launch_pack(ctx, g, false, pa);
+            launches++;
+            FBG_TRY(sort_slots(ctx, g, N, 0));
+        }
+        // the sample sort sizes its buffers itself: take the pointers again
+        keysA = ctx->keysA.as<uint64_t>(); keysB = ctx->keysB.as<uint64_t>();
+        valsA = ctx->valsA.as<uint32_t>(); valsB = ctx->valsB.as<uint32_t>();
+        sa = valsB;
+        ctx->sa_ptr = sa;
     }
     FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->flags, (N + FC_TILE - 1) / FC_TILE * FC_TILE));   // whole tiles: k_flag_compact loads 16 bytes at a time

@@ -19,6 +19,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 ENVS = [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_MSD_MIN": "1"}, {"FBG_RANK_NO_THRESHOLD": "1"},
         {"FBG_NO_RANKED": "1"}, {"FBG_FULL_KEYS": "1"}, {"FBG_MSD_MIN": "1", "FBG_FORCE_WIDE": "1", "FBG_FULL_KEYS": "1"},
         {"FBG_MSD_MIN": "1", "FBG_FULL_KEYS": "1"}, {"FBG_BP_MIN": "1"}, {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},
+        {"FBG_MSD_MIN": "1", "FBG_NO_RANKED": "1"}, {"FBG_MSD_MIN": "1", "FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},
         {"FBG_PURE_SCAN": "1"}, {"FBG_PURE_SCAN": "1", "FBG_NO_PACKED": "1"}, {"FBG_PURE_SCAN": "1", "FBG_MSD_MIN": "1"}]
 ALL_KEYS = sorted({k for e in ENVS for k in e})
 eng = F.Engine(0)

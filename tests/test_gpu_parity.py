@@ -388,6 +388,7 @@ ALT_PATHS = [
     {"FBG_FORCE_WIDE": "1"},                         # ... on wide pairs (the layout for texts beyond 2^32 symbols)
     {"FBG_MSD_MIN": "1"},                            # three-pass MSD sort (msd_sort.hip) also for small texts
     {"FBG_NO_MSD_SORT": "1"},                        # rocPRIM's onesweep instead of it
+    {"FBG_MSD_MIN": "1", "FBG_NO_RANKED": "1"},      # record path behind the three-pass sample sort of (key, position) pairs
     {"FBG_BP_MIN": "1"},                             # records reach their text positions through splitting passes ...
     {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},       # ... also for gap-free MSAs
     {"FBG_RECORD_SCATTER": "1"},                     # ... or by a direct scatter whatever the size
@@ -925,12 +926,16 @@ def test_gapped_nonelastic_large(engine):
     assert (b is None) == (gb is None) and (b is None or np.array_equal(gb, b))
 
 
-def test_records_by_position_passes(engine):
+@pytest.mark.parametrize("sort", ["rocprim", "samplesort"])
+def test_records_by_position_passes(engine, sort):
     """The record path's way back from suffix order to text order (k_bp_groups0 / k_bp_split / k_bp_leaf): index arrays
-    against the oracle with the passes forced on small texts, and a gapped MSA large enough to take them by itself."""
+    against the oracle with the passes forced on small texts, and a gapped MSA large enough to take them by itself --
+    behind rocPRIM's sort and behind the three-pass sample sort of the pairs (msd_sort_pairs.hip, MODE 1)."""
     import os
     rng = np.random.default_rng(31)
-    with fbg_options(engine, {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"}):
+    switches = {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"}
+    switches["FBG_MSD_MIN" if sort == "samplesort" else "FBG_NO_MSD_SORT"] = "1"
+    with fbg_options(engine, switches):
         for (m, n, kw) in [(7, 1300, dict(gap_p=0.03, gap_run=5)), (33, 257, dict(similar=0.95)), (3, 3000, dict(alphabet="AC", similar=0.99)),
                            (65, 1290, dict(alphabet="ACGTN")), (2, 4097, {}), (9, 70000, dict(gap_p=0.01, gap_run=3))]:
             msa = random_msa(rng, m, n, **kw)
@@ -944,7 +949,8 @@ def test_records_by_position_passes(engine):
             assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA]), (m, n)
             assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1]), (m, n)
     msa = random_msa(rng, 24, 800000, gap_p=0.05 / 16, gap_run=16, n_p=0.001)      # 1.9 * 10^7 symbols > 2^24
-    assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), O.compute_f(msa, ignore="N", threads=8))
+    with fbg_options(engine, {"FBG_NO_MSD_SORT": "1"} if sort == "rocprim" else {}):
+        assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), O.compute_f(msa, ignore="N", threads=8))
 
 
 def test_gapped_v_on_a_partitioned_index():
