@@ -48,6 +48,7 @@ struct PpArgs {
     unsigned long long *flag;
     const uint64_t *grid;                      // MODE 1: G[PP_NB * PP_NB] quantiles of the key sample (G[0] is not used: below every key)
     uint64_t top;                              // MODE 1: 2^key_bits, the end of the last sub-bucket's key range
+    int sigma;                                 // MODE 1: number of symbol codes in use (codes are 0 .. sigma - 1)
 };
 
 // t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
@@ -282,17 +283,34 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
                                                const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint32_t sb)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
-    // MODE 1: the keys of sub-bucket sb lie in [G[sb], G[sb + 1]); bins are linear in between (monotone in the key:
-    // conversion to double and a multiplication by a positive constant both are)
-    uint64_t klo = 0;
-    double kscale = 0.0;
+    // MODE 1: the keys of sub-bucket sb lie in [G[sb], G[sb + 1]): they share the symbols the two grid keys share, and
+    // the bin is what follows, read as a number in base sigma (the codes are the ranks of the symbols that occur, so
+    // that number is dense where the key bits are not: 4 frequent letters in 3-bit codes fill a sixteenth of a linear
+    // map's bins after four symbols) -- first the symbol where the grid keys part, as an offset, then as many more
+    // symbols as 1024 bins hold.  Lexicographic in the symbols, hence monotone in the key; the cap keeps it so.
+    int s_shift = 0, s_more = 0;                           // bit position of the parting symbol; symbols after it
+    uint32_t s_first = 0;
     if (MODE == 1) {
-        klo = sb ? a.grid[sb] : 0ull;
-        const uint64_t khi = sb + 1 < (uint32_t)(PP_NB * PP_NB) ? a.grid[sb + 1] : a.top;
-        kscale = khi > klo ? (double)PP_FBINS / (double)(khi - klo) : 0.0;
+        const uint64_t klo = sb ? a.grid[sb] : 0ull;
+        const uint64_t khi = sb + 1 < (uint32_t)(PP_NB * PP_NB) ? a.grid[sb + 1] : a.top - 1;
+        const int kb = a.b * a.K;
+        const uint64_t d = klo ^ khi;
+        const int same = d ? (__clzll((long long)d) - (64 - kb)) / a.b : a.K - 1;      // leading symbols in common
+        const int c = same < a.K ? same : a.K - 1;
+        s_shift = a.b * (a.K - 1 - c);
+        const uint32_t smask = (1u << a.b) - 1;
+        s_first = (uint32_t)(klo >> s_shift) & smask;
+        uint32_t room = PP_FBINS / (((uint32_t)(khi >> s_shift) & smask) - s_first + 1);
+        while (s_more < a.K - 1 - c && room >= (uint32_t)a.sigma) { room /= (uint32_t)a.sigma; s_more++; }
     }
     auto bin_of = [&](uint64_t word) -> uint32_t {
-        if (MODE == 1) return min((uint32_t)(PP_FBINS - 1), (uint32_t)((double)((word >> a.pb) - klo) * kscale));
+        if (MODE == 1) {
+            const uint64_t key = word >> a.pb;
+            const uint32_t smask = (1u << a.b) - 1;
+            uint32_t v = ((uint32_t)(key >> s_shift) & smask) - s_first;
+            for (int q = 1; q <= s_more; q++) v = v * (uint32_t)a.sigma + ((uint32_t)(key >> (s_shift - q * a.b)) & smask);
+            return min((uint32_t)(PP_FBINS - 1), v);
+        }
         return pp_t28(a, word) & (PP_FBINS - 1);
     };
     uint32_t bn[ITEMS];
@@ -517,7 +535,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     if (est / nsub + est / (8 * nsub) + 64 > PP_FN_CAP) return FBG_OK;
     PpArgs a;
     a.lo = lo; a.hi = hi; a.mul = (uint64_t)((one << 92) / span); a.nohi = nohi;      // mul < 2^64 since span > 2^28
-    a.grid = nullptr; a.top = top;
+    a.grid = nullptr; a.top = top; a.sigma = 1 << g.b;
     return pp_sort<0>(ctx, g, a, est, nparts, out_offset, count, ok, launches);
 }
 
@@ -576,6 +594,9 @@ int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches
     PpArgs a;
     a.lo = 0; a.hi = 0; a.mul = 0; a.nohi = 1;
     a.grid = grid; a.top = 1ull << g.key_bits;
+    a.sigma = 0;
+    for (int c = 0; c < 256; c++) a.sigma += ctx->byte_hist[c] != 0;     // fbg_key_setup's order-preserving codes: 0 .. sigma - 1
+    if (a.sigma < 2) a.sigma = 2;
     uint64_t count = 0;
     const uint64_t est = N + N / 64 + 65536;
     FBG_TRY(pp_sort<1>(ctx, g, a, est, 1, 0, &count, ok, launches));
