@@ -54,6 +54,7 @@ struct PpArgs {
 // t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
 __device__ __forceinline__ uint32_t pp_t28(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
 #define PP_FBINS 1024
+#define PP_SMP 128                             // MODE 1: sample keys (bin boundaries) of a sub-bucket's finish
 
 // MODE 1: number of grid keys sp[1..511] not above the key (sp[0] counts as below every key): 9 steps, no branches
 __device__ __forceinline__ uint32_t pp_rank511(const uint64_t *sp, uint64_t key)
@@ -280,36 +281,22 @@ __global__ void k_pp_widen(const uint32_t *__restrict__ count2, unsigned long lo
 template <int CAP, int MODE>
 __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t *loff, uint32_t *wsum,
                                                const uint64_t *wa, const uint32_t *va, uint32_t n_a, const uint64_t *wb,
-                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint32_t sb)
+                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint64_t *smp, uint64_t *srt)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
-    // MODE 1: the keys of sub-bucket sb lie in [G[sb], G[sb + 1]): they share the symbols the two grid keys share, and
-    // the bin is what follows, read as a number in base sigma (the codes are the ranks of the symbols that occur, so
-    // that number is dense where the key bits are not: 4 frequent letters in 3-bit codes fill a sixteenth of a linear
-    // map's bins after four symbols) -- first the symbol where the grid keys part, as an offset, then as many more
-    // symbols as 1024 bins hold.  Lexicographic in the symbols, hence monotone in the key; the cap keeps it so.
-    int s_shift = 0, s_more = 0;                           // bit position of the parting symbol; symbols after it
-    uint32_t s_first = 0;
-    if (MODE == 1) {
-        const uint64_t klo = sb ? a.grid[sb] : 0ull;
-        const uint64_t khi = sb + 1 < (uint32_t)(PP_NB * PP_NB) ? a.grid[sb + 1] : a.top - 1;
-        const int kb = a.b * a.K;
-        const uint64_t d = klo ^ khi;
-        const int same = d ? (__clzll((long long)d) - (64 - kb)) / a.b : a.K - 1;      // leading symbols in common
-        const int c = same < a.K ? same : a.K - 1;
-        s_shift = a.b * (a.K - 1 - c);
-        const uint32_t smask = (1u << a.b) - 1;
-        s_first = (uint32_t)(klo >> s_shift) & smask;
-        uint32_t room = PP_FBINS / (((uint32_t)(khi >> s_shift) & smask) - s_first + 1);
-        while (s_more < a.K - 1 - c && room >= (uint32_t)a.sigma) { room /= (uint32_t)a.sigma; s_more++; }
-    }
+    // MODE 1: the keys of a sub-bucket follow no formula (they cluster at the two ends of its key range, deep below the
+    // symbols its grid keys share), so the bins come from the sub-bucket itself: PP_SMP of its keys, sorted, are the bin
+    // boundaries (the slots arrive in no particular order: every (have / PP_SMP)-th is a fair sample) and a slot's bin
+    // is the number of boundaries not above its key (binary search in LDS).  The loads happen below; the sample is
+    // taken from a staged copy of the keys in sw.
     auto bin_of = [&](uint64_t word) -> uint32_t {
         if (MODE == 1) {
             const uint64_t key = word >> a.pb;
-            const uint32_t smask = (1u << a.b) - 1;
-            uint32_t v = ((uint32_t)(key >> s_shift) & smask) - s_first;
-            for (int q = 1; q <= s_more; q++) v = v * (uint32_t)a.sigma + ((uint32_t)(key >> (s_shift - q * a.b)) & smask);
-            return min((uint32_t)(PP_FBINS - 1), v);
+            uint32_t at = 0;
+#pragma unroll
+            for (uint32_t step = PP_SMP / 2; step >= 1; step >>= 1)
+                if (srt[at + step - 1] <= key) at += step;
+            return at + (srt[at] <= key ? 1u : 0u);            // 0 .. PP_SMP
         }
         return pp_t28(a, word) & (PP_FBINS - 1);
     };
@@ -323,6 +310,24 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         w[r] = j < have ? (j < n_a ? wa[j] : wb[j - n_a]) : ~0ull;
         v[r] = (j < have && !a.packed) ? (j < n_a ? va[j] : vb[j - n_a]) : 0u;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * PP_THREADS;
+            if (j < have) sw[j] = w[r];
+        }
+        __syncthreads();
+        const uint32_t ns = min((uint32_t)PP_SMP, have);
+        if (threadIdx.x < PP_SMP) smp[threadIdx.x] = threadIdx.x < ns ? sw[(uint64_t)threadIdx.x * have / ns] >> a.pb : ~0ull;
+        __syncthreads();
+        if (threadIdx.x < PP_SMP) {                             // rank of every sample key among the sample: its place
+            const uint64_t mine = smp[threadIdx.x];
+            uint32_t place = 0;
+            for (uint32_t u = 0; u < PP_SMP; u++) { const uint64_t o = smp[u]; place += (o < mine || (o == mine && u < threadIdx.x)) ? 1u : 0u; }
+            srt[place] = mine;
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -389,8 +394,10 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(Pp
     if (have == 0 || have > PP_FN_CAP) return;                 // the larger ones: k_pp_finish_big
     const uint64_t *wa = a.w2 + (uint64_t)blockIdx.x * PP_FN_CAP;
     const uint32_t *va = a.v2 + (uint64_t)blockIdx.x * PP_FN_CAP;
+    __shared__ uint64_t smp[MODE == 1 ? PP_SMP : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
+    if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
     pp_finish_body<PP_FN_CAP, MODE>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[blockIdx.x], a.vout + a.off[blockIdx.x],
-                                    blockIdx.x);
+                                    smp, srt);
 }
 
 template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
@@ -408,8 +415,10 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_bi
     if (e > 0 && sb_sorted[e - 1] == sb) return;
     const uint32_t have = a.count2[sb];
     if (have > PP_BIG_CAP || have <= PP_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
+    __shared__ uint64_t smp[MODE == 1 ? PP_SMP : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
+    if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
     pp_finish_body<PP_BIG_CAP, MODE>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
-                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], sb);
+                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt);
 }
 
 __global__ void k_pp_gather(const uint32_t *__restrict__ idx_sorted, const uint64_t *__restrict__ aw, const uint32_t *__restrict__ av,
