@@ -54,7 +54,7 @@ struct PpArgs {
 // t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
 __device__ __forceinline__ uint32_t pp_t28(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
 #define PP_FBINS 1024
-#define PP_SMP 128                             // MODE 1: sample keys (bin boundaries) of a sub-bucket's finish
+#define PP_SMP 127                             // MODE 1: sample keys (bin boundaries) of a sub-bucket's finish: 128 stretches x 8 bins
 
 // MODE 1: number of grid keys sp[1..511] not above the key (sp[0] counts as below every key): 9 steps, no branches
 __device__ __forceinline__ uint32_t pp_rank511(const uint64_t *sp, uint64_t key)
@@ -281,7 +281,8 @@ __global__ void k_pp_widen(const uint32_t *__restrict__ count2, unsigned long lo
 template <int CAP, int MODE>
 __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t *loff, uint32_t *wsum,
                                                const uint64_t *wa, const uint32_t *va, uint32_t n_a, const uint64_t *wb,
-                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint64_t *smp, uint64_t *srt)
+                                               const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint64_t *smp, uint64_t *srt,
+                                               uint32_t *place)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
     // MODE 1: the keys of a sub-bucket follow no formula (they cluster at the two ends of its key range, deep below the
@@ -291,12 +292,20 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     // taken from a staged copy of the keys in sw.
     auto bin_of = [&](uint64_t word) -> uint32_t {
         if (MODE == 1) {
+            // PP_SMP boundaries -> PP_SMP + 1 stretches; a stretch between two boundaries is cut into 8 more bins
+            // linearly in the key (float arithmetic: monotone), which thins the bins out wherever the keys of the
+            // stretch do not sit at one end of it
             const uint64_t key = word >> a.pb;
             uint32_t at = 0;
 #pragma unroll
-            for (uint32_t step = PP_SMP / 2; step >= 1; step >>= 1)
-                if (srt[at + step - 1] <= key) at += step;
-            return at + (srt[at] <= key ? 1u : 0u);            // 0 .. PP_SMP
+            for (uint32_t step = (PP_SMP + 1) / 2; step >= 1; step >>= 1)
+                if (srt[at + step - 1] <= key) at += step;         // boundaries not above the key: 0 .. PP_SMP
+            uint32_t fine = 0;
+            if (at > 0 && at < PP_SMP) {
+                const uint64_t lo = srt[at - 1], hi = srt[at];
+                fine = min(7u, (uint32_t)((float)(key - lo) * (8.0f / (float)(hi - lo))));
+            }
+            return at * 8 + fine;
         }
         return pp_t28(a, word) & (PP_FBINS - 1);
     };
@@ -320,13 +329,19 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         __syncthreads();
         const uint32_t ns = min((uint32_t)PP_SMP, have);
         if (threadIdx.x < PP_SMP) smp[threadIdx.x] = threadIdx.x < ns ? sw[(uint64_t)threadIdx.x * have / ns] >> a.pb : ~0ull;
+        if (threadIdx.x < PP_SMP) place[threadIdx.x] = 0;
         __syncthreads();
-        if (threadIdx.x < PP_SMP) {                             // rank of every sample key among the sample: its place
-            const uint64_t mine = smp[threadIdx.x];
-            uint32_t place = 0;
-            for (uint32_t u = 0; u < PP_SMP; u++) { const uint64_t o = smp[u]; place += (o < mine || (o == mine && u < threadIdx.x)) ? 1u : 0u; }
-            srt[place] = mine;
+        {   // rank of every sample key among the sample = its place; four threads share a key's comparisons
+            const uint32_t t = threadIdx.x >> 2, part = threadIdx.x & 3;
+            if (t < PP_SMP) {
+                const uint64_t mine = smp[t];
+                uint32_t c = 0;
+                for (uint32_t u = part; u < PP_SMP; u += 4) { const uint64_t o = smp[u]; c += (o < mine || (o == mine && u < t)) ? 1u : 0u; }
+                if (c) atomicAdd(&place[t], c);
+            }
         }
+        __syncthreads();
+        if (threadIdx.x < PP_SMP) srt[place[threadIdx.x]] = smp[threadIdx.x];
         __syncthreads();
     }
 #pragma unroll
@@ -365,7 +380,9 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
             uint32_t smaller = 0;
             for (uint32_t q = 0; q < c; q++) {
                 const uint64_t x = sw[b0 + q];
-                smaller += (x < w[r] || (x == w[r] && sv[b0 + q] < v[r])) ? 1u : 0u;
+                bool less = x < w[r];
+                if (x == w[r]) less = sv[b0 + q] < v[r];           // equal keys are rare: the second array is seldom read
+                smaller += less ? 1u : 0u;
             }
             rk[r] = b0 + smaller;
         }
@@ -394,10 +411,11 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(Pp
     if (have == 0 || have > PP_FN_CAP) return;                 // the larger ones: k_pp_finish_big
     const uint64_t *wa = a.w2 + (uint64_t)blockIdx.x * PP_FN_CAP;
     const uint32_t *va = a.v2 + (uint64_t)blockIdx.x * PP_FN_CAP;
-    __shared__ uint64_t smp[MODE == 1 ? PP_SMP : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
+    __shared__ uint64_t smp[MODE == 1 ? PP_SMP + 1 : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
+    __shared__ uint32_t place[MODE == 1 ? PP_SMP + 1 : 1];
     if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
     pp_finish_body<PP_FN_CAP, MODE>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[blockIdx.x], a.vout + a.off[blockIdx.x],
-                                    smp, srt);
+                                    smp, srt, place);
 }
 
 template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
@@ -415,10 +433,11 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_bi
     if (e > 0 && sb_sorted[e - 1] == sb) return;
     const uint32_t have = a.count2[sb];
     if (have > PP_BIG_CAP || have <= PP_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
-    __shared__ uint64_t smp[MODE == 1 ? PP_SMP : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
+    __shared__ uint64_t smp[MODE == 1 ? PP_SMP + 1 : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
+    __shared__ uint32_t place[MODE == 1 ? PP_SMP + 1 : 1];
     if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
     pp_finish_body<PP_BIG_CAP, MODE>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
-                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt);
+                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place);
 }
 
 __global__ void k_pp_gather(const uint32_t *__restrict__ idx_sorted, const uint64_t *__restrict__ aw, const uint32_t *__restrict__ av,
