@@ -254,6 +254,7 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
         uint32_t upd_g[RS_ITEMS], upd_c[RS_ITEMS];
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) { upd_g[r] = 0; upd_c[r] = 0; }
+        uint32_t slow4 = 0, tie4 = 0, cand4 = 0;
         uint32_t lcp[RS_ITEMS + 1];                                    // key LCP of slots my_i + r - 1 and my_i + r (K for equal keys)
 #pragma unroll
         for (int r = 0; r <= RS_ITEMS; r++) lcp[r] = PLAIN ? rs_key_lcp(kk[r + 2], kk[r + 3], a.b, a.key_bits) : 0u;
@@ -261,7 +262,6 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
         for (int r = 0; r < RS_ITEMS; r++) {
             // slot i with keys K[-3..3] = kk[r .. r+6] and columns C[-2..2] = cc[r .. r+4]
             const int i = my_i + r;
-            const uint64_t k = base + (uint64_t)(i - RS_HALO);
             const bool in = i < hi_i;
             const bool window = i - 3 >= lo_i && i + 3 < hi_i;         // all of it inside the owned range
             const uint64_t key = kk[r + 3];
@@ -300,18 +300,38 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
                     else { want_cand = true; want_cand2 = true; }
                 } else if (!(eqp && !eqn && kk[r + 1] != key && i - 4 >= lo_i)) slow = true;    // not the tail of a pair settled by its head
             }
-            const unsigned long long smask = __ballot(slow);
-            if (smask) {
-                uint32_t qb = 0;
-                const int leader = __ffsll((long long)smask) - 1;
-                if (lane == leader) qb = atomicAdd(&sqn, (uint32_t)__popcll(smask));
-                qb = __shfl(qb, leader, 64);
-                if (slow) sq[qb + (uint32_t)__popcll(smask & ((1ull << lane) - 1))] = (uint16_t)i;
+            // what the slot asks for is only noted here: one bit per slot of the thread and kind
+            slow4 |= (slow ? 1u : 0u) << r;
+            tie4 |= (want_tie ? 1u : 0u) << r;
+            cand4 |= ((want_cand ? 1u : 0u) << r) | ((want_cand2 ? 16u : 0u) << r);
+        }
+        // The appends, once per chunk instead of once per slot row: a round takes one noted slot of every thread that
+        // still has one (most threads have none, few have two of a kind), so the wave-wide ballots and the branches
+        // around them -- scalar work that rivalled the vector work of this kernel -- shrink to one or two rounds per kind.
+        for (uint32_t bits = slow4; __ballot(bits != 0);) {
+            const bool on = bits != 0;
+            const int rr = on ? __ffs((int)bits) - 1 : 0;
+            bits &= bits - 1;
+            const unsigned long long smask = __ballot(on);
+            uint32_t qb = 0;
+            const int leader = __ffsll((long long)smask) - 1;
+            if (lane == leader) qb = atomicAdd(&sqn, (uint32_t)__popcll(smask));
+            qb = __shfl(qb, leader, 64);
+            if (on) sq[qb + (uint32_t)__popcll(smask & ((1ull << lane) - 1))] = (uint16_t)(my_i + rr);
+        }
+        if (!a.values_only) {
+            const uint32_t k_first = (uint32_t)(base + (uint64_t)(my_i - RS_HALO));      // slot of the thread's first item
+            for (uint32_t bits = tie4; __ballot(bits != 0);) {
+                const bool on = bits != 0;
+                const int rr = on ? __ffs((int)bits) - 1 : 0;
+                bits &= bits - 1;
+                rs_append(on, &s_tie_n, a.ties, a.tie_region, k_first + (uint32_t)rr);
             }
-            if (!a.values_only) {
-                rs_append(want_cand, &s_cand_n, a.cand, a.region, (uint32_t)k);
-                rs_append(want_cand2, &s_cand_n, a.cand, a.region, (uint32_t)k + 1);
-                rs_append(want_tie, &s_tie_n, a.ties, a.tie_region, (uint32_t)k);
+            for (uint32_t bits = cand4; __ballot(bits != 0);) {                          // bits 4..7: the slot after (the tail of a pair)
+                const bool on = bits != 0;
+                const int rr = on ? __ffs((int)bits) - 1 : 0;
+                bits &= bits - 1;
+                rs_append(on, &s_cand_n, a.cand, a.region, k_first + (uint32_t)(rr & 3) + (uint32_t)(rr >> 2));
             }
         }
         // column maxima: the table reads of the thread's slots go out together (g = 0: nothing to do) and are
