@@ -216,15 +216,19 @@ def other_workloads(F, torch, dev):
 
 def measured_traffic(m, n, kernel):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected as
-    MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled on gfx950; cross-check in the JSON); None when no pass exists for this workload / kernel."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_kernels.json")) as fh:
-            d = json.load(fh)
-        if d["workload"] == {"rows": m, "cols": n}:
-            return d["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled on gfx950); None when no pass
+    exists for this workload / kernel."""
+    for name in ("r02_pmc_kernels.json", "r01_pmc_scan_kernels.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                d = json.load(fh)
+            if d["workload"] == {"rows": m, "cols": n}:
+                for k, v in d["kernels"].items():
+                    if k.startswith(kernel) and "hbm_bytes_per_launch" in v:
+                        return v["hbm_bytes_per_launch"], f"profiles/{name}"
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -426,6 +430,7 @@ def main():
             scan_cols, scan_rows = n, rows_pair
             mode_used = f"row-group pairs (G={G}, {len(D.group_pairs(G))} pairs), all-reduce(max)"
         scan_bytes = (13 * scan_rows + 8) * scan_cols
+        traffic, traffic_src = measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
             "metric": "MSA columns segmented/sec", "value": n * args.steps / dt, "unit": "columns/s",
@@ -437,10 +442,9 @@ def main():
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
             "roofline": {"bound": "hbm", "kernel": "k_rank_scan" if ranked else "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
-                         if world == 1 else None,
-                         "traffic_source": "profiles/r01_pmc_scan_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                           "passes, FETCH_SIZE doubled as the guide prescribes for gfx950: equals one read of every slot)",
+                         "traffic": traffic if world == 1 else None,
+                         "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled "
+                                            "as the guide prescribes for gfx950: equals one read of every slot)") if traffic_src else None,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "sweep": ("serial" if sweeper is None else
