@@ -224,7 +224,7 @@ def measured_traffic(m, n, kernel):
                 d = json.load(fh)
             if d["workload"] == {"rows": m, "cols": n}:
                 for k, v in d["kernels"].items():
-                    if k.startswith(kernel) and "hbm_bytes_per_launch" in v:
+                    if (k == kernel or k.startswith(kernel + "<")) and "hbm_bytes_per_launch" in v:
                         return v["hbm_bytes_per_launch"], f"profiles/{name}"
         except Exception:
             continue
@@ -420,7 +420,10 @@ def main():
         # the extension scan is k_rank_scan (rank order, inside the index build) for gap-free MSAs,
         # k_scan_stream (text order) otherwise; one launch per step either way
         ranked = stage_acc.get("rank_kernel", [0.0, 0])[1] > 0
-        scan_ms = (stage_acc["rank_kernel"][0] if ranked else stage_acc["scan"][0]) / max(1, args.steps)
+        scan_total_ms, scan_launches = stage_acc["rank_kernel"] if ranked else stage_acc["scan"]
+        scan_launches = max(1, scan_launches if ranked else args.steps)      # a large rank-order scan goes out in pieces (rank_scan.hip)
+        scan_ms = scan_total_ms / scan_launches                             # average duration of ONE launch of the kernel
+        launches_per_step = scan_launches / max(1, args.steps)
         if state["path"] == "partitioned":
             scan_cols, scan_rows, mode_used = x1 - x0, m, "key-range partitioned index, all-reduce(max) of the column maxima"
         elif state["path"] == "replicated":
@@ -429,7 +432,7 @@ def main():
             G, _, _, rows_pair, _ = bufs["plan"]
             scan_cols, scan_rows = n, rows_pair
             mode_used = f"row-group pairs (G={G}, {len(D.group_pairs(G))} pairs), all-reduce(max)"
-        scan_bytes = (13 * scan_rows + 8) * scan_cols
+        scan_bytes = (13 * scan_rows + 8) * scan_cols / launches_per_step    # algorithmic bytes one launch covers
         traffic, traffic_src = measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
@@ -445,7 +448,7 @@ def main():
                          "traffic": traffic if world == 1 else None,
                          "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled "
                                             "as the guide prescribes for gfx950: equals one read of every slot)") if traffic_src else None,
-                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms},
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches_per_step": launches_per_step},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "sweep": ("serial" if sweeper is None else
                       {"overlapped_with": "the next step's index build (own context and stream on rank 0)",
