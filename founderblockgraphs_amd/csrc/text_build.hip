@@ -57,8 +57,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
                                                           uint32_t *__restrict__ tot,
                                                           unsigned long long *__restrict__ scalars,
                                                           unsigned long long *__restrict__ hist,
-                                                          uint32_t *__restrict__ segcnt)
+                                                          uint32_t *__restrict__ segcnt, uint8_t *__restrict__ T_copy)
 {
+    // T_copy (optional; only when every row takes the 8-byte path: n and the MSA's address multiples of 8): the text of a
+    // gap-free MSA -- row i at T + i * (n + 1), a '#' behind it -- is written along the way, from the very words the
+    // counting loads (8-byte stores at addresses shifted by i bytes: the hardware takes them unaligned).  Should the MSA
+    // turn out to have gaps the caller writes the text again, properly (k_write_text).
+    typedef uint64_t u64_unaligned __attribute__((aligned(1)));
     __shared__ uint32_t red[2][TB_THREADS / 64];
     __shared__ uint32_t sh[256];
     const uint64_t i = blockIdx.y;
@@ -112,6 +117,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
             for (int u = 0; u < RC_UNROLL; u++) {
                 const uint64_t qq = q + (uint64_t)u * TB_THREADS;
                 wv[u] = qq < nwords ? words[qq] : 0ull;
+            }
+            if (T_copy) {
+#pragma unroll
+                for (int u = 0; u < RC_UNROLL; u++) {
+                    const uint64_t qq = q + (uint64_t)u * TB_THREADS;
+                    if (qq < nwords) *reinterpret_cast<u64_unaligned *>(T_copy + i * (n + 1) + x_lo + 8 * qq) = wv[u];
+                }
             }
 #pragma unroll
             for (int u = 0; u < RC_UNROLL; u++) {
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
     if (lane == 0) { red[0][threadIdx.x >> 6] = nongap; red[1][threadIdx.x >> 6] = ign; }
     __syncthreads();
     if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+    if (T_copy && threadIdx.x == 1 && x_hi == n) T_copy[i * (n + 1) + n] = '#';
     if (threadIdx.x == 0) {
         uint32_t a = 0, b = 0;
         for (int k = 0; k < TB_THREADS / 64; k++) { a += red[0][k]; b += red[1][k]; }
@@ -401,8 +414,12 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     FBG_TRY(fbg_reserve(ctx, ctx->segtab, (size_t)m * nseg * 4 * 3));   // per (row, segment): non-gap cells, their prefix, first ignore column
     uint32_t *segcnt = ctx->segtab.as<uint32_t>(), *segoff = segcnt + (size_t)m * nseg, *segmin = segoff + (size_t)m * nseg;
     // (the kernel can count the ignore cells too; nobody asks for that number, and without it rows take the word-wide path)
+    // Optimistic text: most MSAs that come this way have no gaps, and then the text is the MSA with a '#' per row --
+    // written by the counting pass itself from the words it loads (one read of the MSA instead of two)
+    const bool fused = !ctx->reversed && n % 8 == 0 && ((uintptr_t)ctx->d_msa & 7) == 0 && m * (n + 1) + 1 < (1ull << 40);
+    if (fused) FBG_TRY(fbg_reserve(ctx, ctx->text, m * (n + 1) + 1 + 64));
     hipLaunchKernelGGL(k_row_count, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
-                       n, (const uint8_t *)nullptr, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt);
+                       n, (const uint8_t *)nullptr, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt, fused ? ctx->text.as<uint8_t>() : (uint8_t *)nullptr);
     hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(64), 0, st, ctx->tot.as<uint32_t>(), m,
                        ctx->pos.as<uint32_t>(), sc);
     launches += 2;
@@ -441,7 +458,7 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     } else if (ctx->reversed) {
         hipLaunchKernelGGL((k_write_text<false, true>), dim3(1, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
                            pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);
-    } else {
+    } else if (!fused) {
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + CR_SEG - 1) / CR_SEG), (unsigned)m), dim3(TB_THREADS), 0, st,
                            ctx->d_msa, n, m, T);
     }
