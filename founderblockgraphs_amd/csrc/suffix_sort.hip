@@ -434,13 +434,31 @@ __global__ __launch_bounds__(BP_THREADS) void k_bp_groups0(BpArgs a)
         key[r] = in ? a.keys[k] : 0ull;
     }
     uint2 sp[BP_ITEMS];
-#pragma unroll
-    for (int r = 0; r < BP_ITEMS; r++) {
+    if (bounded) {
         // the run hints need the column spans of SA neighbours.  With gaps a span costs two reads of colT at a random
-        // place: bounds from the window tables (small enough to stay in L2) rule nearly every pair out first
-        sp[r] = bounded ? bp_span_bound(a, pp[r]) : a.ct.span(pp[r]);
-        buf[threadIdx.x + r * BP_THREADS] = make_uint4((uint32_t)key[r], (uint32_t)(key[r] >> 32), sp[r].x, sp[r].y);
+        // place: bounds from the window tables (small enough to stay in L2) rule nearly every pair out first.  The
+        // table reads of the thread's eight slots go out together -- one after the other (the branches of
+        // bp_span_bound between them) this kernel spent 88 % of its wave cycles waiting for them
+        uint2 wv[BP_ITEMS];
+        uint32_t wl[BP_ITEMS];
+#pragma unroll
+        for (int r = 0; r < BP_ITEMS; r++) wv[r] = a.win[pp[r] >> BP_WIN_BITS];
+#pragma unroll
+        for (int r = 0; r < BP_ITEMS; r++) wl[r] = (pp[r] & (BP_WIN - 1)) ? 0u : a.win_lo[pp[r] >> BP_WIN_BITS];
+#pragma unroll
+        for (int r = 0; r < BP_ITEMS; r++) {
+            const uint32_t p = pp[r], o = p & (BP_WIN - 1);
+            if (p == a.ct.last) sp[r] = make_uint2(1u, 0u);
+            else if (wv[r].x == BP_WIN_NONE) sp[r] = make_uint2(0u, a.ct.n);
+            else sp[r] = make_uint2(o ? wv[r].x + o : wl[r], wv[r].x + o + wv[r].y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < BP_ITEMS; r++) sp[r] = a.ct.span(pp[r]);
     }
+#pragma unroll
+    for (int r = 0; r < BP_ITEMS; r++)
+        buf[threadIdx.x + r * BP_THREADS] = make_uint4((uint32_t)key[r], (uint32_t)(key[r] >> 32), sp[r].x, sp[r].y);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < BP_ITEMS; r++) {
