@@ -162,7 +162,7 @@ static const OptKey g_opt_keys[] = {
     {"bp_min", &FbgOptions::bp_min}, {"record_scatter", &FbgOptions::record_scatter}, {"lcp_text", &FbgOptions::lcp_text},
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
-    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan},
+    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank},
 };
 
 // The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of
@@ -194,6 +194,12 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (!ctx || !key || !value) return FBG_ERR_INVALID;
     for (const OptKey &k : g_opt_keys)
         if (strcmp(k.name, key) == 0) { *value = ctx->opt.*(k.field); return FBG_OK; }
+    if (strcmp(key, "grs_threshold") == 0) { *value = ctx->grs_t; return FBG_OK; }
+    if (strcmp(key, "grs_redone") == 0) { *value = (int64_t)ctx->grs_redone; return FBG_OK; }
+    if (strcmp(key, "index_kind") == 0) {      // read-only: which form the current index has
+        *value = !ctx->index_valid ? -1 : ctx->part_active ? 3 : ctx->granked ? 2 : ctx->ranked ? 1 : 0;
+        return FBG_OK;
+    }
     return FBG_ERR_INVALID;
 }
 
@@ -242,7 +248,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
                       &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->msd_w, &ctx->msd_v, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d,
-                      &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h};
+                      &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h, &ctx->gwin, &ctx->gbits};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     for (auto &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
@@ -300,7 +306,7 @@ int fbg_release_scratch(fbg_ctx *ctx)
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // valsB stays: it is the suffix array; so does whichever key buffer holds the sorted slots of a rank-order index
-    const bool sorted_in_A = ctx->ranked && ctx->rk_keys == ctx->keysA.as<uint64_t>();
+    const bool sorted_in_A = (ctx->ranked || ctx->granked) && ctx->rk_keys == ctx->keysA.as<uint64_t>();
     DevBuf *bufs[] = {sorted_in_A ? &ctx->keysB : &ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list, &ctx->msd_w, &ctx->msd_v,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d, &ctx->ps_e, &ctx->ps_f,
@@ -353,6 +359,7 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     if (!ctx->d_msa) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_build: no MSA set");
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->index_valid = false;
+    ctx->granked = false;
     ctx->reversed = reversed ? 1 : 0;
     FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
     FBG_TRY(fbg_suffix_sort(ctx));
@@ -371,6 +378,7 @@ int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void 
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->index_valid = false;
     ctx->ranked = false;
+    ctx->granked = false;
     ctx->reversed = reversed ? 1 : 0;
     ctx->allow_wide = true;                        // the partitions together may hold a text of 2^32 symbols and more
     const int rc = fbg_build_text(ctx, nullptr, 0);
@@ -625,15 +633,18 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     // test / debugging API: plain blocking copies
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (text) FBG_HIP_TRY(ctx, hipMemcpy(text, ctx->text.p, N, hipMemcpyDeviceToHost));
-    if (sa && !ctx->ranked) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost));
-    if ((sa || isa || lcp_prev || lcp_next) && ctx->ranked) {
+    if (sa && !ctx->ranked && !ctx->granked) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->sa_ptr, N * 4, hipMemcpyDeviceToHost));
+    if ((sa || isa || lcp_prev || lcp_next) && (ctx->ranked || ctx->granked)) {
         // rank-order index: no per-position records exist; derive the arrays from the sorted keys once
         FBG_TRY(fbg_reserve(ctx, ctx->io_a, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_b, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_c, N * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->io_d, N * 4));
-        FBG_TRY(fbg_rank_materialize(ctx, ctx->io_d.as<uint32_t>(), ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(),
-                                     ctx->io_c.as<uint32_t>()));
+        if (ctx->granked)
+            FBG_TRY(fbg_grs_materialize(ctx, ctx->io_d.as<uint32_t>(), ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>()));
+        else
+            FBG_TRY(fbg_rank_materialize(ctx, ctx->io_d.as<uint32_t>(), ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(),
+                                         ctx->io_c.as<uint32_t>()));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (sa) FBG_HIP_TRY(ctx, hipMemcpy(sa, ctx->io_d.p, N * 4, hipMemcpyDeviceToHost));
         if (isa) FBG_HIP_TRY(ctx, hipMemcpy(isa, ctx->io_a.p, N * 4, hipMemcpyDeviceToHost));

@@ -37,7 +37,7 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0, pure_scan = 0;
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0;
 };
 
 struct fbg_ctx {
@@ -84,6 +84,19 @@ struct fbg_ctx {
     DevBuf exc_scratch;        // per-workgroup column state of k_scan_exceptions_big (MSAs of more than 4096 rows)
     DevBuf exc;                // uint4[n_exc * m]: (rank, lcp_prev, lcp_next) of the rows of the exception columns
     uint32_t n_exc = 0;
+    // rank-order scan of MSAs with gaps / ignore characters (gapped_rank.hip): valid when `granked`
+    bool granked = false;
+    int grs_tricks_off = 0;        // the setting of the elastic tricks gmax was computed for
+    bool grs_skip = false;         // rebuilding the record way after the scan ran out of room
+    uint32_t grs_ign_lo = 0, grs_ign_hi = 0;
+    DevBuf gwin;                   // 16 bytes per 128 text positions: column, row, gap runs
+    DevBuf gbits;                  // 1 bit per text position: not the column after its predecessor's
+    const uint64_t *grs_ebits = nullptr;   // gbits while the pack kernels are to fold it into bit 31 of the sort's values
+    bool grs_flagged = false;      // the sorted values carry that bit
+    uint32_t grs_t = 1;            // the threshold of the last scan (1: none), the columns it redid exactly
+    uint64_t grs_redone = 0;
+    bool cells_built = false;      // prow / igrow hold the current MSA (built on demand: only the record path reads them)
+    uint8_t ignore_tab[256] = {0};
     uint64_t *rk_keys = nullptr; // sorted slots: keys (pairs layout, positions in sa_ptr) or key << rk_pb | position (packed)
     int rk_b = 0, rk_key_bits = 0, rk_K = 0;
     int rk_layout = 0, rk_pb = 0;   // FBG_SLOTS_*
@@ -152,6 +165,12 @@ int fbg_pure_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
 int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disable_tricks, uint64_t *d_out);
 int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
 #define FBG_STAGE_RANKSCAN FBG_STAGE_TILE
+int fbg_grs_prepare(fbg_ctx *ctx, int *launches);
+int fbg_grs_strip(fbg_ctx *ctx, uint32_t *vals);
+int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);             // gapped_rank.hip
+int fbg_grs_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_out, int *ok);
+int fbg_grs_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
+int fbg_build_cell_tables(fbg_ctx *ctx);                                                                // text_build.hip
 int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches);                                // suffix_sort.hip
 int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int pre_ok,
                            uint8_t *d_blob, int *ok);                         // rank_scan.hip

@@ -79,7 +79,7 @@ int fbg_neighbour_lcp(fbg_ctx *ctx)
     const uint64_t N = ctx->N;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_LCP));
     int launches = 0;
-    if (!ctx->lcp_from_keys && !ctx->ranked) {
+    if (!ctx->lcp_from_keys && !ctx->ranked && !ctx->granked) {
         HintArgs ha;
         ha.colT = ctx->gapfree ? nullptr : ctx->colT.as<uint32_t>();
         ha.n = ctx->n; ha.N = N; ha.row_len = (uint32_t)(ctx->n + 1);

@@ -49,6 +49,7 @@ struct PpArgs {
     const uint64_t *grid;                      // MODE 1: G[PP_NB * PP_NB] quantiles of the key sample (G[0] is not used: below every key)
     uint64_t top;                              // MODE 1: 2^key_bits, the end of the last sub-bucket's key range
     int sigma;                                 // MODE 1: number of symbol codes in use (codes are 0 .. sigma - 1)
+    const uint64_t *ebits;                     // pairs: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
 };
 
 // t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
@@ -156,13 +157,21 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
         uint32_t at = 0;
         if (lane == 63 && inc) at = atomicAdd(&staged, inc);
         at = __shfl(at, 63, 64) + inc - mine;
+        uint64_t eb = 0;                                        // the irregular-position bits of [p0, p0 + 64), p0 the thread's first position
+        if (a.ebits) {
+            const uint64_t p0 = base + (uint64_t)threadIdx.x * MSD_ITEMS;
+            const uint64_t *e = a.ebits + (p0 >> 6);
+            const unsigned sh = (unsigned)(p0 & 63);
+            eb = e[0] >> sh;
+            if (sh) eb |= e[1] << (64 - sh);
+        }
 #pragma unroll
         for (int i = 0; i < MSD_ITEMS; i++) {
             if ((km >> i) & 1u) {
                 const uint64_t p = base + (uint64_t)threadIdx.x * MSD_ITEMS + i;
                 if (at < PP_STAGE) {
                     sw[at] = a.packed ? (key[i] << a.pb) | p : a.wide ? (key[i] << a.pb) | (p >> 32) : key[i];
-                    sv[at] = a.packed ? 0u : (uint32_t)p;
+                    sv[at] = a.packed ? 0u : (uint32_t)p | (((eb >> i) & ((1ull << a.K) - 1)) ? 0x80000000u : 0u);
                 } else *a.flag = 1;
                 at++;
             }
@@ -475,6 +484,7 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
     unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;      // [0] flag, [1] arena count, [2] total
     a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = (g.wide || g.packed) ? g.pb : 0; a.nparts = nparts;
     a.wide = g.wide ? 1 : 0; a.packed = g.packed ? 1 : 0;
+    a.ebits = (MODE == 1 && !g.wide && !g.packed && g.K <= 32) ? ctx->grs_ebits : nullptr;
     a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
     a.count1 = ctx->dp_a.as<unsigned long long>();
     uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + PP_NB * 8);

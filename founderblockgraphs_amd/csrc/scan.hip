@@ -358,7 +358,21 @@ int fbg_scan_columns(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disab
 {
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SCAN));
     int launches = 0;
-    if (x1 > x0 && ctx->ranked) {
+    if (x1 > x0 && ctx->granked) {
+        int ok = 0;
+        FBG_TRY(fbg_grs_finish(ctx, x0, x1, disable_tricks, d_out, &ok));
+        launches++;
+        if (!ok) {
+            // the scan for this setting of the tricks ran out of room: the index again, the record way
+            ctx->grs_skip = true;
+            int rc = fbg_suffix_sort(ctx);
+            ctx->grs_skip = false;
+            FBG_TRY(rc);
+            FBG_TRY(fbg_neighbour_lcp(ctx));
+        }
+    }
+    if (x1 > x0 && ctx->granked) {
+    } else if (x1 > x0 && ctx->ranked) {
         // rank-order index: column maxima are ready, only the exception columns need the per-column kernel
         FBG_TRY(fbg_rank_finish(ctx, x0, x1, mode, disable_tricks, d_out));
         launches++;

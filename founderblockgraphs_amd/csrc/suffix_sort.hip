@@ -57,7 +57,18 @@ struct PackArgs {
     uint64_t lo, hi, cap;      // FILTER
     int nohi;
     unsigned long long *counter;
+    const uint64_t *ebits = nullptr;   // PAIRS: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
 };
+
+// any irregular position among [p, p + K)?  (K <= 32; the bitmap is padded beyond the text)
+__device__ __forceinline__ uint32_t pack_flag(const uint64_t *__restrict__ ebits, uint64_t p, int K)
+{
+    const uint64_t *e = ebits + (p >> 6);
+    const unsigned sh = (unsigned)(p & 63);
+    uint64_t bits = e[0] >> sh;
+    if (sh) bits |= e[1] << (64 - sh);
+    return (bits & ((1ull << K) - 1)) ? 0x80000000u : 0u;
+}
 
 template <bool COMPACT, int LAYOUT, bool FILTER>
 __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
             if (p < a.N) {
                 if (LAYOUT == FBG_SLOTS_PACKED) a.keys[p] = (skeys[j] << a.pb) | p;
                 else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[p] = (skeys[j] << a.pb) | (p >> 32); a.vals[p] = (uint32_t)p; }
-                else { a.keys[p] = skeys[j]; a.vals[p] = (uint32_t)p; }
+                else { a.keys[p] = skeys[j]; a.vals[p] = (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
             }
         }
         return;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
                 const uint64_t p = base + j;
                 if (LAYOUT == FBG_SLOTS_PACKED) a.keys[o] = (skeys[j] << a.pb) | p;
                 else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[o] = (skeys[j] << a.pb) | (p >> 32); a.vals[o] = (uint32_t)p; }
-                else { a.keys[o] = skeys[j]; a.vals[o] = (uint32_t)p; }
+                else { a.keys[o] = skeys[j]; a.vals[o] = (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
             }
         }
         off += (uint64_t)__popcll(keep[i]);
@@ -817,6 +828,9 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     const uint8_t *T = ctx->text.as<uint8_t>();
     ctx->part_active = false;
     ctx->ranked = false;
+    ctx->granked = false;
+    ctx->grs_ebits = nullptr;
+    ctx->grs_flagged = false;
     KeyGeom g;
 
     // ---- gap-free MSAs: compact keys, sort, and the whole extension scan in rank order (rank_scan.hip) -------
@@ -876,6 +890,10 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     ct.row_len = (uint32_t)(ctx->n + 1);
     ct.n = (uint32_t)ctx->n;
     ct.last = (uint32_t)(N - 1);
+    // MSAs with gaps / ignore characters: the scan in rank order follows the sort (gapped_rank.hip); its table of the
+    // text's irregular positions is made now, the pack kernels fold it into the values' top bit
+    const bool try_grs = (!ctx->gapfree || ctx->have_ignore) && !ctx->reversed && !ctx->grs_skip && ctx->opt.gapped_rank != -1 && K <= 32;
+    if (try_grs) FBG_TRY(fbg_grs_prepare(ctx, &launches));
     {
         // three passes of a sample sort fused with the key packing (msd_sort_pairs.hip) where the sizes suit it; else,
         // or when a capacity does not hold, pack and sort with rocPRIM's onesweep
@@ -886,6 +904,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
             pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = b; pa.K = K; pa.pb = 0;
             pa.keys = keysA; pa.vals = valsA;
             pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
+            pa.ebits = ctx->grs_ebits;
             launch_pack(ctx, g, false, pa);
             launches++;
             FBG_TRY(sort_slots(ctx, g, N, 0));
@@ -896,6 +915,18 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         sa = valsB;
         ctx->sa_ptr = sa;
     }
+    // ---- MSAs with gaps / ignore characters: the extension scan in rank order on these slots (gapped_rank.hip) ----
+    ctx->grs_ebits = nullptr;
+    if (try_grs) {
+        int done = 0;
+        FBG_TRY(fbg_grs_try(ctx, keysB, valsB, g, &done));
+        if (done) {
+            FBG_HIP_TRY(ctx, hipGetLastError());
+            return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
+        }
+        FBG_TRY(fbg_grs_strip(ctx, valsB));        // the record path reads the values as the suffix array
+    }
+    FBG_TRY(fbg_build_cell_tables(ctx));       // the per-cell tables of the record path's column scan
     FBG_TRY(fbg_reserve(ctx, ctx->grp, N * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->flags, (N + FC_TILE - 1) / FC_TILE * FC_TILE));   // whole tiles: k_flag_compact loads 16 bytes at a time
     FBG_TRY(fbg_reserve(ctx, ctx->rec, N * 16));

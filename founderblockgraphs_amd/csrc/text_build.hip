@@ -259,7 +259,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__rest
 #pragma unroll
             for (int k = 0; k < TB_ITEMS; k++) {
                 if (x0 + k < x_hi) {
-                    prow[i * n + x0 + k] = p0 + off;      // pos_i + rank_i(x)
+                    if (prow) prow[i * n + x0 + k] = p0 + off;      // pos_i + rank_i(x)
                     if (c[k] != '-') { T[p0 + off] = c[k]; colT[p0 + off] = (uint32_t)(x0 + k); off++; }
                 }
             }
@@ -397,14 +397,11 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->scalars.p, 0, 64 * sizeof(unsigned long long), st));
 
     ctx->have_ignore = ignore_len > 0;
-    uint8_t *d_is_ignore = nullptr;
+    ctx->cells_built = false;
+    memset(ctx->ignore_tab, 0, sizeof(ctx->ignore_tab));
     if (ctx->have_ignore) {
-        uint8_t table[256];
-        memset(table, 0, sizeof(table));
-        for (uint64_t k = 0; k < ignore_len; k++) table[ignore[k]] = 1;   // fbg.cpp:1853,1868
-        d_is_ignore = ctx->small.as<uint8_t>();
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(d_is_ignore, table, 256, hipMemcpyHostToDevice, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));  // table[] is on this stack frame
+        for (uint64_t k = 0; k < ignore_len; k++) ctx->ignore_tab[ignore[k]] = 1;   // fbg.cpp:1853,1868
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->small.as<uint8_t>(), ctx->ignore_tab, 256, hipMemcpyHostToDevice, st));
     }
     unsigned long long *sc = ctx->scalars.as<unsigned long long>();
     unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ctx->small.as<uint8_t>() + 4096);
@@ -412,7 +409,7 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->tot.p, 0, m * 4, st));
     const unsigned nseg = (unsigned)((n + RC_SEG - 1) / RC_SEG);
     FBG_TRY(fbg_reserve(ctx, ctx->segtab, (size_t)m * nseg * 4 * 3));   // per (row, segment): non-gap cells, their prefix, first ignore column
-    uint32_t *segcnt = ctx->segtab.as<uint32_t>(), *segoff = segcnt + (size_t)m * nseg, *segmin = segoff + (size_t)m * nseg;
+    uint32_t *segcnt = ctx->segtab.as<uint32_t>(), *segoff = segcnt + (size_t)m * nseg;
     // (the kernel can count the ignore cells too; nobody asks for that number, and without it rows take the word-wide path)
     // Optimistic text: most MSAs that come this way have no gaps, and then the text is the MSA with a '#' per row --
     // written by the counting pass itself from the words it loads (one read of the MSA instead of two)
@@ -449,11 +446,11 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     uint8_t *T = ctx->text.as<uint8_t>();
     const uint32_t *pos = ctx->pos.as<uint32_t>(), *tot = ctx->tot.as<uint32_t>();
     if (!ctx->gapfree) {
-        FBG_TRY(fbg_reserve(ctx, ctx->prow, m * n * 4));
+        // (the text pointer of every cell, prow, is written on demand: fbg_build_cell_tables)
         FBG_TRY(fbg_reserve(ctx, ctx->colT, ctx->N * 4));
         hipLaunchKernelGGL(k_seg_offsets, dim3(fbg_blocks(m, 64)), dim3(64), 0, st, segcnt, m, nseg, segoff);
         hipLaunchKernelGGL((k_write_text<true, false>), dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
-                           pos, tot, T, ctx->prow.as<uint32_t>(), ctx->colT.as<uint32_t>(), (const uint32_t *)segoff);
+                           pos, tot, T, (uint32_t *)nullptr, ctx->colT.as<uint32_t>(), (const uint32_t *)segoff);
         launches++;
     } else if (ctx->reversed) {
         hipLaunchKernelGGL((k_write_text<false, true>), dim3(1, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
@@ -468,15 +465,36 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
         FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->colT.as<uint32_t>() + (ctx->N - 1), &nn, 4, hipMemcpyHostToDevice, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return fbg_stage_end(ctx, FBG_STAGE_TEXT, launches);
+}
+
+// The per-cell tables only the record path's column scan reads (scan.hip): prow, the text pointer of every cell of an
+// MSA with gaps (fbg.cpp:1596-1600,1687-1691), and igrow, the first ignore column at or after every cell.  4 bytes per
+// cell each, so they are written only when that path is taken (the text and colT are written again along the way).
+int fbg_build_cell_tables(fbg_ctx *ctx)
+{
+    if (ctx->cells_built) return FBG_OK;
+    const uint64_t m = ctx->m, n = ctx->n;
+    hipStream_t st = ctx->stream;
+    const unsigned nseg = (unsigned)((n + RC_SEG - 1) / RC_SEG);
+    uint32_t *segcnt = ctx->segtab.as<uint32_t>(), *segoff = segcnt + (size_t)m * nseg, *segmin = segoff + (size_t)m * nseg;
+    if (!ctx->gapfree) {
+        FBG_TRY(fbg_reserve(ctx, ctx->prow, m * n * 4));
+        hipLaunchKernelGGL((k_write_text<true, false>), dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
+                           ctx->pos.as<uint32_t>(), ctx->tot.as<uint32_t>(), ctx->text.as<uint8_t>(), ctx->prow.as<uint32_t>(),
+                           ctx->colT.as<uint32_t>(), (const uint32_t *)segoff);
+    }
     if (ctx->have_ignore) {
+        const uint8_t *d_is_ignore = ctx->small.as<uint8_t>();
         FBG_TRY(fbg_reserve(ctx, ctx->igrow, m * n * 4));
         hipLaunchKernelGGL(k_ignore_segmin, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore, segmin);
         hipLaunchKernelGGL(k_ignore_sweep, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n, d_is_ignore,
                            (const uint32_t *)segmin, ctx->igrow.as<uint32_t>());
-        launches += 2;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());
-    return fbg_stage_end(ctx, FBG_STAGE_TEXT, launches);
+    ctx->cells_built = true;
+    return FBG_OK;
 }
 
 // ---- synthetic MSA generator of SURVEY.md section 8(d) ---------------------------------------

@@ -80,6 +80,9 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   no_aux_stream      k_tie_simple on the main stream
  *   rank_no_threshold  no extension threshold in the rank-order scan
  *   dp_literal, dp_wave, dp_tile, dp_safe_window   which sweep kernel runs the min-max-length / non-elastic DP
+ *   gapped_rank        -1: MSAs with gaps / ignore characters always take the record path (no scan in suffix order)
+ * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
+ * gap-free MSA, 2 rank-order scan of an MSA with gaps / ignore characters, 3 one partition of a partitioned index.
  * Unknown key: FBG_ERR_INVALID.
  */
 int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value);

@@ -20,7 +20,8 @@ ENVS = [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_MSD_MIN": "1"
         {"FBG_NO_RANKED": "1"}, {"FBG_FULL_KEYS": "1"}, {"FBG_MSD_MIN": "1", "FBG_FORCE_WIDE": "1", "FBG_FULL_KEYS": "1"},
         {"FBG_MSD_MIN": "1", "FBG_FULL_KEYS": "1"}, {"FBG_BP_MIN": "1"}, {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},
         {"FBG_MSD_MIN": "1", "FBG_NO_RANKED": "1"}, {"FBG_MSD_MIN": "1", "FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},
-        {"FBG_PURE_SCAN": "1"}, {"FBG_PURE_SCAN": "1", "FBG_NO_PACKED": "1"}, {"FBG_PURE_SCAN": "1", "FBG_MSD_MIN": "1"}]
+        {"FBG_PURE_SCAN": "1"}, {"FBG_PURE_SCAN": "1", "FBG_NO_PACKED": "1"}, {"FBG_PURE_SCAN": "1", "FBG_MSD_MIN": "1"},
+        {"FBG_GAPPED_RANK": "-1"}, {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"}, {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"}]
 ALL_KEYS = sorted({k for e in ENVS for k in e})
 eng = F.Engine(0)
 parts = [F.Engine(0) for _ in range(3)]
@@ -50,6 +51,12 @@ while time.time() - t0 < budget:
     if gaps:
         kw["gap_p"] = float(rng.choice([0.01, 0.05, 0.3])); kw["gap_run"] = int(rng.choice([1, 4, 20]))
     msa = random_msa(rng, m, n, alphabet=alphabet, **kw)
+    if gaps and n >= 33 and rng.random() < 0.4:          # rows that start late, end early or skip a long stretch
+        for i in rng.choice(m, size=max(1, m // 3), replace=False):
+            kind = int(rng.integers(3))
+            w = int(rng.integers(1, max(2, n // 2)))
+            a0 = 0 if kind == 0 else n - w if kind == 1 else int(rng.integers(0, n - w))
+            msa[i, a0:a0 + w] = ord("-")
     env = ENVS[int(rng.integers(len(ENVS)))]
     for e in [eng] + parts:                               # fbg_set_option: the library does not read the environment
         for k in ALL_KEYS:

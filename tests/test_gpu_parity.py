@@ -355,15 +355,20 @@ def test_nonelastic_dp_random_v(engine, max_len):
             assert np.array_equal(gb, b)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(similar=0.97), dict(gap_p=0.01, gap_run=8)], ids=["iid", "similar", "gaps"])
+@pytest.mark.parametrize("kw", [dict(), dict(similar=0.97), dict(gap_p=0.01, gap_run=8), dict(gap_p=0.01, gap_run=8, records=1)],
+                         ids=["iid", "similar", "gaps", "gaps-records"])
 def test_large_text_index_arrays(engine, kw):
-    """Texts above 2^20 symbols (packed compact keys for the iid rows, record path for the other two): index
-    arrays and f must equal the oracle's."""
+    """Texts above 2^20 symbols (packed compact keys for the iid rows, group-level scan for the similar ones, the scan in
+    suffix order of gapped_rank.hip for the rows with gaps, and the record path for them): index arrays and f must
+    equal the oracle's."""
     rng = np.random.default_rng(77)
+    kw = dict(kw)
+    engine.set_option("gapped_rank", -1 if kw.pop("records", 0) else 0)
     msa = random_msa(rng, 48, 24000, **kw)
     T, SA, ISA, LCP = O.msa_index(msa)
     engine.msa_load_host(msa)
     engine.index_build()
+    engine.set_option("gapped_rank", 0)
     gT, gSA, gISA, gPL, gPR = engine.index_download()
     assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64))
     assert np.array_equal(gISA.astype(np.int64), ISA.astype(np.int64))
@@ -392,6 +397,9 @@ ALT_PATHS = [
     {"FBG_BP_MIN": "1"},                             # records reach their text positions through splitting passes ...
     {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},       # ... also for gap-free MSAs
     {"FBG_RECORD_SCATTER": "1"},                     # ... or by a direct scatter whatever the size
+    {"FBG_GAPPED_RANK": "-1"},                       # record path for the MSAs with gaps / ignore characters (default: gapped_rank.hip)
+    {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"},
+    {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"},
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
     {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
@@ -933,7 +941,7 @@ def test_records_by_position_passes(engine, sort):
     behind rocPRIM's sort and behind the three-pass sample sort of the pairs (msd_sort_pairs.hip, MODE 1)."""
     import os
     rng = np.random.default_rng(31)
-    switches = {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"}
+    switches = {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1", "FBG_GAPPED_RANK": "-1"}
     switches["FBG_MSD_MIN" if sort == "samplesort" else "FBG_NO_MSD_SORT"] = "1"
     with fbg_options(engine, switches):
         for (m, n, kw) in [(7, 1300, dict(gap_p=0.03, gap_run=5)), (33, 257, dict(similar=0.95)), (3, 3000, dict(alphabet="AC", similar=0.99)),
@@ -949,8 +957,74 @@ def test_records_by_position_passes(engine, sort):
             assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA]), (m, n)
             assert np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1]), (m, n)
     msa = random_msa(rng, 24, 800000, gap_p=0.05 / 16, gap_run=16, n_p=0.001)      # 1.9 * 10^7 symbols > 2^24
-    with fbg_options(engine, {"FBG_NO_MSD_SORT": "1"} if sort == "rocprim" else {}):
-        assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), O.compute_f(msa, ignore="N", threads=8))
+    want = O.compute_f(msa, ignore="N", threads=8)
+    with fbg_options(engine, {"FBG_NO_MSD_SORT": "1", "FBG_GAPPED_RANK": "-1"} if sort == "rocprim" else {"FBG_GAPPED_RANK": "-1"}):
+        assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), want)
+        assert engine.get_option("index_kind") == 0
+    with fbg_options(engine, {"FBG_NO_MSD_SORT": "1"} if sort == "rocprim" else {}):       # and the scan in suffix order behind the same sort
+        assert np.array_equal(engine.elastic_f(msa, ignorechars="N"), want)
+        assert engine.get_option("index_kind") == 2
+
+
+def _long_gaps(rng, msa):
+    """rows that start late, end early or skip a long stretch"""
+    m, n = msa.shape
+    for i in rng.choice(m, size=max(1, m // 3), replace=False):
+        kind = int(rng.integers(3))
+        w = int(rng.integers(1, max(2, n // 2)))
+        a0 = 0 if kind == 0 else n - w if kind == 1 else int(rng.integers(0, n - w))
+        msa[i, a0:a0 + w] = ord("-")
+    return msa
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_gapped_rank_scan_matches_oracle(engine, case):
+    """MSAs with gaps and / or ignore characters through the scan in suffix order (gapped_rank.hip): f with and
+    without the elastic tricks (the second is a re-scan of the kept slots), the max-merge into a given f, column shards,
+    the index arrays read back from the slots, long gap runs (a position that is its row's pointer for hundreds of columns)."""
+    import torch
+    import founderblockgraphs_amd as F
+    rng = np.random.default_rng(900 + case)
+    m, n, kw, ign, long_gaps = [
+        (12, 900, dict(gap_p=0.02, gap_run=5, n_p=0.01), "N", False),
+        (64, 400, dict(gap_p=0.05, gap_run=2), "", True),
+        (5, 3000, dict(alphabet="AC", gap_p=0.01, gap_run=30), "", True),
+        (30, 700, dict(n_p=0.03), "N", False),                                   # no gaps at all: ignore characters only
+        (17, 1200, dict(similar=0.9, gap_p=0.01, gap_run=8, n_p=0.005), "N", True),
+        (130, 257, dict(alphabet="ACGTRYKM", gap_p=0.3, gap_run=1), "RY", False),
+        (3, 100, dict(gap_p=0.05, gap_run=20), "", True),
+        (40, 2000, dict(gap_p=0.005, gap_run=4, n_p=0.001), "N", True)][case]
+    msa = random_msa(rng, m, n, **kw)
+    if long_gaps:
+        msa = _long_gaps(rng, msa)
+    assert (msa != ord("-")).sum(axis=1).min() > 0
+    for off in (False, True):
+        want = O.compute_f(msa, ignore=ign, disable_tricks=off)
+        try:
+            got = engine.elastic_f(msa, ignorechars=ign, disable_efg_tricks=off)
+            assert np.array_equal(got, want), (off, np.flatnonzero(got != want)[:8])
+        except F.NoSegmentation:
+            assert want[0] == n
+        assert engine.get_option("index_kind") == 2
+    f0 = rng.integers(0, n, n).astype(np.uint64)
+    want = O.compute_f(msa, ignore=ign, f_init=f0)
+    assert np.array_equal(engine.elastic_f(msa, ignorechars=ign, f=f0), want)
+    # staged calls: one index, both settings of the tricks in turn, shards
+    engine.msa_load_host(msa)
+    engine.index_build(ignorechars=ign)
+    for off in (True, False, True):
+        d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        for k in range(3):
+            engine.scan_f(n * k // 3, n * (k + 1) // 3, d_f.data_ptr(), disable_efg_tricks=off)
+        engine.sync()
+        assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa, ignore=ign, disable_tricks=off))
+    T, SA, ISA, LCP = O.msa_index(msa)
+    gT, gSA, gISA, gPL, gPR = engine.index_download()
+    lcp_ext = np.concatenate([LCP, [0]]).astype(np.int64)
+    assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64)) and np.array_equal(gISA.astype(np.int64), ISA.astype(np.int64))
+    assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA]) and np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1])
+    assert np.array_equal(engine.gapped_v(msa), O.gapped_v(msa))       # segment2elasticValid: f without the tricks underneath
 
 
 def test_gapped_v_on_a_partitioned_index():
