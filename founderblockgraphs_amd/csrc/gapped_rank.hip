@@ -253,15 +253,21 @@ __device__ __forceinline__ uint32_t gr_slot_lcp(const GrsArgs &a, uint64_t k)
 }
 
 // histogram of g = 1 + max(LCP before, LCP after) over evenly spaced slots (ties: K + 1)
-__global__ void k_grs_sample(GrsArgs a, uint64_t stride, unsigned long long *__restrict__ hist)
+__global__ __launch_bounds__(256) void k_grs_sample(GrsArgs a, uint64_t stride, unsigned long long *__restrict__ hist)
 {
+    __shared__ uint32_t h[66];
+    if (threadIdx.x < 66) h[threadIdx.x] = 0;
+    __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t s = i * stride + 1;
-    if (i >= GR_SAMPLE || s + 1 >= a.N) return;
-    const uint64_t kp = a.keys[s - 1], k = a.keys[s], kn = a.keys[s + 1];
-    uint32_t g = (uint32_t)a.K + 1;
-    if (kp != k && kn != k) g = max(gr_key_lcp(kp, k, a.b, a.key_bits), gr_key_lcp(k, kn, a.b, a.key_bits)) + 1;
-    atomicAdd(&hist[min(g, 65u)], 1ull);
+    if (i < GR_SAMPLE && s + 1 < a.N) {
+        const uint64_t kp = a.keys[s - 1], k = a.keys[s], kn = a.keys[s + 1];
+        uint32_t g = (uint32_t)a.K + 1;
+        if (kp != k && kn != k) g = max(gr_key_lcp(kp, k, a.b, a.key_bits), gr_key_lcp(k, kn, a.b, a.key_bits)) + 1;
+        atomicAdd(&h[min(g, 65u)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 66 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
 // first symbol of the key that is an ignore character, among its first `reach` (<= K); reach if none
@@ -612,39 +618,62 @@ __global__ __launch_bounds__(256) void k_grs_long(GrsArgs a, uint32_t count)
 
 // Candidates sorted by (column, slot), possibly listed more than once: a run = consecutive slots in one column
 // (fbg.cpp:1633-1641).  Every run that holds a slot the scan worked on is listed whole (gr_walk), so the slots before
-// and after a listed run are not coloured.  One thread per run head walks it:
-// g = 1 + max(min LCP towards the run's head, min LCP towards its tail) (fbg.cpp:1644-1678).
-__global__ void k_grs_runs(GrsArgs a, uint64_t T)
+// and after a listed run are not coloured.  g = 1 + max(min LCP towards the run's head, min LCP towards its tail)
+// (fbg.cpp:1644-1678) in three steps: the LCPs of every entry with the slot before and after it (parallel; these are
+// the dependent reads), the two running minima along each run (one thread per run head, over the arrays just made: a
+// run of the row ends' 256 suffixes walked with the reads inside took 1.3 ms), the update per entry (parallel).
+__global__ void k_grs_runs_lcp(GrsArgs a, uint64_t T, uint32_t *__restrict__ lcpL, uint32_t *__restrict__ lcpR)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint64_t s = (uint32_t)a.cand[t];
+    lcpL[t] = gr_slot_lcp(a, s);
+    lcpR[t] = gr_slot_lcp(a, s + 1);
+}
+
+// gq[t] (= a.pm): g of the entry, 0 for the repeats of an entry
+__global__ void k_grs_runs_walk(GrsArgs a, uint64_t T, const uint32_t *__restrict__ lcpL, const uint32_t *__restrict__ lcpR)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const unsigned long long e = a.cand[t];
     if (t > 0 && (a.cand[t - 1] == e || a.cand[t - 1] + 1 == e)) return;          // a repeat, or (x, slot - 1) is listed: not a head
-    const uint32_t x = (uint32_t)(e >> 32);
-    uint64_t s = (uint32_t)e, tt = t;
-    uint32_t run = gr_slot_lcp(a, s);
+    uint64_t tt = t;
+    uint32_t run = lcpL[t];
     for (;;) {
         a.pm[tt] = run;
         if (tt + 1 >= T) break;
         const unsigned long long nx = a.cand[tt + 1], cu = a.cand[tt];
         if (nx == cu) { tt++; continue; }
         if (nx != cu + 1) break;
-        tt++; s++;
-        run = min(run, gr_slot_lcp(a, s));
+        tt++;
+        run = min(run, lcpL[tt]);
     }
     uint32_t rmin = 0xffffffffu;
     for (;;) {
-        rmin = min(rmin, gr_slot_lcp(a, s + 1));
+        rmin = min(rmin, lcpR[tt]);
         const uint32_t g = max(a.pm[tt], rmin) + 1;
-        const uint32_t p = a.vals[s] & a.vmask;
-        uint32_t lo, hi, row;
-        GWin w;
-        gr_span(a, p, lo, hi, row, w);
-        gr_update(a, x, gr_extent(a, p, row, g, a.keys[s], g <= (uint32_t)a.K, w));
-        while (tt > t && a.cand[tt - 1] == a.cand[tt]) tt--;
+        while (tt > t && a.cand[tt - 1] == a.cand[tt]) { a.pm[tt] = 0; tt--; }
+        a.pm[tt] = g;
         if (tt == t) break;
-        tt--; s--;
+        tt--;
     }
+}
+
+__global__ void k_grs_runs_apply(GrsArgs a, uint64_t T)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t g = a.pm[t];
+    if (g == 0) return;
+    const unsigned long long e = a.cand[t];
+    const uint32_t x = (uint32_t)(e >> 32);
+    const uint64_t s = (uint32_t)e;
+    const uint32_t p = a.vals[s] & a.vmask;
+    uint32_t lo, hi, row;
+    GWin w;
+    gr_span(a, p, lo, hi, row, w);
+    gr_update(a, x, gr_extent(a, p, row, g, a.keys[s], g <= (uint32_t)a.K, w));
 }
 
 // columns whose maximum a skipped slot could beat (it contributes at most x + t - 2): listed, to be redone
@@ -773,10 +802,13 @@ static int grs_sort_and_runs(fbg_ctx *ctx, GrsArgs &a, uint64_t T, int *launches
     e = rocprim::radix_sort_keys(ctx->tmp.p, have, a.cand, sorted, (size_t)T, 0u, 32u + (unsigned)nb, st);
     if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_keys: %s", hipGetErrorString(e));
     unsigned long long *unsorted = a.cand;
+    uint32_t *lcpL = reinterpret_cast<uint32_t *>(unsorted), *lcpR = lcpL + a.cand_cap;     // the unsorted list is done with
     a.cand = sorted;
-    hipLaunchKernelGGL(k_grs_runs, dim3(fbg_blocks(T, 64)), dim3(64), 0, st, a, T);
+    hipLaunchKernelGGL(k_grs_runs_lcp, dim3(fbg_blocks(T, 256)), dim3(256), 0, st, a, T, lcpL, lcpR);
+    hipLaunchKernelGGL(k_grs_runs_walk, dim3(fbg_blocks(T, 64)), dim3(64), 0, st, a, T, lcpL, lcpR);
+    hipLaunchKernelGGL(k_grs_runs_apply, dim3(fbg_blocks(T, 256)), dim3(256), 0, st, a, T);
     a.cand = unsorted;
-    *launches += 2;
+    *launches += 4;
     return FBG_OK;
 }
 

@@ -21,7 +21,8 @@ ENVS = [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_MSD_MIN": "1"
         {"FBG_MSD_MIN": "1", "FBG_FULL_KEYS": "1"}, {"FBG_BP_MIN": "1"}, {"FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},
         {"FBG_MSD_MIN": "1", "FBG_NO_RANKED": "1"}, {"FBG_MSD_MIN": "1", "FBG_BP_MIN": "1", "FBG_NO_RANKED": "1"},
         {"FBG_PURE_SCAN": "1"}, {"FBG_PURE_SCAN": "1", "FBG_NO_PACKED": "1"}, {"FBG_PURE_SCAN": "1", "FBG_MSD_MIN": "1"},
-        {"FBG_GAPPED_RANK": "-1"}, {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"}, {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"}]
+        {"FBG_GAPPED_RANK": "-1"}, {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"}, {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"},
+        {"FBG_GAPPED_RANK": "4"}, {"FBG_GAPPED_RANK": "4", "FBG_MSD_MIN": "1"}, {"FBG_GAPPED_RANK": "2"}, {"FBG_GAPPED_RANK": "3"}]
 ALL_KEYS = sorted({k for e in ENVS for k in e})
 eng = F.Engine(0)
 parts = [F.Engine(0) for _ in range(3)]
@@ -47,7 +48,7 @@ while time.time() - t0 < budget:
     kw = {}
     if rng.random() < 0.5:
         kw["similar"] = float(rng.choice([0.5, 0.9, 0.99]))
-    gaps = rng.random() < 0.3
+    gaps = rng.random() < 0.45
     if gaps:
         kw["gap_p"] = float(rng.choice([0.01, 0.05, 0.3])); kw["gap_run"] = int(rng.choice([1, 4, 20]))
     msa = random_msa(rng, m, n, alphabet=alphabet, **kw)
