@@ -43,6 +43,7 @@ SIGNATURES = {
                                     C.c_uint32, C.c_uint64, C.c_uint64]),
     "fbg_index_build": (C.c_int, [vp, C.c_int, u8p, C.c_uint64]),
     "fbg_part_index_build": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]),
+    "fbg_part_index_build_ignore": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_uint64, vp, C.POINTER(C.c_int)]),
     "fbg_part_scan": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int)]),
     "fbg_part_finish": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
     "fbg_part_rescan": (C.c_int, [vp, vp]),

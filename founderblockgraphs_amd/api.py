@@ -187,9 +187,13 @@ class Engine:
         self._chk(self._L.fbg_index_build(self._h, int(reversed), _u8(ig), il))
 
     # partitioned index (multi-GPU, include/fbg_hip.h): each returns ok; False = use index_build on every rank
-    def part_index_build(self, part, nparts, d_blob_ptr, reversed=False):
+    def part_index_build(self, part, nparts, d_blob_ptr, reversed=False, ignorechars="", disable_efg_tricks=False):
+        """One key-range partition of the index (fbg_part_index_build_ignore).  MSAs with gaps / ignore characters are
+        scanned for ONE setting of the elastic tricks (option part_tricks_off), given here."""
         ok = C.c_int(0)
-        self._chk(self._L.fbg_part_index_build(self._h, int(reversed), part, nparts, C.c_void_p(d_blob_ptr), C.byref(ok)))
+        ig, il = _ignore(ignorechars)
+        self.set_option("part_tricks_off", int(bool(disable_efg_tricks)))
+        self._chk(self._L.fbg_part_index_build_ignore(self._h, int(reversed), part, nparts, _u8(ig), il, C.c_void_p(d_blob_ptr), C.byref(ok)))
         return bool(ok.value)
 
     def part_scan(self, d_blobs_ptr, d_gmax_ptr):

@@ -162,7 +162,7 @@ static const OptKey g_opt_keys[] = {
     {"bp_min", &FbgOptions::bp_min}, {"record_scatter", &FbgOptions::record_scatter}, {"lcp_text", &FbgOptions::lcp_text},
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
-    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank},
+    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off},
 };
 
 // The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of
@@ -360,6 +360,7 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->index_valid = false;
     ctx->granked = false;
+    ctx->gpart = false;
     ctx->reversed = reversed ? 1 : 0;
     FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
     FBG_TRY(fbg_suffix_sort(ctx));
@@ -371,17 +372,23 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
 
 int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void *d_blob, int *ok)
 {
+    return fbg_part_index_build_ignore(ctx, reversed, part, nparts, nullptr, 0, d_blob, ok);
+}
+
+int fbg_part_index_build_ignore(fbg_ctx *ctx, int reversed, int part, int nparts, const uint8_t *ignore_chars, uint64_t ignore_len, void *d_blob, int *ok)
+{
     if (!ctx) return FBG_ERR_INVALID;
     if (!ctx->d_msa) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_index_build: no MSA set");
-    if (!d_blob || !ok || nparts < 1 || part < 0 || part >= nparts)
+    if (!d_blob || !ok || nparts < 1 || part < 0 || part >= nparts || (ignore_len && !ignore_chars))
         return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_index_build: bad arguments");
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->index_valid = false;
     ctx->ranked = false;
     ctx->granked = false;
     ctx->reversed = reversed ? 1 : 0;
+    ctx->gpart = false;
     ctx->allow_wide = true;                        // the partitions together may hold a text of 2^32 symbols and more
-    const int rc = fbg_build_text(ctx, nullptr, 0);
+    const int rc = fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len);
     ctx->allow_wide = false;
     FBG_TRY(rc);
     return fbg_part_sort(ctx, part, nparts, static_cast<uint8_t *>(d_blob), ok);
@@ -394,6 +401,7 @@ int fbg_part_scan(fbg_ctx *ctx, const void *d_blobs, uint32_t *d_gmax, int *ok)
         return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_scan needs fbg_part_index_build first");
     if (!d_blobs || !d_gmax || !ok) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_scan: bad arguments");
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->gpart) return fbg_grs_part_scan(ctx, static_cast<const uint8_t *>(d_blobs), d_gmax, ok);
     return fbg_rank_part_runs(ctx, static_cast<const uint8_t *>(d_blobs), d_gmax, ok);
 }
 
@@ -412,9 +420,11 @@ int fbg_part_finish(fbg_ctx *ctx, const uint32_t *d_gmax, int *ok)
     if (*ok) {
         // a column whose maximum is below the threshold some partition scanned with may have lost a larger value
         uint64_t unfilled = 0;
-        FBG_TRY(fbg_rank_part_unfilled(ctx, &unfilled));
+        if (ctx->gpart) FBG_TRY(fbg_grs_part_unfilled(ctx, &unfilled));
+        else FBG_TRY(fbg_rank_part_unfilled(ctx, &unfilled));
         if (unfilled) { *ok = 2; return FBG_OK; }
-        ctx->n_exc = 0; ctx->ranked = true; ctx->index_valid = true;
+        ctx->n_exc = 0; ctx->index_valid = true;
+        if (ctx->gpart) ctx->granked = true; else ctx->ranked = true;
     }
     return FBG_OK;
 }
@@ -426,9 +436,11 @@ int fbg_part_rescan(fbg_ctx *ctx, uint32_t *d_gmax)
         return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_rescan follows a fbg_part_finish that returned *ok = 2");
     if (!d_gmax) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_part_rescan: bad arguments");
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FBG_TRY(fbg_rank_part_rescan(ctx));
+    uint32_t verdict = 0;
+    if (ctx->gpart) { FBG_TRY(fbg_grs_part_rescan(ctx)); verdict = ctx->grs_part_failed ? 1u : 0u; }
+    else FBG_TRY(fbg_rank_part_rescan(ctx));
     FBG_HIP_TRY(ctx, hipMemcpyAsync(d_gmax, ctx->gmax.p, (ctx->n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(d_gmax + ctx->n, 0, 4, ctx->stream));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(d_gmax + ctx->n, &verdict, 4, hipMemcpyHostToDevice, ctx->stream));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FBG_OK;
 }

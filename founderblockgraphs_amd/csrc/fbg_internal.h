@@ -37,7 +37,7 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0;
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0;
 };
 
 struct fbg_ctx {
@@ -93,6 +93,8 @@ struct fbg_ctx {
     DevBuf gbits;                  // 1 bit per text position: not the column after its predecessor's
     const uint64_t *grs_ebits = nullptr;   // gbits while the pack kernels are to fold it into bit 31 of the sort's values
     bool grs_flagged = false;      // the sorted values carry that bit
+    bool gpart = false;            // one key-range partition of such an index (fbg_part_*)
+    bool grs_part_failed = false;  // its exact redo of a few columns ran out of room
     uint32_t grs_t = 1;            // the threshold of the last scan (1: none), the columns it redid exactly
     uint64_t grs_redone = 0;
     bool cells_built = false;      // prow / igrow hold the current MSA (built on demand: only the record path reads them)
@@ -166,6 +168,10 @@ int fbg_rank_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int mode, int disabl
 int fbg_rank_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
 #define FBG_STAGE_RANKSCAN FBG_STAGE_TILE
 int fbg_grs_prepare(fbg_ctx *ctx, int *launches);
+int fbg_grs_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int eligible, uint8_t *d_blob, int *ok);
+int fbg_grs_part_scan(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok);
+int fbg_grs_part_unfilled(fbg_ctx *ctx, uint64_t *unfilled);
+int fbg_grs_part_rescan(fbg_ctx *ctx);
 int fbg_grs_strip(fbg_ctx *ctx, uint32_t *vals);
 int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);             // gapped_rank.hip
 int fbg_grs_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_out, int *ok);

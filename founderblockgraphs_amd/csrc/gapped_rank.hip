@@ -70,7 +70,10 @@ struct GrsArgs {
     const GWin *win;                 // nullptr: rows without gaps (ignore characters only), position = row * (n + 1) + column
     const uint32_t *colT, *pos, *tot;
     const uint8_t *is_ignore;        // by byte; nullptr: no ignore characters
-    uint64_t N, n, m;
+    uint64_t N, n, m;                // text length, columns, rows
+    uint64_t own_lo, own_hi;         // the slots this scan works on (a key-range partition: the middle of the arrays) ...
+    uint64_t lim_lo, lim_hi;         // ... and the slots that exist around them (halos of the neighbouring partitions)
+    int open_lo, open_hi;            // more slots, unseen, beyond lim_lo / lim_hi (another partition's)
     int b, K, key_bits, disable_tricks;
     uint32_t ign_lo, ign_hi;         // bit c of (ign_hi:ign_lo): symbol code c is an ignore character
     uint32_t t;                      // slots with g < t that are regular are skipped (1: none)
@@ -220,13 +223,13 @@ __global__ void k_grs_ebits_gapfree(uint64_t N, uint64_t n, uint64_t words, unsi
 // tie groups (equal keys) in text order: insertion sort by the text beyond the key, values rewritten in place
 __global__ void k_grs_ties(GrsArgs a)
 {
-    const uint64_t k0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k0 + 1 >= a.N) return;
+    const uint64_t k0 = a.own_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (equal keys never straddle partitions)
+    if (k0 + 1 >= a.own_hi) return;
     const uint64_t key = a.keys[k0];
     if (a.keys[k0 + 1] != key) return;
-    if (k0 > 0 && a.keys[k0 - 1] == key) return;
+    if (k0 > a.own_lo && a.keys[k0 - 1] == key) return;
     uint32_t s = 2;
-    while (k0 + s < a.N && s <= GR_MAX_TIE && a.keys[k0 + s] == key) s++;
+    while (k0 + s < a.own_hi && s <= GR_MAX_TIE && a.keys[k0 + s] == key) s++;
     if (s > GR_MAX_TIE) { a.counters[1] = 1; return; }
     // (two suffixes with equal keys both have K symbols before the sentinel, and the compare ends at the sentinel at the latest)
     for (uint32_t i = 1; i < s; i++) {
@@ -246,7 +249,7 @@ __global__ void k_grs_ties(GrsArgs a)
 // LCP of the suffixes in slots k - 1 and k (final order)
 __device__ __forceinline__ uint32_t gr_slot_lcp(const GrsArgs &a, uint64_t k)
 {
-    if (k == 0 || k >= a.N) return 0;
+    if (k <= a.lim_lo || k >= a.lim_hi) return 0;
     const uint64_t x = a.keys[k - 1], y = a.keys[k];
     if (x != y) return gr_key_lcp(x, y, a.b, a.key_bits);
     return fbg_clamp_lcp(fbg_extend_match(a.T, (uint64_t)(a.vals[k - 1] & a.vmask) + a.K, (uint64_t)(a.vals[k] & a.vmask) + a.K, 0) + (uint32_t)a.K);
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(256) void k_grs_sample(GrsArgs a, uint64_t stride, 
     if (threadIdx.x < 66) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t s = i * stride + 1;
-    if (i < GR_SAMPLE && s + 1 < a.N) {
+    const uint64_t s = a.own_lo + i * stride + 1;
+    if (i < GR_SAMPLE && s + 1 < a.own_hi) {
         const uint64_t kp = a.keys[s - 1], k = a.keys[s], kn = a.keys[s + 1];
         uint32_t g = (uint32_t)a.K + 1;
         if (kp != k && kn != k) g = max(gr_key_lcp(kp, k, a.b, a.key_bits), gr_key_lcp(k, kn, a.b, a.key_bits)) + 1;
@@ -323,7 +326,8 @@ __device__ __forceinline__ void gr_walk(const GrsArgs &a, uint64_t s, uint32_t l
 {
     for (int dir = -1; dir <= 1; dir += 2) {
         uint32_t l = lo, h = hi;
-        for (uint64_t q = s + dir; q < a.N; q += dir) {                 // (s = 0, dir = -1: q wraps and ends the loop)
+        uint64_t q = s + dir;
+        for (; q >= a.lim_lo && q < a.lim_hi; q += dir) {               // (q = 0 - 1 wraps and ends the loop)
             uint32_t ql, qh, qrow;
             GWin qw;
             gr_span(a, a.vals[q] & a.vmask, ql, qh, qrow, qw);
@@ -331,6 +335,7 @@ __device__ __forceinline__ void gr_walk(const GrsArgs &a, uint64_t s, uint32_t l
             if (l > h) break;
             f(l, h, q);
         }
+        if (l <= h && (dir < 0 ? a.open_lo : a.open_hi)) a.counters[1] = 1;   // the run goes on where this partition cannot see
     }
 }
 
@@ -347,7 +352,7 @@ __device__ __forceinline__ void gr_slot(const GrsArgs &a, bool in, uint64_t s, u
                                         uint64_t k2p, uint64_t k2n, unsigned long long *stage, uint32_t *stage_fill)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const bool has_prev = s > 0, has_next = s + 1 < a.N;
+    const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
     const uint32_t v = in ? a.vals[s] : 0u;
     const uint32_t p = v & a.vmask;
     const bool flagged = a.vmask == 0xffffffffu || (v >> 31);
@@ -379,9 +384,9 @@ __device__ __forceinline__ void gr_slot(const GrsArgs &a, bool in, uint64_t s, u
         bool see_prev = has_prev, see_next = has_next;
         if (cheap_ok && !flagged && !tie && g >= a.t) {
             // is the neighbour one the scan skips?  (its g from its own two neighbours' keys, its flag from its value)
-            if (has_prev && kp != key && s >= 2 && k2p != kp && !(a.vals[s - 1] >> 31))
+            if (has_prev && kp != key && s >= a.lim_lo + 2 && k2p != kp && !(a.vals[s - 1] >> 31))
                 see_prev = max(lp, gr_key_lcp(k2p, kp, a.b, a.key_bits)) + 1 >= a.t;
-            if (has_next && kn != key && s + 2 < a.N && k2n != kn && !(a.vals[s + 1] >> 31))
+            if (has_next && kn != key && s + 2 < a.lim_hi && k2n != kn && !(a.vals[s + 1] >> 31))
                 see_next = max(ln, gr_key_lcp(kn, k2n, a.b, a.key_bits)) + 1 >= a.t;
         }
         if (see_prev) { gr_span(a, a.vals[s - 1] & a.vmask, pl, ph, r2, w2); pl = max(pl, lo); ph = min(ph, hi); }
@@ -445,13 +450,13 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_all(GrsArgs a)
     __shared__ uint64_t skey[GR_THREADS + 2];
     __shared__ unsigned long long stage[GR_STAGE], gbase;
     __shared__ uint32_t stage_fill;
-    const uint64_t base = (uint64_t)blockIdx.x * GR_THREADS;
+    const uint64_t base = a.own_lo + (uint64_t)blockIdx.x * GR_THREADS;
     const int me = (int)threadIdx.x + 1;
     const uint64_t s = base + threadIdx.x;
-    const bool in = s < a.N;
-    skey[me] = in ? a.keys[s] : 0ull;
-    if (threadIdx.x == 0) skey[0] = base > 0 ? a.keys[base - 1] : 0ull;
-    if (threadIdx.x == 1) skey[GR_THREADS + 1] = base + GR_THREADS < a.N ? a.keys[base + GR_THREADS] : 0ull;
+    const bool in = s < a.own_hi;
+    skey[me] = s < a.lim_hi ? a.keys[s] : 0ull;
+    if (threadIdx.x == 0) skey[0] = base > a.lim_lo ? a.keys[base - 1] : 0ull;
+    if (threadIdx.x == 1) skey[GR_THREADS + 1] = base + GR_THREADS < a.lim_hi ? a.keys[base + GR_THREADS] : 0ull;
     if (threadIdx.x == 0) stage_fill = 0;
     __syncthreads();
     gr_slot(a, in, s, skey[me], skey[me - 1], skey[me + 1], false, 0, 0, stage, &stage_fill);
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_list(GrsArgs a, const u
     const bool in = i < count;
     const uint64_t s = in ? list[i] : 0;
     const uint64_t key = in ? a.keys[s] : 0ull;
-    const uint64_t kp = in && s > 0 ? a.keys[s - 1] : 0ull, kn = in && s + 1 < a.N ? a.keys[s + 1] : 0ull;
+    const uint64_t kp = in && s > a.lim_lo ? a.keys[s - 1] : 0ull, kn = in && s + 1 < a.lim_hi ? a.keys[s + 1] : 0ull;
     gr_slot(a, in, s, key, kp, kn, false, 0, 0, stage, &stage_fill);
     gr_flush(a, stage, &stage_fill, &gbase, true);
 }
@@ -491,10 +496,10 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const ui
         uint64_t key = 0, kp = 0, kn = 0, k2p = 0, k2n = 0;
         if (in) {
             key = a.keys[s];
-            if (s > 0) kp = a.keys[s - 1];
-            if (s > 1) k2p = a.keys[s - 2];
-            if (s + 1 < a.N) kn = a.keys[s + 1];
-            if (s + 2 < a.N) k2n = a.keys[s + 2];
+            if (s > a.lim_lo) kp = a.keys[s - 1];
+            if (s > a.lim_lo + 1) k2p = a.keys[s - 2];
+            if (s + 1 < a.lim_hi) kn = a.keys[s + 1];
+            if (s + 2 < a.lim_hi) k2n = a.keys[s + 2];
         }
         gr_slot(a, in, s, key, kp, kn, true, k2p, k2n, stage, &stage_fill);
         gr_flush(a, stage, &stage_fill, &gbase, r + GR_THREADS >= cnt);
@@ -514,17 +519,17 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t
     uint32_t *mine = list + (uint64_t)blockIdx.x * GR_SEG;
     if (threadIdx.x == 0) fill = 0;
     for (uint32_t r = 0; r < GR_SEG; r += GR_THREADS) {
-        const uint64_t base = (uint64_t)blockIdx.x * GR_SEG + r;
+        const uint64_t base = a.own_lo + (uint64_t)blockIdx.x * GR_SEG + r;
         const uint64_t s = base + threadIdx.x;
-        const bool in = s < a.N;
+        const bool in = s < a.own_hi;
         __syncthreads();
-        skey[me] = in ? a.keys[s] : 0ull;
-        if (threadIdx.x == 0) skey[0] = base > 0 && base <= a.N ? a.keys[base - 1] : 0ull;
-        if (threadIdx.x == 1) skey[GR_THREADS + 1] = base + GR_THREADS < a.N ? a.keys[base + GR_THREADS] : 0ull;
+        skey[me] = s < a.lim_hi ? a.keys[s] : 0ull;
+        if (threadIdx.x == 0) skey[0] = base > a.lim_lo && base <= a.lim_hi ? a.keys[base - 1] : 0ull;
+        if (threadIdx.x == 1) skey[GR_THREADS + 1] = base + GR_THREADS < a.lim_hi ? a.keys[base + GR_THREADS] : 0ull;
         const uint32_t v = in ? a.vals[s] : 0u;
         __syncthreads();
         const uint64_t key = skey[me], kp = skey[me - 1], kn = skey[me + 1];
-        const bool has_prev = s > 0, has_next = s + 1 < a.N;
+        const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
         const bool tie = (has_prev && kp == key) || (has_next && kn == key);
         bool work = in && ((v >> 31) || tie);
         if (in && !work) work = max(has_prev ? gr_key_lcp(kp, key, a.b, a.key_bits) : 0u, has_next ? gr_key_lcp(key, kn, a.b, a.key_bits) : 0u) + 1 >= a.t;
@@ -539,8 +544,9 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t
 }
 
 // second pass: the slots whose position is in the set (LDS copy; hbits = log2 of its size)
-__global__ __launch_bounds__(256) void k_grs_find(const uint32_t *__restrict__ vals, uint32_t vmask, uint64_t N, const uint32_t *__restrict__ set,
-                                                  uint32_t hbits, uint32_t *__restrict__ list, uint32_t cap, unsigned long long *__restrict__ counters)
+__global__ __launch_bounds__(256) void k_grs_find(const uint32_t *__restrict__ vals, uint32_t vmask, uint64_t N, uint32_t first_slot,
+                                                  const uint32_t *__restrict__ set, uint32_t hbits, uint32_t *__restrict__ list, uint32_t cap,
+                                                  unsigned long long *__restrict__ counters)
 {
     extern __shared__ uint32_t set_lds[];
     const uint32_t H = 1u << hbits;
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(256) void k_grs_find(const uint32_t *__restrict__ v
     const uint64_t quads = (N + 3) / 4;
     for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * 256) {
         uint32_t pv[4];
-        if (4 * q + 3 < N) { const uint4 x = reinterpret_cast<const uint4 *>(vals)[q]; pv[0] = x.x; pv[1] = x.y; pv[2] = x.z; pv[3] = x.w; }
+        if (4 * q + 3 < N && ((uintptr_t)vals & 15) == 0) { const uint4 x = reinterpret_cast<const uint4 *>(vals)[q]; pv[0] = x.x; pv[1] = x.y; pv[2] = x.z; pv[3] = x.w; }
         else for (int i = 0; i < 4; i++) pv[i] = 4 * q + i < N ? vals[4 * q + i] : GR_EMPTY;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(256) void k_grs_find(const uint32_t *__restrict__ v
                 const uint32_t v = set_lds[h];
                 if (v == p) {
                     const unsigned long long at = atomicAdd(&counters[4], 1ull);
-                    if (at < cap) list[at] = (uint32_t)(4 * q + i);
+                    if (at < cap) list[at] = first_slot + (uint32_t)(4 * q + i);
                     break;
                 }
                 if (v == GR_EMPTY) break;
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256) void k_grs_long(GrsArgs a, uint32_t count)
     uint32_t lo, hi, row;
     GWin w;
     gr_span(a, p, lo, hi, row, w);
-    const bool has_prev = s > 0, has_next = s + 1 < a.N;
+    const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
     uint64_t kp = 0, kn = 0;
     uint32_t pl = 1, ph = 0, nl = 1, nh = 0, r2;
     GWin w2;
@@ -748,6 +754,14 @@ static void grs_args(fbg_ctx *ctx, GrsArgs &a, int disable_tricks)
     a.pos = ctx->pos.as<uint32_t>(); a.tot = ctx->tot.as<uint32_t>();
     a.is_ignore = ctx->have_ignore ? ctx->small.as<uint8_t>() : nullptr;
     a.N = ctx->N; a.n = ctx->n; a.m = ctx->m;
+    if (ctx->part_active) {
+        a.own_lo = FBG_PART_HALO; a.own_hi = FBG_PART_HALO + ctx->part_count;
+        a.open_lo = ctx->part > 0; a.open_hi = ctx->part + 1 < ctx->nparts;
+        a.lim_lo = a.open_lo ? 0 : a.own_lo; a.lim_hi = a.open_hi ? a.own_hi + FBG_PART_HALO : a.own_hi;
+    } else {
+        a.own_lo = a.lim_lo = 0; a.own_hi = a.lim_hi = ctx->N;
+        a.open_lo = a.open_hi = 0;
+    }
     a.b = ctx->rk_b; a.K = ctx->rk_K; a.key_bits = ctx->rk_key_bits; a.disable_tricks = disable_tricks;
     a.ign_lo = ctx->grs_ign_lo; a.ign_hi = ctx->grs_ign_hi;
     a.t = 1;
@@ -812,8 +826,23 @@ static int grs_sort_and_runs(fbg_ctx *ctx, GrsArgs &a, uint64_t T, int *launches
     return FBG_OK;
 }
 
-// one pass over the slots, or over the listed ones (+ the long spans, the candidates' runs); *ok = 0: a capacity did not hold
-// (segcnt: the list is in stretches of GR_SEG, `count` of them, filled to segcnt[])
+// the scratch lists of a scan over `a`'s own slots
+static int grs_buffers(fbg_ctx *ctx, GrsArgs &a)
+{
+    const uint64_t own = a.own_hi - a.own_lo;
+    a.cand_cap = std::max<uint64_t>(own / 8, 1u << 20);
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_e, a.cand_cap * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_f, a.cand_cap * 8));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_g, a.cand_cap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)GR_LONG_CAP * 4));
+    a.cand = ctx->ps_e.as<unsigned long long>();
+    a.pm = ctx->ps_g.as<uint32_t>();
+    a.longs = ctx->ps_h.as<uint32_t>();
+    return FBG_OK;
+}
+
+// one pass over the own slots (list = nullptr), over a list, or over the stretches k_grs_classify filled (segcnt:
+// `count` stretches of GR_SEG) -- plus the long spans and the candidates' runs; *ok = 0: a capacity did not hold
 static int grs_pass(fbg_ctx *ctx, GrsArgs &a, const uint32_t *list, const uint32_t *segcnt, uint32_t count, int *ok, int *launches)
 {
     *ok = 0;
@@ -821,7 +850,7 @@ static int grs_pass(fbg_ctx *ctx, GrsArgs &a, const uint32_t *list, const uint32
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 3 * sizeof(unsigned long long), st));
     if (segcnt) hipLaunchKernelGGL(k_grs_scan_seg, dim3(count), dim3(GR_THREADS), 0, st, a, list, segcnt);
     else if (list) hipLaunchKernelGGL(k_grs_scan_list, dim3(fbg_blocks(count, GR_THREADS)), dim3(GR_THREADS), 0, st, a, list, count);
-    else hipLaunchKernelGGL(k_grs_scan_all, dim3(fbg_blocks(a.N, GR_THREADS)), dim3(GR_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(k_grs_scan_all, dim3(fbg_blocks(a.own_hi - a.own_lo, GR_THREADS)), dim3(GR_THREADS), 0, st, a);
     unsigned long long h[3];
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -832,108 +861,159 @@ static int grs_pass(fbg_ctx *ctx, GrsArgs &a, const uint32_t *list, const uint32
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 1;
-        if (h[0] > a.cand_cap) return FBG_OK;
+        if (h[1] != 0 || h[0] > a.cand_cap) return FBG_OK;
     }
-    if (h[0] > 0) FBG_TRY(grs_sort_and_runs(ctx, a, h[0], launches));
+    if (h[0] > 0) {
+        FBG_TRY(grs_sort_and_runs(ctx, a, h[0], launches));
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));     // (a run beyond a partition's halo)
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (h[1] != 0) return FBG_OK;
+    }
     *ok = 1;
     return FBG_OK;
 }
 
-// the scan proper on the kept slots, for one setting of the elastic tricks; *ok = 0: a capacity did not hold
+// the threshold from a sample of the own slots: at least ln(n) + 10 slots per column expected at or above it (a column
+// without any is redone afterwards); 1: none
+static int grs_pick_threshold(fbg_ctx *ctx, GrsArgs &a, uint32_t *t, int *launches)
+{
+    *t = 1;
+    hipStream_t st = ctx->stream;
+    const uint64_t own = a.own_hi - a.own_lo, N = ctx->N, n = ctx->n;
+    if (!ctx->grs_flagged || ctx->opt.gapped_rank == 3 || !(own > 4 * (uint64_t)GR_SAMPLE || ctx->opt.gapped_rank == 4) || own < 4) return FBG_OK;
+    unsigned long long *hist = a.counters + 8;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(hist, 0, 66 * sizeof(unsigned long long), st));
+    const uint64_t stride = std::max<uint64_t>(1, own / GR_SAMPLE);
+    hipLaunchKernelGGL(k_grs_sample, dim3(GR_SAMPLE / 256), dim3(256), 0, st, a, stride, hist);
+    unsigned long long hh[66];
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 1;
+    unsigned long long total = 0;
+    for (int g = 0; g < 66; g++) total += hh[g];
+    double need = (log((double)n) + 10.0) / ((double)N / (double)n);             // fraction of ALL the slots (every partition has its share)
+    if (ctx->opt.gapped_rank == 4) need = 0.05;                                    // tests: skip a lot whatever the shape
+    unsigned long long above = 0;
+    if (total > 0 && need < 0.5)
+        for (int g = 65; g >= 2; g--) {
+            above += hh[g];
+            if ((double)above >= need * (double)total) { *t = (uint32_t)g; break; }
+        }
+    return FBG_OK;
+}
+
+// the main pass with threshold a.t: classify + the listed slots, or every slot
+static int grs_main_pass(fbg_ctx *ctx, GrsArgs &a, int *ok, int *launches)
+{
+    if (a.t > 1) {
+        const uint32_t nseg = fbg_blocks(a.own_hi - a.own_lo, GR_SEG);
+        FBG_TRY(fbg_reserve(ctx, ctx->grp, (size_t)nseg * GR_SEG * 4));
+        FBG_TRY(fbg_reserve(ctx, ctx->flags, (size_t)nseg * 4));
+        hipLaunchKernelGGL(k_grs_classify, dim3(nseg), dim3(GR_THREADS), 0, ctx->stream, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
+        *launches += 1;
+        return grs_pass(ctx, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>(), nseg, ok, launches);
+    }
+    return grs_pass(ctx, a, nullptr, nullptr, 0, ok, launches);
+}
+
+// columns a skipped slot could still beat, given the largest threshold t any scan used -> ctx->xlist, *nc of them
+static int grs_unfilled(fbg_ctx *ctx, GrsArgs &a, uint32_t t, uint64_t *nc)
+{
+    *nc = 0;
+    if (t <= 1) return FBG_OK;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = ctx->n;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(n, 1u << 20);
+    FBG_TRY(fbg_reserve(ctx, ctx->xlist, (n + 1) * 4));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 3, 0, 8, st));
+    hipLaunchKernelGGL(k_grs_unfilled, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.fmax, n, t, (uint32_t)a.K, a.disable_tricks, ctx->xlist.as<uint32_t>(),
+                       cap, a.counters);
+    unsigned long long h = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&h, a.counters + 3, 8, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *nc = h;
+    return FBG_OK;
+}
+
+// the nc columns of ctx->xlist exactly, on top of the maxima in ctx->gmax: their rows' pointers -> hash set -> the own
+// slots that hold them -> the treatment of the main pass for those; too many for the set: every own slot again
+static int grs_redo(fbg_ctx *ctx, GrsArgs &a, uint64_t nc, int *ok, int *launches)
+{
+    *ok = 1;
+    if (nc == 0) return FBG_OK;
+    hipStream_t st = ctx->stream;
+    const uint64_t own = a.own_hi - a.own_lo;
+    if (nc * ctx->m > GR_HASH_FILL) {
+        a.t = 1;
+        return grs_pass(ctx, a, nullptr, nullptr, 0, ok, launches);
+    }
+    uint32_t hbits = 10;
+    while ((1ull << hbits) < 2 * nc * ctx->m) hbits++;
+    const uint32_t lcap = (uint32_t)(nc * ctx->m);
+    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)GR_HASH * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)lcap * 4));
+    uint32_t *set = ctx->list.as<uint32_t>(), *found = ctx->tie_list.as<uint32_t>();
+    FBG_HIP_TRY(ctx, hipMemsetAsync(set, 0xff, (size_t)4 << hbits, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 4, 0, 8, st));
+    hipLaunchKernelGGL(k_grs_pointers, dim3(fbg_blocks(nc * ctx->m, 256)), dim3(256), 0, st, a, ctx->xlist.as<uint32_t>(), (uint32_t)nc, set, hbits);
+    const size_t lds = (size_t)4 << hbits;
+    if (lds > 48 * 1024) FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_grs_find, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_grs_find, dim3(fbg_blocks(own, 256, 2048)), dim3(256), lds, st, a.vals + a.own_lo, a.vmask, own, (uint32_t)a.own_lo, set, hbits,
+                       found, lcap, a.counters);
+    unsigned long long nf = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&nf, a.counters + 4, 8, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 2;
+    if (nf > lcap) return fbg_fail(ctx, FBG_ERR_HIP, "gapped rank scan: %llu slots for %u row pointers", nf, lcap);
+    if (nf > 0) FBG_TRY(grs_pass(ctx, a, found, nullptr, (uint32_t)nf, ok, launches));
+    return FBG_OK;
+}
+
+// the scan proper on the kept slots of a whole index, for one setting of the elastic tricks; *ok = 0: a capacity did not hold
 static int grs_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
 {
     *ok = 0;
-    hipStream_t st = ctx->stream;
-    const uint64_t N = ctx->N, n = ctx->n;
     GrsArgs a;
     grs_args(ctx, a, disable_tricks);
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
-    a.cand_cap = std::max<uint64_t>(N / 8, 1u << 20);
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_e, a.cand_cap * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_f, a.cand_cap * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_g, a.cand_cap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)GR_LONG_CAP * 4));
-    a.cand = ctx->ps_e.as<unsigned long long>();
-    a.pm = ctx->ps_g.as<uint32_t>();
-    a.longs = ctx->ps_h.as<uint32_t>();
-    // the threshold: at least ln(n) + 10 slots per column expected at or above it (a column without any is redone below)
-    a.t = 1;
-    ctx->grs_redone = 0;
-    if (ctx->grs_flagged && ctx->opt.gapped_rank != 3 && (N > 4 * (uint64_t)GR_SAMPLE || ctx->opt.gapped_rank == 4)) {
-        unsigned long long *hist = a.counters + 8;
-        FBG_HIP_TRY(ctx, hipMemsetAsync(hist, 0, 66 * sizeof(unsigned long long), st));
-        const uint64_t stride = std::max<uint64_t>(1, N / GR_SAMPLE);
-        hipLaunchKernelGGL(k_grs_sample, dim3(GR_SAMPLE / 256), dim3(256), 0, st, a, stride, hist);
-        unsigned long long hh[66];
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        *launches += 1;
-        unsigned long long total = 0;
-        for (int g = 0; g < 66; g++) total += hh[g];
-        double need = (log((double)n) + 10.0) / ((double)N / (double)n);         // fraction of the slots
-        if (ctx->opt.gapped_rank == 4) need = 0.05;                                // tests: skip a lot whatever the shape
-        unsigned long long above = 0;
-        if (total > 0 && need < 0.5)
-            for (int g = 65; g >= 2; g--) {
-                above += hh[g];
-                if ((double)above >= need * (double)total) { a.t = (uint32_t)g; break; }
-            }
-    }
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (ctx->n + 1) * 4, ctx->stream));
+    FBG_TRY(grs_buffers(ctx, a));
+    FBG_TRY(grs_pick_threshold(ctx, a, &a.t, launches));
     ctx->grs_t = a.t;
-    if (a.t > 1) {
-        const uint32_t nseg = fbg_blocks(N, GR_SEG);
-        FBG_TRY(fbg_reserve(ctx, ctx->grp, (size_t)nseg * GR_SEG * 4));
-        FBG_TRY(fbg_reserve(ctx, ctx->flags, (size_t)nseg * 4));
-        hipLaunchKernelGGL(k_grs_classify, dim3(nseg), dim3(GR_THREADS), 0, st, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
-        *launches += 1;
-        FBG_TRY(grs_pass(ctx, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>(), nseg, ok, launches));
-    } else FBG_TRY(grs_pass(ctx, a, nullptr, nullptr, 0, ok, launches));
+    ctx->grs_redone = 0;
+    FBG_TRY(grs_main_pass(ctx, a, ok, launches));
     if (!*ok) return FBG_OK;
-    if (a.t > 1) {
-        // columns a skipped slot could still beat: exactly, from the pointers of their rows
-        const uint32_t cap = (uint32_t)std::min<uint64_t>(n, 1u << 20);
-        FBG_TRY(fbg_reserve(ctx, ctx->xlist, (n + 1) * 4));
-        FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)GR_HASH * 4));
-        uint32_t *cols = ctx->xlist.as<uint32_t>(), *set = ctx->list.as<uint32_t>();
-        FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 3, 0, 8, st));
-        hipLaunchKernelGGL(k_grs_unfilled, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a.fmax, n, a.t, (uint32_t)a.K, a.disable_tricks, cols, cap, a.counters);
-        unsigned long long nc = 0;
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(&nc, a.counters + 3, 8, hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        *launches += 1;
-        ctx->grs_redone = nc;
-        if (nc > 0 && nc * ctx->m <= GR_HASH_FILL) {
-            // their rows' pointers -> hash set -> the slots that hold them -> the exact treatment for those
-            uint32_t hbits = 10;
-            while ((1ull << hbits) < 2 * nc * ctx->m) hbits++;
-            const uint32_t lcap = (uint32_t)(nc * ctx->m);
-            FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)lcap * 4));
-            uint32_t *found = ctx->tie_list.as<uint32_t>();
-            FBG_HIP_TRY(ctx, hipMemsetAsync(set, 0xff, (size_t)4 << hbits, st));
-            FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 4, 0, 8, st));
-            hipLaunchKernelGGL(k_grs_pointers, dim3(fbg_blocks(nc * ctx->m, 256)), dim3(256), 0, st, a, cols, (uint32_t)nc, set, hbits);
-            const size_t lds = (size_t)4 << hbits;
-            if (lds > 48 * 1024) FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_grs_find, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_grs_find, dim3(fbg_blocks(N, 256, 2048)), dim3(256), lds, st, a.vals, a.vmask, N, set, hbits, found, lcap, a.counters);
-            unsigned long long nf = 0;
-            FBG_HIP_TRY(ctx, hipMemcpyAsync(&nf, a.counters + 4, 8, hipMemcpyDeviceToHost, st));
-            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-            *launches += 2;
-            if (nf > lcap) return fbg_fail(ctx, FBG_ERR_HIP, "gapped rank scan: %llu slots for %u row pointers", nf, lcap);
-            if (nf > 0) FBG_TRY(grs_pass(ctx, a, found, nullptr, (uint32_t)nf, ok, launches));
-        } else if (nc > 0) {
-            // too many for the set: everything again without the threshold
-            a.t = 1;
-            ctx->grs_t = 1;
-            FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
-            FBG_TRY(grs_pass(ctx, a, nullptr, nullptr, 0, ok, launches));
-        }
-        if (!*ok) return FBG_OK;
-    }
+    uint64_t nc = 0;
+    FBG_TRY(grs_unfilled(ctx, a, a.t, &nc));
+    ctx->grs_redone = nc;
+    FBG_TRY(grs_redo(ctx, a, nc, ok, launches));
+    if (!*ok) return FBG_OK;
     FBG_HIP_TRY(ctx, hipGetLastError());
     ctx->grs_tricks_off = disable_tricks;
-    *ok = 1;
     return FBG_OK;
+}
+
+// the ignore characters as a mask over symbol codes (the key's alphabet: ranks of the bytes that occur); false: not for this scan
+static bool grs_ignore_mask(fbg_ctx *ctx, uint64_t *by_code)
+{
+    *by_code = 0;
+    if (!ctx->have_ignore) return true;
+    int code = 0;
+    for (int c = 0; c < 256; c++) {
+        const bool occurs = ctx->byte_hist[c] != 0;
+        if (ctx->ignore_tab[c]) {
+            if (c == '-') return false;                                // gap cells that clamp: the record path's per-cell table
+            if (occurs) { if (code >= 64) return false; *by_code |= 1ull << code; }
+        }
+        if (occurs) code++;
+    }
+    return true;
+}
+
+static void grs_remember(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, uint64_t by_code)
+{
+    ctx->rk_keys = keys; ctx->sa_ptr = vals;
+    ctx->rk_layout = FBG_SLOTS_PAIRS; ctx->rk_pb = 0; ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
+    ctx->grs_ign_lo = (uint32_t)by_code; ctx->grs_ign_hi = (uint32_t)(by_code >> 32);
 }
 
 // Called by fbg_suffix_sort after the round-0 sort of the (key, position) pairs of an MSA with gaps / ignore characters
@@ -946,25 +1026,12 @@ int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, 
     const uint64_t N = ctx->N, n = ctx->n, m = ctx->m;
     if (N >= (1ull << 32) || m >= GW_IRREGULAR || g.compact || g.packed || g.wide || ctx->reversed) return FBG_OK;
     hipStream_t st = ctx->stream;
-    // the ignore characters as a mask over symbol codes (the key's alphabet: ranks of the bytes that occur)
     uint64_t by_code = 0;
-    if (ctx->have_ignore) {
-        int code = 0;
-        for (int c = 0; c < 256; c++) {
-            const bool occurs = ctx->byte_hist[c] != 0;
-            if (ctx->ignore_tab[c]) {
-                if (c == '-') return FBG_OK;                           // gap cells that clamp: the record path's per-cell table
-                if (occurs) { if (code >= 64) return FBG_OK; by_code |= 1ull << code; }
-            }
-            if (occurs) code++;
-        }
-    }
+    if (!grs_ignore_mask(ctx, &by_code)) return FBG_OK;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
     int launches = 0;
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
-    ctx->rk_keys = keys; ctx->sa_ptr = vals;
-    ctx->rk_layout = FBG_SLOTS_PAIRS; ctx->rk_pb = 0; ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
-    ctx->grs_ign_lo = (uint32_t)by_code; ctx->grs_ign_hi = (uint32_t)(by_code >> 32);
+    grs_remember(ctx, keys, vals, g, by_code);
     GrsArgs a;
     grs_args(ctx, a, 0);
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 6 * sizeof(unsigned long long), st));
@@ -984,12 +1051,147 @@ int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, 
     return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
 }
 
+// ---- key-range partitions of a multi-GPU job (suffix_sort.hip, fbg_part_sort; the contract: include/fbg_hip.h) --------
+// keys / vals: FBG_PART_HALO + count + FBG_PART_HALO slots, the middle sorted.  Equal keys never straddle partitions,
+// so tie groups are whole; what a partition cannot see is a run of coloured slots that goes on beyond the 64 edge slots
+// its neighbours publish (declined: every rank falls back together).
+__global__ void k_grs_halo_export(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t own_lo, uint64_t own_hi, uint64_t word,
+                                  uint8_t *__restrict__ blob)
+{
+    uint64_t *bk = reinterpret_cast<uint64_t *>(blob);
+    uint32_t *bv = reinterpret_cast<uint32_t *>(blob + 2 * FBG_PART_HALO * 8);
+    uint64_t *tail = reinterpret_cast<uint64_t *>(blob + 2 * FBG_PART_HALO * 12);
+    const uint32_t t = threadIdx.x;                    // 2 * FBG_PART_HALO threads: head slots, then tail slots
+    if (word & 1) {
+        const uint64_t k = t < FBG_PART_HALO ? own_lo + t : own_hi - 2 * FBG_PART_HALO + t;
+        bk[t] = keys[k]; bv[t] = vals[k];
+    } else { bk[t] = 0; bv[t] = 0; }
+    if (t == 0) { tail[0] = word; tail[1] = own_hi - own_lo; }
+}
+
+__global__ void k_grs_halo_import(const uint8_t *__restrict__ blobs, int part, int nparts, uint64_t own_hi, uint64_t *__restrict__ keys,
+                                  uint32_t *__restrict__ vals)
+{
+    const uint32_t t = threadIdx.x;                    // FBG_PART_HALO threads
+    if (part > 0) {                                    // tail of the previous partition -> slots [0, H)
+        const uint8_t *bl = blobs + (size_t)(part - 1) * FBG_PART_HALO_BYTES;
+        keys[t] = reinterpret_cast<const uint64_t *>(bl)[FBG_PART_HALO + t];
+        vals[t] = reinterpret_cast<const uint32_t *>(bl + 2 * FBG_PART_HALO * 8)[FBG_PART_HALO + t];
+    }
+    if (part + 1 < nparts) {                           // head of the next partition -> slots [own_hi, own_hi + H)
+        const uint8_t *bl = blobs + (size_t)(part + 1) * FBG_PART_HALO_BYTES;
+        keys[own_hi + t] = reinterpret_cast<const uint64_t *>(bl)[t];
+        vals[own_hi + t] = reinterpret_cast<const uint32_t *>(bl + 2 * FBG_PART_HALO * 8)[t];
+    }
+}
+
+// Phase 1 (fbg_part_index_build): the tie groups of the owned slots in text order, the threshold from a sample of them,
+// the edge slots published (d_blob; its tail word: bit 0 = this partition can go on, bits 8.. = its threshold).
+int fbg_grs_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int eligible, uint8_t *d_blob, int *ok)
+{
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
+    int launches = 0;
+    ctx->granked = false; ctx->ranked = false; ctx->gpart = true;
+    ctx->part_count = count;
+    uint64_t by_code = 0;
+    int good = eligible && count >= 2 * FBG_PART_HALO && ctx->N < (1ull << 32) && ctx->m < GW_IRREGULAR && grs_ignore_mask(ctx, &by_code);
+    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (ctx->n + 1) * 4));
+    grs_remember(ctx, keys, vals, g, by_code);
+    GrsArgs a;
+    grs_args(ctx, a, ctx->opt.part_tricks_off ? 1 : 0);
+    uint32_t t = 1;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 6 * sizeof(unsigned long long), st));
+    if (good) {
+        hipLaunchKernelGGL(k_grs_ties, dim3(fbg_blocks(count, 256)), dim3(256), 0, st, a);
+        launches++;
+        unsigned long long flag = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&flag, a.counters + 1, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (flag != 0) good = 0;
+    }
+    if (good) FBG_TRY(grs_pick_threshold(ctx, a, &t, &launches));
+    ctx->grs_t = t;
+    hipLaunchKernelGGL(k_grs_halo_export, dim3(1), dim3(2 * FBG_PART_HALO), 0, st, keys, vals, a.own_lo, a.own_hi, (uint64_t)good | ((uint64_t)t << 8), d_blob);
+    launches++;
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    *ok = good;
+    return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+}
+
+// Phase 2 (fbg_part_scan): halos in, the scan of the owned slots, their column maxima out (d_gmax: n + 1 words; word n =
+// 1 when a partition declined, so that the max-reduction carries the verdict).
+int fbg_grs_part_scan(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, int *ok)
+{
+    const uint64_t n = ctx->n;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
+    int launches = 0;
+    std::vector<uint8_t> hb((size_t)ctx->nparts * FBG_PART_HALO_BYTES);
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(hb.data(), d_blobs, hb.size(), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    int good = 1;
+    uint32_t t_all = 1;
+    for (int p = 0; p < ctx->nparts; p++) {
+        uint64_t tail[2];
+        memcpy(tail, hb.data() + (size_t)p * FBG_PART_HALO_BYTES + 2 * FBG_PART_HALO * 12, sizeof(tail));
+        if (!(tail[0] & 1)) good = 0;
+        t_all = std::max(t_all, (uint32_t)(tail[0] >> 8));
+    }
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    if (good) {
+        GrsArgs a;
+        grs_args(ctx, a, ctx->opt.part_tricks_off ? 1 : 0);
+        hipLaunchKernelGGL(k_grs_halo_import, dim3(1), dim3(FBG_PART_HALO), 0, st, d_blobs, ctx->part, ctx->nparts, a.own_hi, ctx->rk_keys, a.vals);
+        launches++;
+        FBG_TRY(grs_buffers(ctx, a));
+        a.t = ctx->grs_t;
+        FBG_TRY(grs_main_pass(ctx, a, &good, &launches));
+        ctx->grs_tricks_off = a.disable_tricks;
+    }
+    ctx->part_gmin = t_all;         // the unfilled test of fbg_part_finish goes by the largest threshold any partition used
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(d_gmax, ctx->gmax.p, (n + 1) * 4, hipMemcpyDeviceToDevice, st));
+    const uint32_t verdict = good ? 0u : 1u;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(d_gmax + n, &verdict, 4, hipMemcpyHostToDevice, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *ok = good;
+    return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+}
+
+// after the max-reduction (ctx->gmax holds the reduced maxima): the columns that have to be redone (the same list on every rank)
+int fbg_grs_part_unfilled(fbg_ctx *ctx, uint64_t *unfilled)
+{
+    GrsArgs a;
+    grs_args(ctx, a, ctx->grs_tricks_off);
+    FBG_TRY(grs_unfilled(ctx, a, ctx->part_gmin, unfilled));
+    ctx->grs_redone = *unfilled;
+    return FBG_OK;
+}
+
+// those columns exactly from this partition's slots, on top of the reduced maxima in ctx->gmax
+int fbg_grs_part_rescan(fbg_ctx *ctx)
+{
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
+    int launches = 0, ok = 1;
+    GrsArgs a;
+    grs_args(ctx, a, ctx->grs_tricks_off);
+    FBG_TRY(grs_buffers(ctx, a));
+    a.t = ctx->grs_t;
+    FBG_TRY(grs_redo(ctx, a, ctx->grs_redone, &ok, &launches));
+    ctx->part_gmin = 0;
+    ctx->grs_part_failed = !ok;
+    return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+}
+
 // f for columns [x0, x1) from the per-column maxima; the scan is redone first when it ran for the other setting of the
 // tricks.  *ok = 0: that second scan ran out of room -- the caller rebuilds the index the record way.
 int fbg_grs_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_out, int *ok)
 {
     *ok = 1;
     if ((disable_tricks != 0) != (ctx->grs_tricks_off != 0)) {
+        if (ctx->gpart)
+            return fbg_fail(ctx, FBG_ERR_INVALID, "the partitioned index of this MSA (gaps / ignore characters) was scanned %s the elastic tricks; "
+                            "set option part_tricks_off before fbg_part_index_build for the other setting", ctx->grs_tricks_off ? "without" : "with");
         int launches = 0;
         FBG_TRY(grs_scan(ctx, disable_tricks ? 1 : 0, ok, &launches));
         if (!*ok) return FBG_OK;

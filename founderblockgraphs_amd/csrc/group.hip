@@ -280,9 +280,10 @@ int pick_partitions(fbg_group *g, int *parts)
 // ---- plan: key-range partitioned index --------------------------------------------------------------------------
 // *done = 1: member 0 (every member when each holds one partition) is ready for fbg_scan_f / fbg_scan_v.
 // *done = 0: some partition declined; nothing usable.
-int plan_partitioned(fbg_group *g, int reversed, int *done)
+int plan_partitioned(fbg_group *g, int reversed, const uint8_t *ignore, uint64_t ignore_len, int disable_tricks, int *done)
 {
     *done = 0;
+    for (Member &mb : g->mem) mb.ctx->opt.part_tricks_off = disable_tricks ? 1 : 0;     // (MSAs with gaps / ignore characters: one setting per scan)
     const int nm = (int)g->mem.size();
     int P = 0;
     FBG_TRY(pick_partitions(g, &P));
@@ -302,7 +303,7 @@ int plan_partitioned(fbg_group *g, int reversed, int *done)
         for (int q = 0; q < k; q++) {
             const int p = i * k + q;
             int ok = 0;
-            FBG_TRY(fbg_part_index_build(mb.ctx, reversed, p, P, mb.blobs.as<uint8_t>() + (size_t)p * HB, &ok));
+            FBG_TRY(fbg_part_index_build_ignore(mb.ctx, reversed, p, P, ignore, ignore_len, mb.blobs.as<uint8_t>() + (size_t)p * HB, &ok));
             if (!ok) good[i] = 0;                          // the verdict travels in the blob as well
         }
         return fbg_sync(mb.ctx);
@@ -319,7 +320,7 @@ int plan_partitioned(fbg_group *g, int reversed, int *done)
             int ok = 0;
             if (k > 1) {
                 FBG_TRY(mem_reserve(g, mb, mb.pair, HB));
-                FBG_TRY(fbg_part_index_build(mb.ctx, reversed, p, P, mb.pair.p, &ok));
+                FBG_TRY(fbg_part_index_build_ignore(mb.ctx, reversed, p, P, ignore, ignore_len, mb.pair.p, &ok));
                 if (!ok) { good[i] = 0; break; }
             }
             FBG_TRY(fbg_part_scan(mb.ctx, mb.blobs.p, mb.gmax.as<uint32_t>(), &ok));
@@ -343,10 +344,13 @@ int plan_partitioned(fbg_group *g, int reversed, int *done)
             FBG_TRY(all_reduce_max(g, red, n + 1, 4));
             FBG_TRY(parallel(g, [&](int i) -> int { return fbg_part_finish(g->mem[i].ctx, (const uint32_t *)red(i), &verdict[i]); }));
         } else {
-            std::vector<int64_t> old(nm);
-            for (int i = 0; i < nm; i++) { old[i] = g->mem[i].ctx->opt.rank_no_threshold; g->mem[i].ctx->opt.rank_no_threshold = 1; }
-            const int rc = plan_partitioned(g, reversed, done);
-            for (int i = 0; i < nm; i++) g->mem[i].ctx->opt.rank_no_threshold = old[i];
+            std::vector<int64_t> old(nm), old_g(nm);
+            for (int i = 0; i < nm; i++) {
+                old[i] = g->mem[i].ctx->opt.rank_no_threshold; g->mem[i].ctx->opt.rank_no_threshold = 1;
+                old_g[i] = g->mem[i].ctx->opt.gapped_rank; if (old_g[i] == 0 || old_g[i] == 4) g->mem[i].ctx->opt.gapped_rank = 3;
+            }
+            const int rc = plan_partitioned(g, reversed, ignore, ignore_len, disable_tricks, done);
+            for (int i = 0; i < nm; i++) { g->mem[i].ctx->opt.rank_no_threshold = old[i]; g->mem[i].ctx->opt.gapped_rank = old_g[i]; }
             return rc;
         }
     }
@@ -432,9 +436,9 @@ int group_scan(fbg_group *g, int reversed, const uint8_t *ignore, uint64_t ignor
         // one context whose index fits: the plain path.  Otherwise partitions first
         plan = (nm == 1 && P == 1 && fits32) ? FBG_PLAN_COLUMNS : FBG_PLAN_PARTITIONED;
     }
-    if (plan == FBG_PLAN_PARTITIONED && ignore_len == 0) {
+    if (plan == FBG_PLAN_PARTITIONED) {
         int done = 0;
-        FBG_TRY(plan_partitioned(g, reversed, &done));
+        FBG_TRY(plan_partitioned(g, reversed, ignore, ignore_len, disable_tricks, &done));
         if (done) {
             Member &m0 = g->mem[0];
             if (reversed) FBG_TRY(fbg_scan_v(m0.ctx, 0, n, m0.f.as<uint64_t>()));

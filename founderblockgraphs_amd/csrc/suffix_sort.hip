@@ -1088,9 +1088,16 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     int launches = 0;
     const uint8_t *T = ctx->text.as<uint8_t>();
     KeyGeom g;
+    ctx->granked = false; ctx->gpart = false;
+    ctx->grs_ebits = nullptr; ctx->grs_flagged = false;
     int pre_ok = ctx->gapfree && !ctx->have_ignore && !ctx->opt.no_ranked;
     FBG_TRY(fbg_key_setup(ctx, pre_ok != 0, &g, &launches));
     pre_ok = pre_ok && g.compact;
+    // MSAs with gaps / ignore characters: the same partitioning on (key, position) pairs in the code of any alphabet,
+    // scanned by gapped_rank.hip
+    const bool gapped = (!ctx->gapfree || ctx->have_ignore) && !ctx->reversed && ctx->opt.gapped_rank != -1 && !g.compact && g.K <= 32 &&
+                        N < (1ull << 32);
+    if (gapped) FBG_TRY(fbg_grs_prepare(ctx, &launches));
     if (pre_ok) {
         // similar rows tie almost everywhere: not for the slot-level scan of the partitions (every rank draws the same
         // sample and declines alike); the caller builds the whole index, whose group-level scan is made for them
@@ -1106,11 +1113,11 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     if (S < 1024) S = N < 1024 ? N : 1024;
     const uint64_t stride = N / S;
     uint64_t lo = 0, hi = 0;
-    if (pre_ok && nparts > 1) {
+    if ((pre_ok || gapped) && nparts > 1) {
         FBG_TRY(fbg_reserve(ctx, ctx->dp_g, S * 8));
         FBG_TRY(fbg_reserve(ctx, ctx->dp_h, S * 8));
         uint64_t *smp = ctx->dp_g.as<uint64_t>(), *smp_sorted = ctx->dp_h.as<uint64_t>();
-        hipLaunchKernelGGL(k_sample_keys, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, T, N, g.d_code, g.b, g.K, 1, stride, S, smp);
+        hipLaunchKernelGGL(k_sample_keys, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, T, N, g.d_code, g.b, g.K, g.compact ? 1 : 0, stride, S, smp);
         FBG_TRY(with_tmp(ctx, [&](void *tmp, size_t &bytes) {
             return rocprim::radix_sort_keys(tmp, bytes, smp, smp_sorted, (size_t)S, 0u, (unsigned)g.key_bits, st);
         }));
@@ -1124,7 +1131,7 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     int msd_ok = 0;
     if (pre_ok)     // three passes over 12-byte slots, packing and filtering fused into the first (msd_sort_pairs.hip)
         FBG_TRY(fbg_msd_sort_part(ctx, g, lo, hi, part + 1 >= nparts, nparts, FBG_PART_HALO, &count, &msd_ok, &launches));
-    if (pre_ok && !msd_ok) {
+    if ((pre_ok || gapped) && !msd_ok) {
         unsigned long long *d_count = ctx->scalars.as<unsigned long long>() + 8;
         uint64_t cap = N / nparts + N / 8 + 65536;
         if (cap > N) cap = N;
@@ -1136,6 +1143,7 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
             pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = g.b; pa.K = g.K; pa.pb = g.pb;
             pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
             pa.lo = lo; pa.hi = hi; pa.cap = cap; pa.nohi = part + 1 >= nparts; pa.counter = d_count;
+            pa.ebits = gapped ? ctx->grs_ebits : nullptr;
             launch_pack(ctx, g, true, pa);
             launches++;
             unsigned long long hc = 0;
@@ -1149,9 +1157,12 @@ int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok)
     const uint64_t slots = count + 2 * FBG_PART_HALO;
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, slots * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsB, slots * 4));
-    if (pre_ok && !msd_ok && count > 0) FBG_TRY(sort_slots(ctx, g, count, FBG_PART_HALO));
+    if ((pre_ok || gapped) && !msd_ok && count > 0) FBG_TRY(sort_slots(ctx, g, count, FBG_PART_HALO));
+    ctx->grs_ebits = nullptr;
     FBG_HIP_TRY(ctx, hipGetLastError());
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches));
+    if (gapped)
+        return fbg_grs_part_classify(ctx, ctx->keysB.as<uint64_t>(), ctx->valsB.as<uint32_t>(), count, g, 1, d_blob, ok);
     return fbg_rank_part_classify(ctx, ctx->keysB.as<uint64_t>(), g.packed ? nullptr : ctx->valsB.as<uint32_t>(), count, g,
                                   pre_ok, d_blob, ok);
 }

@@ -137,14 +137,14 @@ def all_reduce_max(f_partial, group=None):
 #
 # Every rank holds the whole MSA but sorts and scans only the suffixes whose leading symbols fall into its key
 # range (include/fbg_hip.h, fbg_part_*).  Two collectives: an all-gather of the partitions' edge slots (1.5 KB
-# per rank) and an all-reduce(MAX) of the per-column maxima ((n + 1) * 4 bytes).  Gap-free MSAs without ignore
-# characters only; every rank learns from the collectives whether all partitions succeeded, so the fall-back
-# to the replicated index is taken by all ranks or none.
+# per rank) and an all-reduce(MAX) of the per-column maxima ((n + 1) * 4 bytes).  Every rank learns from the
+# collectives whether all partitions succeeded, so the fall-back to the replicated index is taken by all ranks or none.
 
-def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=False, device="cuda"):
+def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=False, device="cuda", ignorechars="", disable_efg_tricks=False):
     """Build the index of the engine's current MSA partitioned over the ranks.  True: the engine is ready for
     scan_f / scan_v (any column range, normally all of them on rank 0).  False: nothing usable was built --
-    call engine.index_build() on every rank instead."""
+    call engine.index_build() on every rank instead.  MSAs with gaps / ignore characters (ignorechars) are scanned for
+    the setting of the elastic tricks given here; scan_f must ask for the same."""
     from ._lib import PART_HALO_BYTES
     world = dist.get_world_size(group) if world is None else world
     rank = dist.get_rank(group) if rank is None else rank
@@ -169,7 +169,7 @@ def partitioned_index(engine, n, rank=None, world=None, group=None, reversed=Fal
     fence()
     error = None
     try:
-        engine.part_index_build(rank, world, blob.data_ptr(), reversed)   # verdict travels inside the blob
+        engine.part_index_build(rank, world, blob.data_ptr(), reversed, ignorechars, disable_efg_tricks)   # verdict travels inside the blob
     except Exception as e:          # noqa: BLE001
         error = e
         blob.zero_()

@@ -81,6 +81,7 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   rank_no_threshold  no extension threshold in the rank-order scan
  *   dp_literal, dp_wave, dp_tile, dp_safe_window   which sweep kernel runs the min-max-length / non-elastic DP
  *   gapped_rank        -1: MSAs with gaps / ignore characters always take the record path (no scan in suffix order)
+ *   part_tricks_off    1: the partitioned index of an MSA with gaps / ignore characters is scanned without the elastic tricks
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
  * gap-free MSA, 2 rank-order scan of an MSA with gaps / ignore characters, 3 one partition of a partitioned index.
  * Unknown key: FBG_ERR_INVALID.
@@ -203,6 +204,12 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
 #define FBG_PART_HALO 64
 #define FBG_PART_HALO_BYTES (2 * FBG_PART_HALO * 12 + 16)
 int fbg_part_index_build(fbg_ctx *ctx, int reversed, int part, int nparts, void *d_blob, int *ok);
+/* The same for MSAs with gaps and / or ignore characters (texts below 2^32 symbols, elastic scan): the partitions are
+ * scanned in suffix order like the whole index of such an MSA (gapped_rank.hip).  The scan of fbg_part_scan is for one
+ * setting of the elastic tricks -- option part_tricks_off, read at fbg_part_index_build -- and fbg_scan_f must ask for
+ * that one.  ignore_chars = NULL, ignore_len = 0: fbg_part_index_build. */
+int fbg_part_index_build_ignore(fbg_ctx *ctx, int reversed, int part, int nparts, const uint8_t *ignore_chars, uint64_t ignore_len,
+                                void *d_blob, int *ok);
 int fbg_part_scan(fbg_ctx *ctx, const void *d_blobs, uint32_t *d_gmax, int *ok);
 int fbg_part_finish(fbg_ctx *ctx, const uint32_t *d_gmax, int *ok);
 int fbg_part_rescan(fbg_ctx *ctx, uint32_t *d_gmax);

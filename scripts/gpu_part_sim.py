@@ -2,7 +2,8 @@
 are played one after the other; each partition's stage timers show what its rank would spend on a GPU of its own.
 Default: P contexts (as tests/test_gpu_parity.py::_partitioned does).  --sequential: one context only, each
 partition built twice (once for its edge slots, once more before its scan) -- for sizes where P contexts do not
-fit one GPU's memory.  Usage: gpu_part_sim.py P [cols_per_gpu] [--sequential]"""
+fit one GPU's memory.  --c5: BASELINE config 5 instead (256 x 2,000,000 with gaps and N, --ignore-chars=N; the same MSA
+whatever P: strong scaling).  Usage: gpu_part_sim.py P [cols_per_gpu] [--sequential] [--c5]"""
 import json
 import os
 import sys
@@ -17,10 +18,15 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 sequential = "--sequential" in sys.argv
 P = int(args[0])
 cols = int(args[1]) if len(args) > 1 else 1_000_000
-m, n = 1000, cols * P
+c5 = "--c5" in sys.argv
+m, n = (256, 2_000_000) if c5 else (1000, cols * P)
+ign = "N" if c5 else ""
 d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
 engines = [F.Engine() for _ in range(1 if sequential else P)]
-engines[0].msa_synthetic(d.data_ptr(), m, n)
+if c5:
+    engines[0].msa_synthetic(d.data_ptr(), m, n, gap_fraction=0.05, gap_run=16, n_fraction=0.001)
+else:
+    engines[0].msa_synthetic(d.data_ptr(), m, n)
 blobs = torch.zeros(P * PART_HALO_BYTES, dtype=torch.uint8, device="cuda")
 red = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
 gm = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
@@ -34,11 +40,11 @@ for it in range(1 if sequential else 2):
         e = engines[0]
         e.msa_set_device(d.data_ptr(), m, n)
         for r in range(P):
-            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, ignorechars=ign)
             e.sync()
         for r in range(P):
             t = time.perf_counter()
-            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, ignorechars=ign)
             assert e.part_scan(blobs.data_ptr(), gm.data_ptr())
             e.sync()
             wall[r] = time.perf_counter() - t
@@ -49,7 +55,7 @@ for it in range(1 if sequential else 2):
         for r, e in enumerate(engines):
             e.msa_set_device(d.data_ptr(), m, n)
             t = time.perf_counter()
-            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+            assert e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, ignorechars=ign)
             e.sync()
             wall[r] += time.perf_counter() - t
         for r, e in enumerate(engines):
@@ -74,7 +80,7 @@ for it in range(1 if sequential else 2):
         tail = time.perf_counter() - t
 for r in range(P):
     print(json.dumps({"part": r, "wall_ms": 1e3 * wall[r], "stages": stages[r]}))
-print(json.dumps({"P": P, "n": n, "text": m * (n + 1) + 1, "sequential": sequential, "blocks": blocks, "rank0_tail_ms": 1e3 * tail,
+print(json.dumps({"config": "C5 256 x 2,000,000 gaps + N" if c5 else "1000 rows, 10^6 columns per partition", "P": P, "n": n, "text": m * (n + 1) + 1, "sequential": sequential, "blocks": blocks, "rank0_tail_ms": 1e3 * tail,
                   "device_GB": engines[0].device_bytes() / 1e9,
                   "est_step_ms": 1e3 * (max(wall) + tail), "est_cols_per_s": n / (max(wall) + tail),
                   # bench.py runs the sweep of a step on a second stream beside the next step's index build

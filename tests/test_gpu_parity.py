@@ -432,7 +432,7 @@ def test_alternative_paths_stay_bit_identical(engine, env):
                 assert (bb is None) == (gbb is None) and (bb is None or np.array_equal(gbb, bb))
 
 
-def _partitioned(engines, n, reversed=False):
+def _partitioned(engines, n, reversed=False, ignorechars="", tricks_off=False):
     """fbg_part_* with the partitions of a multi-GPU job played by several contexts on one GPU: what
     distributed.partitioned_index does, with torch.cat / torch.maximum standing in for the two collectives.
     Returns the list of per-partition verdicts after each phase."""
@@ -442,7 +442,7 @@ def _partitioned(engines, n, reversed=False):
     blobs = torch.zeros(P * PART_HALO_BYTES, dtype=torch.uint8, device="cuda")
     gm = [torch.zeros(n + 1, dtype=torch.int32, device="cuda") for _ in range(P)]
     torch.cuda.synchronize()
-    ok1 = [e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, reversed) for r, e in enumerate(engines)]
+    ok1 = [e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, reversed, ignorechars, tricks_off) for r, e in enumerate(engines)]
     for e in engines:
         e.sync()
     ok2 = [e.part_scan(blobs.data_ptr(), gm[r].data_ptr()) for r, e in enumerate(engines)]
@@ -504,8 +504,8 @@ def test_partitioned_index_matches_oracle(P):
 
 
 def test_partitioned_index_declines_consistently():
-    """Inputs the partitioned path does not take (gaps, near-identical rows, tiny partitions): every partition
-    must report the same verdict after the collectives, and nothing may claim a usable index."""
+    """Inputs the partitioned path does not take (gaps while the scan in suffix order is switched off, near-identical rows,
+    tiny partitions): every partition must report the same verdict after the collectives, and nothing may claim a usable index."""
     import torch
     from founderblockgraphs_amd import Engine, FbgError
     rng = np.random.default_rng(77)
@@ -515,7 +515,10 @@ def test_partitioned_index_declines_consistently():
             msa = random_msa(rng, m, n, **kw)
             for e in engines:
                 e.msa_load_host(msa)
+                e.set_option("gapped_rank", -1 if "gap_p" in kw else 0)
             ok1, ok2, ok3 = _partitioned(engines, n)
+            for e in engines:
+                e.set_option("gapped_rank", 0)
             assert not any(ok2) and not any(ok3), (kw, ok1, ok2, ok3)
             d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
             with pytest.raises(FbgError):
@@ -1025,6 +1028,47 @@ def test_gapped_rank_scan_matches_oracle(engine, case):
     assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64)) and np.array_equal(gISA.astype(np.int64), ISA.astype(np.int64))
     assert np.array_equal(gPL.astype(np.int64), lcp_ext[ISA]) and np.array_equal(gPR.astype(np.int64), lcp_ext[ISA.astype(np.int64) + 1])
     assert np.array_equal(engine.gapped_v(msa), O.gapped_v(msa))       # segment2elasticValid: f without the tricks underneath
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5])
+def test_partitioned_gapped_index_matches_oracle(P):
+    """Key-range partitions of an MSA with gaps / ignore characters (fbg_part_index_build_ignore; the scan in suffix order
+    of gapped_rank.hip per partition, edge slots and column maxima exchanged): f with and without the elastic tricks,
+    with the threshold forced on (option gapped_rank=4: columns redone through fbg_part_rescan) and without."""
+    import torch
+    from founderblockgraphs_amd import Engine
+    rng = np.random.default_rng(8800 + P)
+    engines = [Engine() for _ in range(P)]
+    try:
+        cases = [(40, 700, dict(gap_p=0.02, gap_run=5, n_p=0.01), "N", False), (64, 400, dict(gap_p=0.05, gap_run=2), "", True),
+                 (12, 3000, dict(alphabet="AC", gap_p=0.01, gap_run=30), "", True), (130, 300, dict(n_p=0.03), "N", False),
+                 (30, 1500, dict(gap_p=0.005, gap_run=4, n_p=0.002), "N", True)]
+        took = 0
+        for forced in (0, 4):
+            for e in engines:
+                e.set_option("gapped_rank", forced)
+            for (m, n, kw, ign, long_gaps) in cases:
+                msa = random_msa(rng, m, n, **kw)
+                if long_gaps:
+                    msa = _long_gaps(rng, msa)
+                for e in engines:
+                    e.msa_load_host(msa)
+                for off in (False, True):
+                    ok1, ok2, ok3 = _partitioned(engines, n, ignorechars=ign, tricks_off=off)
+                    if not (all(ok1) and all(ok2) and all(ok3)):
+                        continue                          # declined (a partition of fewer than 128 slots, a run beyond the halo)
+                    took += 1
+                    want = O.compute_f(msa, ignore=ign, disable_tricks=off)
+                    d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+                    torch.cuda.synchronize()
+                    engines[P - 1].scan_f(0, n, d_f.data_ptr(), disable_efg_tricks=off)
+                    engines[P - 1].sync()
+                    got = d_f.cpu().numpy().astype(np.uint64)
+                    assert np.array_equal(got, want), (P, forced, m, n, kw, off, np.flatnonzero(got != want)[:8])
+        assert took >= 8
+    finally:
+        for e in engines:
+            e.close()
 
 
 def test_gapped_v_on_a_partitioned_index():

@@ -236,12 +236,11 @@ def test_c5_full_size_column_shards():
             cnt2 = eng.minmax_dp_device(whole.data_ptr(), n, d_b2.data_ptr(), d_mml2.data_ptr(), d_bt2.data_ptr())
         assert cnt2 == cnt and torch.equal(d_mml, d_mml2) and torch.equal(d_bt, d_bt2) and torch.equal(d_b[:cnt], d_b2[:cnt])
         del d_b2, d_mml2, d_bt2, shards
-    # the same through the group: 2 members on this one device (each holds a replicated index of ~60 GB; four of them
-    # are for four GPUs), column shards, one all-gather of f
+    # the same through the group: 2 members on this one device, each sorting and scanning half of the suffixes
     from founderblockgraphs_amd.api import device_view
     with F.Group([0, 0]) as grp:
         grp.msa_synthetic(m, n, gap_fraction=0.05, gap_run=16, n_fraction=0.001)
         p = grp.scan_f(ignorechars="N")
-        assert grp.plan_used()[0] == "columns"
+        assert grp.plan_used() == ("partitioned", 2)         # key-range partitions scanned in suffix order (gapped_rank.hip)
         torch.cuda.synchronize()
         assert torch.equal(device_view(p, n), whole)
