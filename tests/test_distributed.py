@@ -118,7 +118,7 @@ class _OraclePartEngine:
     def sync(self):
         pass
 
-    def part_index_build(self, part, nparts, blob_ptr, reversed=False):
+    def part_index_build(self, part, nparts, blob_ptr, reversed=False, ignorechars="", disable_efg_tricks=False):
         from founderblockgraphs_amd._lib import PART_HALO, PART_HALO_BYTES
         assert not reversed
         self.part, self.nparts = part, nparts
