@@ -88,16 +88,19 @@ while time.time() - t0 < budget:
         if not gaps:
             v = O.segment_v(msa)
             assert np.array_equal(eng.repeatfree_v(msa), v), "v"
-            # key-range partitions played by separate contexts
+        if not all(all(c == ord("-") for c in msa[i]) for i in range(m)):
+            # key-range partitions played by separate contexts (gaps / ignore characters: fbg_part_index_build_ignore)
             P = int(rng.integers(1, 4))
             es = parts[:P]
+            pign = ign if gaps or ign else ""
+            poff = tricks_off if (gaps or ign) else False
             blobs = torch.zeros(P * PART_HALO_BYTES, dtype=torch.uint8, device="cuda")
             gm = [torch.zeros(n + 1, dtype=torch.int32, device="cuda") for _ in range(P)]
             torch.cuda.synchronize()
             for e in es:
                 e.msa_load_host(msa)
             for r, e in enumerate(es):
-                e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES)
+                e.part_index_build(r, P, blobs.data_ptr() + r * PART_HALO_BYTES, False, pign, poff)
                 e.sync()
             for r, e in enumerate(es):
                 e.part_scan(blobs.data_ptr(), gm[r].data_ptr())
@@ -116,11 +119,13 @@ while time.time() - t0 < budget:
                     red = torch.maximum(red, x)
                 torch.cuda.synchronize()
                 vd = [e.part_finish(red.data_ptr()) for e in es]
+                assert len(set(vd)) == 1, f"verdicts after the re-scan {vd}"
             if vd[0] == 1:
                 d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
                 torch.cuda.synchronize()
-                es[0].scan_f(0, n, d_f.data_ptr()); es[0].sync()
-                assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), O.compute_f(msa)), "partitioned f"
+                es[0].scan_f(0, n, d_f.data_ptr(), disable_efg_tricks=poff); es[0].sync()
+                want = O.compute_f(msa, ignore=pign, disable_tricks=poff)
+                assert np.array_equal(d_f.cpu().numpy().astype(np.uint64), want), f"partitioned f (P={P})"
     except Exception as ex:      # noqa: BLE001
         print("MISMATCH", tag, repr(ex), flush=True)
         sys.exit(1)
