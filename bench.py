@@ -234,8 +234,8 @@ def measured_traffic(m, n, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1000)
     ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample-cols", type=int, default=40_000)

@@ -93,6 +93,7 @@ struct fbg_ctx {
     DevBuf gbits;                  // 1 bit per text position: not the column after its predecessor's
     const uint64_t *grs_ebits = nullptr;   // gbits while the pack kernels are to fold it into bit 31 of the sort's values
     bool grs_flagged = false;      // the sorted values carry that bit
+    bool grs_ties_done = false;    // the tie groups of the kept slots are in text order
     bool gpart = false;            // one key-range partition of such an index (fbg_part_*)
     bool grs_part_failed = false;  // its exact redo of a few columns ran out of room
     uint32_t grs_t = 1;            // the threshold of the last scan (1: none), the columns it redid exactly

@@ -53,6 +53,7 @@
 #define GR_HASH (1u << 15)           // slots of the position set of the columns that are redone (LDS, 128 KB)
 #define GR_HASH_FILL (GR_HASH / 2)
 #define GR_EMPTY 0xffffffffu
+#define GR_HEAD 0x80000000u          // k_grs_classify's list: the slot is the first of a tie group (texts below 2^31 symbols)
 
 struct GWin {                        // window of GW text positions
     uint32_t col0;                   // MSA column of its first position
@@ -82,7 +83,7 @@ struct GrsArgs {
     uint32_t *pm;                    // scratch parallel to cand
     unsigned long long cand_cap;
     uint32_t *longs;                 // slots with long spans
-    unsigned long long *counters;    // [0] candidates, [1] decline flag, [2] long slots, [3] columns to redo, [4] their slots, [5] listed slots
+    unsigned long long *counters;    // [0] candidates, [1] decline flag, [2] long slots, [3] columns to redo, [4] their slots, [6] long runs
 };
 
 __device__ __forceinline__ uint32_t gr_key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
@@ -191,10 +192,26 @@ __global__ __launch_bounds__(256) void k_gw_build(const uint32_t *__restrict__ c
     GWin &e = out[threadIdx.x >> 6];
     if (lane == 0) {
         e.col0 = c0; e.off[0] = e.off[1] = 0; e.len[0] = e.len[1] = 0; e.row = GW_IRREGULAR; e.lo0 = 0;
-        if (!irregular) {
-            const uint32_t row = gr_row_of(pos, m, (uint32_t)w0);
-            e.row = (uint16_t)row;
-            e.lo0 = pos[row] == (uint32_t)w0 ? 0u : cp0 + 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!irregular) {
+        // the window's row: the last row that starts at or before w0.  All lanes probe (64 probes narrow the range 65 times:
+        // two or three rounds of one load each; lane 0 searching alone -- eight dependent loads per window -- was most of this kernel)
+        uint32_t lo = 0, hi = m;                                       // answer in [lo, hi)
+        while (hi - lo > 1) {
+            const uint32_t span = hi - lo;
+            const uint32_t q = lo + 1 + (uint32_t)(((uint64_t)lane * (span - 1)) / 64);      // lo + 1 .. hi - 1, ascending in the lane
+            const unsigned long long le = __ballot(pos[q] <= (uint32_t)w0);                  // true for a prefix of the lanes
+            const uint32_t cnt = (uint32_t)__popcll(le);
+            const uint32_t q_last_true = lo + 1 + (uint32_t)(((uint64_t)(cnt ? cnt - 1 : 0) * (span - 1)) / 64);
+            const uint32_t q_first_false = lo + 1 + (uint32_t)(((uint64_t)cnt * (span - 1)) / 64);
+            const uint32_t nlo = cnt ? q_last_true : lo, nhi = cnt < 64 ? q_first_false : hi;
+            if (nlo == lo && nhi == hi) break;                          // (span - 1 < 64: the probes covered every candidate)
+            lo = nlo; hi = nhi;
+        }
+        if (lane == 0) {
+            e.row = (uint16_t)lo;
+            e.lo0 = pos[lo] == (uint32_t)w0 ? 0u : cp0 + 1;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -220,14 +237,11 @@ __global__ void k_grs_ebits_gapfree(uint64_t N, uint64_t n, uint64_t words, unsi
     ebits[w] = e;
 }
 
-// tie groups (equal keys) in text order: insertion sort by the text beyond the key, values rewritten in place
-__global__ void k_grs_ties(GrsArgs a)
+// the tie group (equal keys) that starts at slot k0 in text order: insertion sort by the text beyond the key, values
+// rewritten in place
+__device__ __forceinline__ void gr_order_group(const GrsArgs &a, uint64_t k0)
 {
-    const uint64_t k0 = a.own_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (equal keys never straddle partitions)
-    if (k0 + 1 >= a.own_hi) return;
     const uint64_t key = a.keys[k0];
-    if (a.keys[k0 + 1] != key) return;
-    if (k0 > a.own_lo && a.keys[k0 - 1] == key) return;
     uint32_t s = 2;
     while (k0 + s < a.own_hi && s <= GR_MAX_TIE && a.keys[k0 + s] == key) s++;
     if (s > GR_MAX_TIE) { a.counters[1] = 1; return; }
@@ -244,6 +258,17 @@ __global__ void k_grs_ties(GrsArgs a)
         }
         a.vals[k0 + j] = cur;
     }
+}
+
+// every tie group of the own slots (one streaming pass over the keys: the partitions, and scans without a threshold)
+__global__ void k_grs_ties(GrsArgs a)
+{
+    const uint64_t k0 = a.own_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (equal keys never straddle partitions)
+    if (k0 + 1 >= a.own_hi) return;
+    const uint64_t key = a.keys[k0];
+    if (a.keys[k0 + 1] != key) return;
+    if (k0 > a.own_lo && a.keys[k0 - 1] == key) return;
+    gr_order_group(a, k0);
 }
 
 // LCP of the suffixes in slots k - 1 and k (final order)
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const ui
     for (uint32_t r = 0; r < cnt; r += GR_THREADS) {
         const uint32_t i = r + threadIdx.x;
         const bool in = i < cnt;
-        const uint64_t s = in ? mine[i] : 0;
+        const uint64_t s = in ? (mine[i] & ~GR_HEAD) : 0;
         uint64_t key = 0, kp = 0, kn = 0, k2p = 0, k2n = 0;
         if (in) {
             key = a.keys[s];
@@ -537,10 +562,28 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t
         uint32_t at = 0;
         if (lane == 0 && mask) at = atomicAdd(&fill, (uint32_t)__popcll(mask));
         at = __shfl(at, 0, 64) + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-        if (work) mine[at] = (uint32_t)s;
+        if (work) mine[at] = (uint32_t)s | ((tie && !(has_prev && kp == key)) ? GR_HEAD : 0u);   // first slot of a tie group
     }
     __syncthreads();
     if (threadIdx.x == 0) segcnt[blockIdx.x] = fill;
+}
+
+// the tie groups whose first slots k_grs_classify marked, put in text order: the marked entries of a stretch gathered
+// in LDS, then one lane per group
+__global__ __launch_bounds__(GR_THREADS) void k_grs_ties_listed(GrsArgs a, uint32_t *__restrict__ list, const uint32_t *__restrict__ segcnt)
+{
+    __shared__ uint32_t heads[GR_SEG / 2];
+    __shared__ uint32_t nheads;
+    if (threadIdx.x == 0) nheads = 0;
+    __syncthreads();
+    const uint32_t cnt = segcnt[blockIdx.x];
+    uint32_t *mine = list + (uint64_t)blockIdx.x * GR_SEG;
+    for (uint32_t i = threadIdx.x; i < cnt; i += GR_THREADS) {
+        const uint32_t e = mine[i];
+        if (e & GR_HEAD) { heads[atomicAdd(&nheads, 1u)] = e & ~GR_HEAD; mine[i] = e & ~GR_HEAD; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nheads; i += GR_THREADS) gr_order_group(a, heads[i]);
 }
 
 // second pass: the slots whose position is in the set (LDS copy; hbits = log2 of its size)
@@ -637,8 +680,11 @@ __global__ void k_grs_runs_lcp(GrsArgs a, uint64_t T, uint32_t *__restrict__ lcp
     lcpR[t] = gr_slot_lcp(a, s + 1);
 }
 
-// gq[t] (= a.pm): g of the entry, 0 for the repeats of an entry
-__global__ void k_grs_runs_walk(GrsArgs a, uint64_t T, const uint32_t *__restrict__ lcpL, const uint32_t *__restrict__ lcpR)
+// gq[t] (= a.pm): g of the entry, 0 for the repeats of an entry.  A run of more than GR_RUN_SERIAL entries is left to
+// k_grs_runs_long (its head's index goes to `longs`: the row ends' suffixes form runs of hundreds).
+#define GR_RUN_SERIAL 48
+__global__ void k_grs_runs_walk(GrsArgs a, uint64_t T, const uint32_t *__restrict__ lcpL, const uint32_t *__restrict__ lcpR, uint32_t *__restrict__ longs,
+                                uint32_t longs_cap)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -654,6 +700,10 @@ __global__ void k_grs_runs_walk(GrsArgs a, uint64_t T, const uint32_t *__restric
         if (nx != cu + 1) break;
         tt++;
         run = min(run, lcpL[tt]);
+        if (tt - t >= GR_RUN_SERIAL) {
+            const unsigned long long at = atomicAdd(&a.counters[6], 1ull);
+            if (at < longs_cap) { longs[at] = (uint32_t)t; return; }
+        }
     }
     uint32_t rmin = 0xffffffffu;
     for (;;) {
@@ -663,6 +713,54 @@ __global__ void k_grs_runs_walk(GrsArgs a, uint64_t T, const uint32_t *__restric
         a.pm[tt] = g;
         if (tt == t) break;
         tt--;
+    }
+}
+
+// one wave per long run: the same two passes, 64 entries at a time
+__global__ __launch_bounds__(64) void k_grs_runs_long(GrsArgs a, uint64_t T, const uint32_t *__restrict__ lcpL, const uint32_t *__restrict__ lcpR,
+                                                      const uint32_t *__restrict__ longs)
+{
+    const uint64_t t0 = longs[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    // forward: the run's end, pm = running minimum of lcpL over the slots (a repeat shares its slot's value)
+    uint64_t end = t0;                                                 // one past the run's last entry
+    uint32_t carry = 0xffffffffu;
+    unsigned long long prev_last = 0;
+    for (uint64_t c = t0;; c += 64) {
+        const uint64_t i = c + lane;
+        const bool in = i < T;
+        const unsigned long long e = in ? a.cand[i] : 0ull;
+        unsigned long long ep = __shfl_up(e, 1, 64);
+        if (lane == 0) ep = prev_last;
+        const bool cont = in && (i == t0 || e == ep || e == ep + 1);
+        const unsigned long long ok = __ballot(cont);
+        const uint32_t len = ok == ~0ull ? 64u : (uint32_t)__ffsll((long long)~ok) - 1;      // leading entries that belong to the run
+        uint32_t v = lane < len ? lcpL[i] : 0xffffffffu;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if ((int)lane >= d) v = min(v, o); }
+        v = min(v, carry);
+        if (lane < len) a.pm[i] = v;
+        end = c + len;
+        if (len < 64) break;
+        carry = __shfl(v, 63, 64);
+        prev_last = __shfl(e, 63, 64);
+    }
+    // backward: suffix minimum of lcpR; g for the first entry of every slot's group of repeats, 0 for the others
+    carry = 0xffffffffu;
+    for (uint64_t hi = end; hi > t0;) {
+        const uint64_t lo = hi - t0 >= 64 ? hi - 64 : t0;
+        const uint32_t len = (uint32_t)(hi - lo);
+        const uint64_t i = lo + lane;
+        uint32_t v = lane < len ? lcpR[i] : 0xffffffffu;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(v, d, 64); if ((int)lane + d < 64) v = min(v, o); }
+        v = min(v, carry);
+        if (lane < len) {
+            const bool first = i == t0 || a.cand[i - 1] != a.cand[i];
+            a.pm[i] = first ? max(a.pm[i], v) + 1 : 0u;
+        }
+        carry = __shfl(v, 0, 64);
+        hi = lo;
     }
 }
 
@@ -819,10 +917,17 @@ static int grs_sort_and_runs(fbg_ctx *ctx, GrsArgs &a, uint64_t T, int *launches
     uint32_t *lcpL = reinterpret_cast<uint32_t *>(unsorted), *lcpR = lcpL + a.cand_cap;     // the unsorted list is done with
     a.cand = sorted;
     hipLaunchKernelGGL(k_grs_runs_lcp, dim3(fbg_blocks(T, 256)), dim3(256), 0, st, a, T, lcpL, lcpR);
-    hipLaunchKernelGGL(k_grs_runs_walk, dim3(fbg_blocks(T, 64)), dim3(64), 0, st, a, T, lcpL, lcpR);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 6, 0, 8, st));
+    uint32_t *long_runs = a.longs;                                     // (k_grs_long is done with the list)
+    hipLaunchKernelGGL(k_grs_runs_walk, dim3(fbg_blocks(T, 64)), dim3(64), 0, st, a, T, lcpL, lcpR, long_runs, (uint32_t)GR_LONG_CAP);
+    unsigned long long nlong = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&nlong, a.counters + 6, 8, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (nlong > GR_LONG_CAP) nlong = GR_LONG_CAP;                     // (the heads beyond the list walked their runs themselves)
+    if (nlong > 0) hipLaunchKernelGGL(k_grs_runs_long, dim3((unsigned)nlong), dim3(64), 0, st, a, T, lcpL, lcpR, long_runs);
     hipLaunchKernelGGL(k_grs_runs_apply, dim3(fbg_blocks(T, 256)), dim3(256), 0, st, a, T);
     a.cand = unsorted;
-    *launches += 4;
+    *launches += 5;
     return FBG_OK;
 }
 
@@ -902,16 +1007,39 @@ static int grs_pick_threshold(fbg_ctx *ctx, GrsArgs &a, uint32_t *t, int *launch
     return FBG_OK;
 }
 
-// the main pass with threshold a.t: classify + the listed slots, or every slot
-static int grs_main_pass(fbg_ctx *ctx, GrsArgs &a, int *ok, int *launches)
+// the main pass with threshold a.t: classify + the listed slots, or every slot.  order_ties: the tie groups are not in
+// text order yet (the classification marks their first slots; without one, a pass of its own finds them).
+static int grs_main_pass(fbg_ctx *ctx, GrsArgs &a, bool order_ties, int *ok, int *launches)
 {
+    hipStream_t st = ctx->stream;
+    *ok = 0;
+    auto ties_fit = [&](bool *fit) -> int {        // a tie group of more than GR_MAX_TIE suffixes raises counters[1]
+        unsigned long long flag = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&flag, a.counters + 1, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        *fit = flag == 0;
+        return FBG_OK;
+    };
+    bool fit = true;
     if (a.t > 1) {
         const uint32_t nseg = fbg_blocks(a.own_hi - a.own_lo, GR_SEG);
         FBG_TRY(fbg_reserve(ctx, ctx->grp, (size_t)nseg * GR_SEG * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->flags, (size_t)nseg * 4));
-        hipLaunchKernelGGL(k_grs_classify, dim3(nseg), dim3(GR_THREADS), 0, ctx->stream, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
+        hipLaunchKernelGGL(k_grs_classify, dim3(nseg), dim3(GR_THREADS), 0, st, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
         *launches += 1;
+        if (order_ties) {
+            hipLaunchKernelGGL(k_grs_ties_listed, dim3(nseg), dim3(GR_THREADS), 0, st, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
+            *launches += 1;
+            FBG_TRY(ties_fit(&fit));
+        }
+        if (!fit) return FBG_OK;
         return grs_pass(ctx, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>(), nseg, ok, launches);
+    }
+    if (order_ties) {
+        hipLaunchKernelGGL(k_grs_ties, dim3(fbg_blocks(a.own_hi - a.own_lo, 256)), dim3(256), 0, st, a);
+        *launches += 1;
+        FBG_TRY(ties_fit(&fit));
+        if (!fit) return FBG_OK;
     }
     return grs_pass(ctx, a, nullptr, nullptr, 0, ok, launches);
 }
@@ -980,8 +1108,9 @@ static int grs_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     FBG_TRY(grs_pick_threshold(ctx, a, &a.t, launches));
     ctx->grs_t = a.t;
     ctx->grs_redone = 0;
-    FBG_TRY(grs_main_pass(ctx, a, ok, launches));
+    FBG_TRY(grs_main_pass(ctx, a, !ctx->grs_ties_done, ok, launches));
     if (!*ok) return FBG_OK;
+    ctx->grs_ties_done = true;
     uint64_t nc = 0;
     FBG_TRY(grs_unfilled(ctx, a, a.t, &nc));
     ctx->grs_redone = nc;
@@ -1035,13 +1164,9 @@ int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, 
     GrsArgs a;
     grs_args(ctx, a, 0);
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 6 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_grs_ties, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a);
-    launches++;
-    unsigned long long flag = 0;
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(&flag, a.counters + 1, 8, hipMemcpyDeviceToHost, st));
-    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    ctx->grs_ties_done = false;                    // (the tie groups are put in text order by the first scan)
     int ok = 0;
-    if (flag == 0) FBG_TRY(grs_scan(ctx, 0, &ok, &launches));
+    FBG_TRY(grs_scan(ctx, 0, &ok, &launches));
     if (ok) {
         ctx->granked = true;
         ctx->ranked = false;
@@ -1146,7 +1271,7 @@ int fbg_grs_part_scan(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, in
         launches++;
         FBG_TRY(grs_buffers(ctx, a));
         a.t = ctx->grs_t;
-        FBG_TRY(grs_main_pass(ctx, a, &good, &launches));
+        FBG_TRY(grs_main_pass(ctx, a, false, &good, &launches));
         ctx->grs_tricks_off = a.disable_tricks;
     }
     ctx->part_gmin = t_all;         // the unfilled test of fbg_part_finish goes by the largest threshold any partition used
