@@ -50,7 +50,38 @@ struct PpArgs {
     uint64_t top;                              // MODE 1: 2^key_bits, the end of the last sub-bucket's key range
     int sigma;                                 // MODE 1: number of symbol codes in use (codes are 0 .. sigma - 1)
     const uint64_t *ebits;                     // pairs: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
+    // MODE 1 finish: bins from the symbols behind the prefix a sub-bucket's keys share, every symbol code replaced by its
+    // rank among the FREQUENT symbols (rb bits; 0: bins from sampled keys instead).  rtab: ew bits per code = the rank;
+    // mtab: 2 bits per code = 0 a frequent symbol, 1 / 2 a rare one below / above the frequent symbol whose rank it shares
+    uint64_t rtab, mtab;
+    int rb, ew, nd, key_bits;
 };
+
+// The bin of a key in the finish of the sample sort (MODE 1), sub-bucket keys in [glo, ghi].  The nd symbols from symbol
+// cp on (the symbols before are the same in glo and ghi, hence in every key between), each as its rank among the frequent
+// symbols, read as one number: for a random text those numbers are spread evenly where the keys themselves are not (the
+// 3-bit codes of a 4-letter text use 4 of 8 values per digit), so a sub-bucket's keys fill the range between the
+// numbers of glo and ghi evenly and the bin is (number - number(glo)) >> shift.  Monotone in the key: a rare symbol
+// ends the number (the remaining digits all 0 when it sorts below the frequent symbol it shares the rank with, all ones
+// when above).  nd * rb = 30 bits: 18 for the 2^18 sub-buckets, 12 to cut one into bins.
+__device__ __forceinline__ uint64_t pp_rank_number(const PpArgs &a, uint64_t key, int cp)
+{
+    const uint32_t dmask = (1u << a.b) - 1, emask = (1u << a.ew) - 1, full = (1u << a.rb) - 1;
+    uint64_t num = 0;
+    uint32_t stop = 0;
+#pragma unroll 5
+    for (int i = 0; i < a.nd; i++) {
+        const int sym = cp + i;
+        uint32_t digit = 0;
+        if (stop == 0 && sym < a.K) {
+            const uint32_t d = (uint32_t)(key >> (a.b * (a.K - 1 - sym))) & dmask;
+            digit = (uint32_t)(a.rtab >> (a.ew * d)) & emask;
+            stop = (uint32_t)(a.mtab >> (2 * d)) & 3u;
+        } else if (stop == 2) digit = full;
+        num = (num << a.rb) | digit;
+    }
+    return num;
+}
 
 // t < 2^28: bucket (9 bits), sub-bucket (9 bits), finish bin (10 bits)
 __device__ __forceinline__ uint32_t pp_t28(const PpArgs &a, uint64_t word) { return (uint32_t)__umul64hi((word >> a.pb) - a.lo, a.mul); }
@@ -291,7 +322,7 @@ template <int CAP, int MODE>
 __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t *loff, uint32_t *wsum,
                                                const uint64_t *wa, const uint32_t *va, uint32_t n_a, const uint64_t *wb,
                                                const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint64_t *smp, uint64_t *srt,
-                                               uint32_t *place)
+                                               uint32_t *place, uint32_t sb)
 {
     constexpr int ITEMS = CAP / PP_THREADS;
     // MODE 1: the keys of a sub-bucket follow no formula (they cluster at the two ends of its key range, deep below the
@@ -299,7 +330,18 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     // boundaries (the slots arrive in no particular order: every (have / PP_SMP)-th is a fair sample) and a slot's bin
     // is the number of boundaries not above its key (binary search in LDS).  The loads happen below; the sample is
     // taken from a staged copy of the keys in sw.
+    int cp = 0, bshift = 0;
+    uint64_t base = 0;
+    if (MODE == 1 && a.rb > 0) {
+        const uint64_t glo = sb ? a.grid[sb] : 0ull, ghi = (sb + 1 < (uint32_t)(PP_NB * PP_NB) ? a.grid[sb + 1] : a.top) - 1;
+        const uint64_t x = glo ^ ghi;
+        cp = (x == 0 || ghi < glo) ? a.K : (int)((uint32_t)(__clzll((long long)x) - (64 - a.key_bits)) / (uint32_t)a.b);
+        base = pp_rank_number(a, glo, cp);
+        const uint64_t span = pp_rank_number(a, ghi, cp) - base;          // the largest difference a key of the sub-bucket can show
+        bshift = span >= PP_FBINS ? 64 - __clzll((long long)span) - 10 : 0;
+    }
     auto bin_of = [&](uint64_t word) -> uint32_t {
+        if (MODE == 1 && a.rb > 0) return (uint32_t)((pp_rank_number(a, word >> a.pb, cp) - base) >> bshift);
         if (MODE == 1) {
             // PP_SMP boundaries -> PP_SMP + 1 stretches; a stretch between two boundaries is cut into 8 more bins
             // linearly in the key (float arithmetic: monotone), which thins the bins out wherever the keys of the
@@ -329,7 +371,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         w[r] = j < have ? (j < n_a ? wa[j] : wb[j - n_a]) : ~0ull;
         v[r] = (j < have && !a.packed) ? (j < n_a ? va[j] : vb[j - n_a]) : 0u;
     }
-    if (MODE == 1) {
+    if (MODE == 1 && a.rb == 0) {
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const uint32_t j = threadIdx.x + r * PP_THREADS;
@@ -410,21 +452,31 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     }
 }
 
-template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a)
+// CAP: slots the workgroup has room for in LDS -- PP_FN_CAP (the stretch of a sub-bucket), or PP_FN_SMALL for the
+// sub-buckets that hold no more than that (a text of 5 * 10^8 symbols fills a stretch to 40 %: with the smaller arrays
+// four workgroups share a CU instead of two and the per-thread loops are half as long); a launch of each
+#define PP_FN_SMALL 3072
+// list = nullptr: one workgroup per sub-bucket, those beyond CAP (up to the stretch) noted in `later`; else the listed ones
+template <int MODE, int CAP> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a, const uint32_t *__restrict__ list, uint32_t *__restrict__ later,
+                                                                                       unsigned long long *__restrict__ later_count)
 {
-    __shared__ uint64_t sw[PP_FN_CAP];
-    __shared__ uint32_t sv[PP_FN_CAP];
+    __shared__ uint64_t sw[CAP];
+    __shared__ uint32_t sv[CAP];
     __shared__ uint32_t cnt[PP_FBINS], loff[PP_FBINS];
     __shared__ uint32_t wsum[PP_THREADS / 64];
-    const uint32_t have = a.count2[blockIdx.x];
+    const uint32_t sb = list ? list[blockIdx.x] : blockIdx.x;
+    const uint32_t have = a.count2[sb];
     if (have == 0 || have > PP_FN_CAP) return;                 // the larger ones: k_pp_finish_big
-    const uint64_t *wa = a.w2 + (uint64_t)blockIdx.x * PP_FN_CAP;
-    const uint32_t *va = a.v2 + (uint64_t)blockIdx.x * PP_FN_CAP;
+    if (have > CAP) {                                          // uniform
+        if (threadIdx.x == 0 && later) later[atomicAdd(later_count, 1ull)] = sb;
+        return;
+    }
+    const uint64_t *wa = a.w2 + (uint64_t)sb * PP_FN_CAP;
+    const uint32_t *va = a.v2 + (uint64_t)sb * PP_FN_CAP;
     __shared__ uint64_t smp[MODE == 1 ? PP_SMP + 1 : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
     __shared__ uint32_t place[MODE == 1 ? PP_SMP + 1 : 1];
     if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
-    pp_finish_body<PP_FN_CAP, MODE>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[blockIdx.x], a.vout + a.off[blockIdx.x],
-                                    smp, srt, place);
+    pp_finish_body<CAP, MODE>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place, sb);
 }
 
 template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
@@ -446,7 +498,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_bi
     __shared__ uint32_t place[MODE == 1 ? PP_SMP + 1 : 1];
     if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
     pp_finish_body<PP_BIG_CAP, MODE>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
-                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place);
+                                     gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place, sb);
 }
 
 __global__ void k_pp_gather(const uint32_t *__restrict__ idx_sorted, const uint64_t *__restrict__ aw, const uint32_t *__restrict__ av,
@@ -525,7 +577,24 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
         e = rocprim::exclusive_scan(ctx->tmp.p, have, wide, off, 0ull, (size_t)nsub, rocprim::plus<unsigned long long>(), st);
         if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim exclusive_scan: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((k_pp_finish<MODE>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a);
+    if (total / nsub + total / (4 * nsub) <= PP_FN_SMALL) {
+        // sparsely filled stretches: the small-capacity variant for all, the full one for the few it notes down
+        FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)nsub * 4));
+        unsigned long long *later_count = flag + 3;
+        FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
+        hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+                           later_count);
+        unsigned long long nlater = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&nlater, later_count, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (nlater > 0)
+            hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP>), dim3((unsigned)nlater), dim3(PP_THREADS), 0, st, a, (const uint32_t *)ctx->ps_a.as<uint32_t>(),
+                               (uint32_t *)nullptr, (unsigned long long *)nullptr);
+        *launches += 1;
+    } else {
+        hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                           (unsigned long long *)nullptr);
+    }
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 4;
@@ -574,6 +643,7 @@ int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, 
     PpArgs a;
     a.lo = lo; a.hi = hi; a.mul = (uint64_t)((one << 92) / span); a.nohi = nohi;      // mul < 2^64 since span > 2^28
     a.grid = nullptr; a.top = top; a.sigma = 1 << g.b;
+    a.rb = 0; a.ew = 2; a.nd = 0; a.rtab = a.mtab = 0; a.key_bits = g.key_bits;
     return pp_sort<0>(ctx, g, a, est, nparts, out_offset, count, ok, launches);
 }
 
@@ -635,6 +705,39 @@ int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches
     a.sigma = 0;
     for (int c = 0; c < 256; c++) a.sigma += ctx->byte_hist[c] != 0;     // fbg_key_setup's order-preserving codes: 0 .. sigma - 1
     if (a.sigma < 2) a.sigma = 2;
+    {
+        // the finish bins by the ranks of the symbols among the frequent ones (pp_rank_number)
+        uint64_t freq[256];
+        int ncodes = 0;
+        for (int c = 0; c < 256; c++) if (ctx->byte_hist[c]) freq[ncodes++] = ctx->byte_hist[c];
+        int nf = 0;
+        for (int c = 0; c < ncodes; c++) nf += freq[c] >= N / 64;
+        a.rb = nf <= 2 ? 1 : nf <= 4 ? 2 : nf <= 8 ? 3 : 0;
+        a.ew = a.rb <= 2 ? 2 : 4;
+        if (g.b > 5 || (1 << g.b) * a.ew > 64 || ctx->opt.msd_sample_bins) a.rb = 0;
+        a.rtab = a.mtab = 0; a.nd = 0; a.key_bits = g.key_bits;
+        if (a.rb > 0) {
+            a.nd = 30 / a.rb;
+            // the 2^rb most frequent codes, in code order, get the ranks; every other code joins the frequent one above it
+            // (mode 1), the last one if there is none (mode 2)
+            const int want = 1 << a.rb;
+            bool main_[256] = {false};
+            for (int k = 0; k < want && k < ncodes; k++) {
+                int best = -1;
+                for (int c = 0; c < ncodes; c++) if (!main_[c] && (best < 0 || freq[c] > freq[best])) best = c;
+                main_[best] = true;
+            }
+            int rank_of[256], nmain = 0;
+            for (int c = 0; c < ncodes; c++) if (main_[c]) rank_of[c] = nmain++;
+            for (int c = 0; c < (1 << g.b); c++) {
+                int r = nmain - 1, mode = 2;
+                if (c < ncodes && main_[c]) { r = rank_of[c]; mode = 0; }
+                else for (int d = c + 1; d < ncodes; d++) if (main_[d]) { r = rank_of[d]; mode = 1; break; }
+                a.rtab |= (uint64_t)r << (a.ew * c);
+                a.mtab |= (uint64_t)mode << (2 * c);
+            }
+        }
+    }
     uint64_t count = 0;
     const uint64_t est = N + N / 64 + 65536;
     FBG_TRY(pp_sort<1>(ctx, g, a, est, 1, 0, &count, ok, launches));

@@ -400,6 +400,8 @@ ALT_PATHS = [
     {"FBG_GAPPED_RANK": "-1"},                       # record path for the MSAs with gaps / ignore characters (default: gapped_rank.hip)
     {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"},
     {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"},
+    {"FBG_MSD_MIN": "1", "FBG_MSD_SAMPLE_BINS": "1"},  # sample sort whose finish bins by sampled keys instead of symbol ranks
+    {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1", "FBG_MSD_SAMPLE_BINS": "1"},
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
     {"FBG_DP_LITERAL": "1"},                         # statement-by-statement sweeps
