@@ -294,8 +294,20 @@ __global__ __launch_bounds__(64) void k_dp_tile(const uint8_t *__restrict__ ext7
 //   k_dp_bt      backtrack[j] from minmaxlength[] alone, one thread per column, with the reference's
 //                tie-breaking (S kind first, else the youngest count_solutions kind; fbg.cpp:1976-2009).
 #define DPB_INF 255u
+typedef unsigned short dp_u16x2 __attribute__((ext_vector_type(2)));      // v_pk_max_u16 / v_pk_min_u16 operands
+__device__ __forceinline__ dp_u16x2 dp_bits(uint32_t x) { return __builtin_bit_cast(dp_u16x2, x); }
+__device__ __forceinline__ uint32_t dp_word(dp_u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ dp_u16x2 dp_pair(uint32_t x) { return dp_bits(x | (x << 16)); }
 
 // R = window / 64: candidates up to 64R columns back, blocks of 64R steps, matrices of (64R)^2 bytes.
+// Step t of source k: w = min over the inside candidates tp < t of max(W[tp][k], t - tp), a candidate counting from the
+// step on at which its block is long enough (t >= tp + ext[tp]) -- 64R steps x 64R candidates x 64R sources per block.
+// The thread's row of W lies along tp in LDS (rows padded by 4 bytes: the lanes' rows start in different banks), so one
+// load brings 4 candidates; their bytes as two pairs of 16-bit lanes go through packed max (with the ages, which are
+// the same for all sources) and packed min; which candidates count is a byte mask per wave, kept up to date by the
+// lanes themselves (lane j clears the bytes of its candidates at the step they become usable): 0xff on a byte makes
+// the maximum at least 255 = no solution.  11 vector operations per 4 candidates instead of 24.
+#define DPB_PADDED(WN) ((WN) + 4)
 template <int R>
 __global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict__ ext7, const uint8_t *__restrict__ amin,
                                                       uint32_t n, uint32_t nblocks, uint8_t *__restrict__ Wt)
@@ -303,12 +315,13 @@ __global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict_
     // amin (optional): per-step minimal block length -- the non-elastic recurrence, where a block ending at
     // step j is valid iff it is at least j - v[j-1] long (fbg.cpp:625-627); 255 = no valid block ends there
     // one thread per source column k; the R waves of a block never need each other's values
-    constexpr uint32_t WN = 64 * R;
+    constexpr uint32_t WN = 64 * R, WP = DPB_PADDED(WN);
     extern __shared__ uint8_t dyn_lds[];
-    uint8_t *wl = dyn_lds;                   // wl[t * WN + k]: W of inside column (block start + 1 + t) for source k
-    uint8_t *s_ext = dyn_lds + WN * WN;      // extensions of the inside columns
+    uint8_t *wl = dyn_lds;                   // wl[k * WP + t]: W of inside column (block start + 1 + t) for source k
+    uint8_t *s_ext = dyn_lds + WN * WP;      // extensions of the inside columns
     uint8_t *s_amin = s_ext + WN;            // minimal block length per step
-    const uint32_t k = threadIdx.x;
+    uint8_t *mk = s_amin + WN + (threadIdx.x >> 6) * 2 * WN;   // this wave's masks: per group of 4 candidates two words (even / odd candidates as 16-bit lanes)
+    const uint32_t k = threadIdx.x, lane = threadIdx.x & 63;
     for (uint32_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const uint32_t jb = WN * b;
         const int64_t xs = (int64_t)jb - (WN - 1) + k;                    // old column of source k
@@ -319,20 +332,50 @@ __global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict_
         __syncthreads();
         uint32_t minext = 255;
         for (uint32_t q = 0; q < WN; q++) minext = min(minext, (uint32_t)s_ext[q]);
+        // all candidates masked out; candidate tp = 4g + j sits in byte 8g + 4(j & 1) + 2(j >> 1)
+        for (uint32_t q = lane; q < WN / 4; q += 64) reinterpret_cast<uint2 *>(mk)[q] = make_uint2(0x00ff00ffu, 0x00ff00ffu);
+        uint32_t ready[R];                                                // the step from which the lane's candidates count
+#pragma unroll
+        for (int r = 0; r < R; r++) { const uint32_t tp = lane + 64 * r; ready[r] = tp + max(1u, (uint32_t)s_ext[tp]); }
+        uint8_t *row = wl + k * WP;
         uint8_t *out = Wt + (size_t)b * WN * WN;
         for (uint32_t t = 0; t < WN; t++) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (ready[r] == t) { const uint32_t tp = lane + 64 * r; mk[8 * (tp >> 2) + 4 * (tp & 1) + 2 * ((tp >> 1) & 1)] = 0; }
+            __builtin_amdgcn_wave_barrier();
             const uint32_t age_src = t + WN - k;                          // (jb+1+t) - xs
             const uint32_t am = s_amin[t];
             uint32_t w = (ext_src <= age_src && age_src <= WN && age_src >= am) ? age_src : DPB_INF;
             // inside candidates need age >= their extension >= minext and age >= the step's minimum
             const uint32_t need = max(minext, am);
             const uint32_t tp_end = t >= need ? t - need + 1 : 0;
-            for (uint32_t tp = 0; tp < tp_end; tp++) {
-                const uint32_t age = t - tp;
-                if (s_ext[tp] <= age) w = min(w, max((uint32_t)wl[tp * WN + k], age));   // wave-uniform test
+            dp_u16x2 acc_e = dp_pair(0xffffu), acc_o = acc_e;
+            uint32_t g4 = 0;
+            for (; g4 + 4 <= tp_end; g4 += 4) {
+                const uint32_t word = *reinterpret_cast<const uint32_t *>(row + g4);
+                const uint2 m = *reinterpret_cast<const uint2 *>(mk + 2 * g4);
+                const uint32_t base = t - g4;
+                const dp_u16x2 age_e = dp_bits(base | ((base - 2) << 16)), age_o = dp_bits((base - 1) | ((base - 3) << 16));
+                acc_e = __builtin_elementwise_min(acc_e, __builtin_elementwise_max(dp_bits((word & 0x00ff00ffu) | m.x), age_e));
+                acc_o = __builtin_elementwise_min(acc_o, __builtin_elementwise_max(dp_bits(((word >> 8) & 0x00ff00ffu) | m.y), age_o));
             }
+            if (g4 < tp_end) {                                            // the last, partial group: candidates from tp_end on do not count
+                const uint32_t word = *reinterpret_cast<const uint32_t *>(row + g4);
+                uint2 m = *reinterpret_cast<const uint2 *>(mk + 2 * g4);
+                const uint32_t live = tp_end - g4;                        // 1 .. 3
+                if (live < 2) m.y |= 0x000000ffu;
+                if (live < 3) m.x |= 0x00ff0000u;
+                m.y |= 0x00ff0000u;
+                const uint32_t base = t - g4;
+                const dp_u16x2 age_e = dp_bits((base & 0xffffu) | ((base - 2) << 16)), age_o = dp_bits(((base - 1) & 0xffffu) | ((base - 3) << 16));
+                acc_e = __builtin_elementwise_min(acc_e, __builtin_elementwise_max(dp_bits((word & 0x00ff00ffu) | m.x), age_e));
+                acc_o = __builtin_elementwise_min(acc_o, __builtin_elementwise_max(dp_bits(((word >> 8) & 0x00ff00ffu) | m.y), age_o));
+            }
+            const dp_u16x2 acc = __builtin_elementwise_min(acc_e, acc_o);
+            w = min(w, min((uint32_t)acc.x, (uint32_t)acc.y));
             w = min(w, DPB_INF);
-            wl[t * WN + k] = (uint8_t)w;
+            row[t] = (uint8_t)w;
             out[(size_t)t * WN + k] = (uint8_t)w;                         // Wt[b][t][k]
         }
     }
@@ -430,20 +473,25 @@ __global__ __launch_bounds__(256) void k_dp_compose(uint8_t *__restrict__ Wt, ui
         for (uint32_t q = tid * 16; q < WN * WN; q += 256 * 16)
             *reinterpret_cast<uint4 *>(W + q) = *reinterpret_cast<const uint4 *>(G + q);
         __syncthreads();
-        // thread -> (row t, 4 consecutive sources k): WN*WN/4 work items
-        for (uint32_t item = tid; item < WN * WN / 4; item += 256) {
-            const uint32_t t = item / (WN / 4), k4 = (item % (WN / 4)) * 4;
-            uint32_t a0 = DPB_INF, a1 = DPB_INF, a2 = DPB_INF, a3 = DPB_INF;
+        // thread -> (row t, 8 consecutive sources k): WN*WN/8 work items.  Bytes as two pairs of 16-bit lanes per word
+        // (even / odd bytes): packed 16-bit max / min do two sources per instruction
+        for (uint32_t item = tid; item < WN * WN / 8; item += 256) {
+            const uint32_t t = item / (WN / 8), k8 = (item % (WN / 8)) * 8;
+            dp_u16x2 a0 = dp_pair(DPB_INF), a1 = a0, a2 = a0, a3 = a0;       // sources (k8, k8+2), (k8+1, k8+3), (k8+4, k8+6), (k8+5, k8+7)
             for (uint32_t u = 0; u < WN; u++) {
                 const uint32_t w = W[t * WN + u];
                 if (w == DPB_INF) continue;
-                const uint32_t p4 = *reinterpret_cast<const uint32_t *>(P + u * WN + k4);
-                a0 = min(a0, max(w, p4 & 255u));
-                a1 = min(a1, max(w, (p4 >> 8) & 255u));
-                a2 = min(a2, max(w, (p4 >> 16) & 255u));
-                a3 = min(a3, max(w, p4 >> 24));
+                const uint2 p8 = *reinterpret_cast<const uint2 *>(P + u * WN + k8);
+                const dp_u16x2 ww = dp_pair(w);
+                a0 = __builtin_elementwise_min(a0, __builtin_elementwise_max(ww, dp_bits(p8.x & 0x00ff00ffu)));
+                a1 = __builtin_elementwise_min(a1, __builtin_elementwise_max(ww, dp_bits((p8.x >> 8) & 0x00ff00ffu)));
+                a2 = __builtin_elementwise_min(a2, __builtin_elementwise_max(ww, dp_bits(p8.y & 0x00ff00ffu)));
+                a3 = __builtin_elementwise_min(a3, __builtin_elementwise_max(ww, dp_bits((p8.y >> 8) & 0x00ff00ffu)));
             }
-            *reinterpret_cast<uint32_t *>(G + t * WN + k4) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+            uint2 o;
+            o.x = dp_word(a0) | (dp_word(a1) << 8);
+            o.y = dp_word(a2) | (dp_word(a3) << 8);
+            *reinterpret_cast<uint2 *>(G + t * WN + k8) = o;
         }
         __syncthreads();
         // the product becomes P for the next block of the group
@@ -754,7 +802,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                     const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN);
                     FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
                     uint8_t *Wt = ctx->tmp.as<uint8_t>();
-                    const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
+                    const size_t lds = (size_t)WN * DPB_PADDED(WN) + 2 * WN + 2 * WN * (WN / 64), lds2 = 2 * (size_t)WN * WN;
                     const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
                     const uint32_t Fg = 16;                              // blocks per group of the chain (a chain step costs ~0.5 us)
                     const uint32_t ngroups = (nblocks + Fg - 1) / Fg;
@@ -947,7 +995,7 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
             const uint32_t nblocks = (uint32_t)((n + WN - 1) / WN), Fg = 4, ngroups = (nblocks + Fg - 1) / Fg;
             FBG_TRY(fbg_reserve(ctx, ctx->tmp, (size_t)nblocks * WN * WN));
             uint8_t *Wt = ctx->tmp.as<uint8_t>();
-            const size_t lds = (size_t)WN * WN + 2 * WN, lds2 = 2 * (size_t)WN * WN;
+            const size_t lds = (size_t)WN * DPB_PADDED(WN) + 2 * WN + 2 * WN * (WN / 64), lds2 = 2 * (size_t)WN * WN;
             const unsigned grid = fbg_blocks(nblocks, 1, 256 * 16);
 #define FBG_NE_PIPE(RR)                                                                                                   \
     do {                                                                                                                 \
