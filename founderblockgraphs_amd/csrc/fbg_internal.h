@@ -91,6 +91,7 @@ struct fbg_ctx {
     uint32_t grs_ign_lo = 0, grs_ign_hi = 0;
     DevBuf gwin;                   // 16 bytes per 128 text positions: column, row, gap runs
     DevBuf gbits;                  // 1 bit per text position: not the column after its predecessor's
+    DevBuf gwin_rows;              // u16 per window of 128 positions: the row of its first position (written with the text)
     const uint64_t *grs_ebits = nullptr;   // gbits while the pack kernels are to fold it into bit 31 of the sort's values
     bool grs_flagged = false;      // the sorted values carry that bit
     bool grs_ties_done = false;    // the tie groups of the kept slots are in text order

@@ -161,7 +161,8 @@ __device__ __forceinline__ uint32_t gr_col(const GrsArgs &a, uint32_t p, uint32_
 // One wave per window: the table entry, and the bitmap "position p is irregular": not the column after its
 // predecessor's (gap run before it, row start), or no symbol at all ('#', sentinel, beyond the text).
 __global__ __launch_bounds__(256) void k_gw_build(const uint32_t *__restrict__ colT, const uint32_t *__restrict__ pos, uint64_t N, uint32_t n,
-                                                  uint32_t m, GWin *__restrict__ win, unsigned long long *__restrict__ ebits)
+                                                  uint32_t m, const uint16_t *__restrict__ winrow, GWin *__restrict__ win,
+                                                  unsigned long long *__restrict__ ebits)
 {
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -194,25 +195,11 @@ __global__ __launch_bounds__(256) void k_gw_build(const uint32_t *__restrict__ c
         e.col0 = c0; e.off[0] = e.off[1] = 0; e.len[0] = e.len[1] = 0; e.row = GW_IRREGULAR; e.lo0 = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    if (!irregular) {
-        // the window's row: the last row that starts at or before w0.  All lanes probe (64 probes narrow the range 65 times:
-        // two or three rounds of one load each; lane 0 searching alone -- eight dependent loads per window -- was most of this kernel)
-        uint32_t lo = 0, hi = m;                                       // answer in [lo, hi)
-        while (hi - lo > 1) {
-            const uint32_t span = hi - lo;
-            const uint32_t q = lo + 1 + (uint32_t)(((uint64_t)lane * (span - 1)) / 64);      // lo + 1 .. hi - 1, ascending in the lane
-            const unsigned long long le = __ballot(pos[q] <= (uint32_t)w0);                  // true for a prefix of the lanes
-            const uint32_t cnt = (uint32_t)__popcll(le);
-            const uint32_t q_last_true = lo + 1 + (uint32_t)(((uint64_t)(cnt ? cnt - 1 : 0) * (span - 1)) / 64);
-            const uint32_t q_first_false = lo + 1 + (uint32_t)(((uint64_t)cnt * (span - 1)) / 64);
-            const uint32_t nlo = cnt ? q_last_true : lo, nhi = cnt < 64 ? q_first_false : hi;
-            if (nlo == lo && nhi == hi) break;                          // (span - 1 < 64: the probes covered every candidate)
-            lo = nlo; hi = nhi;
-        }
-        if (lane == 0) {
-            e.row = (uint16_t)lo;
-            e.lo0 = pos[lo] == (uint32_t)w0 ? 0u : cp0 + 1;
-        }
+    if (!irregular && lane == 0) {
+        // the window's row: noted by the text writer (k_write_text) when it placed the window's first symbol
+        const uint32_t row = winrow[w];
+        e.row = (uint16_t)row;
+        e.lo0 = pos[row] == (uint32_t)w0 ? 0u : cp0 + 1;
     }
     __builtin_amdgcn_wave_barrier();
     if (!irregular) {
@@ -537,32 +524,49 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const ui
 // to one address took 90 ms).
 __global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t *__restrict__ list, uint32_t *__restrict__ segcnt)
 {
-    __shared__ uint64_t skey[GR_THREADS + 2];
+    // four consecutive slots per thread and round (keys and values by 16-byte loads where the slots allow); the keys
+    // next to a thread's four come from the adjacent lanes, at a wave's edges from memory
     __shared__ uint32_t fill;
     const uint32_t lane = threadIdx.x & 63;
-    const int me = (int)threadIdx.x + 1;
     uint32_t *mine = list + (uint64_t)blockIdx.x * GR_SEG;
     if (threadIdx.x == 0) fill = 0;
-    for (uint32_t r = 0; r < GR_SEG; r += GR_THREADS) {
-        const uint64_t base = a.own_lo + (uint64_t)blockIdx.x * GR_SEG + r;
-        const uint64_t s = base + threadIdx.x;
-        const bool in = s < a.own_hi;
-        __syncthreads();
-        skey[me] = s < a.lim_hi ? a.keys[s] : 0ull;
-        if (threadIdx.x == 0) skey[0] = base > a.lim_lo && base <= a.lim_hi ? a.keys[base - 1] : 0ull;
-        if (threadIdx.x == 1) skey[GR_THREADS + 1] = base + GR_THREADS < a.lim_hi ? a.keys[base + GR_THREADS] : 0ull;
-        const uint32_t v = in ? a.vals[s] : 0u;
-        __syncthreads();
-        const uint64_t key = skey[me], kp = skey[me - 1], kn = skey[me + 1];
-        const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
-        const bool tie = (has_prev && kp == key) || (has_next && kn == key);
-        bool work = in && ((v >> 31) || tie);
-        if (in && !work) work = max(has_prev ? gr_key_lcp(kp, key, a.b, a.key_bits) : 0u, has_next ? gr_key_lcp(key, kn, a.b, a.key_bits) : 0u) + 1 >= a.t;
-        const unsigned long long mask = __ballot(work);
+    __syncthreads();
+    const bool aligned = ((a.own_lo & 3) == 0) && (((uintptr_t)a.keys & 15) == 0) && (((uintptr_t)a.vals & 15) == 0);
+    for (uint32_t r = 0; r < GR_SEG; r += 4 * GR_THREADS) {
+        const uint64_t s0 = a.own_lo + (uint64_t)blockIdx.x * GR_SEG + r + 4 * threadIdx.x;
+        uint64_t k[4];
+        uint32_t v[4];
+        if (aligned && s0 + 4 <= a.lim_hi) {
+            const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(a.keys + s0), k23 = *reinterpret_cast<const ulonglong2 *>(a.keys + s0 + 2);
+            const uint4 vv = *reinterpret_cast<const uint4 *>(a.vals + s0);
+            k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
+            v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const bool ex = s0 + i < a.lim_hi; k[i] = ex ? a.keys[s0 + i] : 0ull; v[i] = ex ? a.vals[s0 + i] : 0u; }
+        }
+        uint64_t kprev = __shfl_up(k[3], 1, 64), knext = __shfl_down(k[0], 1, 64);
+        if (lane == 0) kprev = (s0 > a.lim_lo && s0 <= a.lim_hi) ? a.keys[s0 - 1] : 0ull;
+        if (lane == 63) knext = s0 + 4 < a.lim_hi ? a.keys[s0 + 4] : 0ull;
+        uint32_t entry[4], cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t s = s0 + i, key = k[i], kp = i ? k[i - 1] : kprev, kn = i < 3 ? k[i + 1] : knext;
+            const bool in = s < a.own_hi;
+            const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
+            const bool tie = (has_prev && kp == key) || (has_next && kn == key);
+            bool work = in && ((v[i] >> 31) || tie);
+            if (in && !work) work = max(has_prev ? gr_key_lcp(kp, key, a.b, a.key_bits) : 0u, has_next ? gr_key_lcp(key, kn, a.b, a.key_bits) : 0u) + 1 >= a.t;
+            if (work) entry[cnt++] = (uint32_t)s | ((tie && !(has_prev && kp == key)) ? GR_HEAD : 0u);   // first slot of a tie group
+        }
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
         uint32_t at = 0;
-        if (lane == 0 && mask) at = atomicAdd(&fill, (uint32_t)__popcll(mask));
-        at = __shfl(at, 0, 64) + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-        if (work) mine[at] = (uint32_t)s | ((tie && !(has_prev && kp == key)) ? GR_HEAD : 0u);   // first slot of a tie group
+        if (lane == 63 && inc) at = atomicAdd(&fill, inc);
+        at = __shfl(at, 63, 64) + inc - cnt;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i < (int)cnt) mine[at + i] = entry[i];
     }
     __syncthreads();
     if (threadIdx.x == 0) segcnt[blockIdx.x] = fill;
@@ -882,7 +886,7 @@ int fbg_grs_prepare(fbg_ctx *ctx, int *launches)
     if (!ctx->gapfree) {
         FBG_TRY(fbg_reserve(ctx, ctx->gwin, nwin * sizeof(GWin)));
         hipLaunchKernelGGL(k_gw_build, dim3(fbg_blocks(nwin, 4)), dim3(256), 0, st, ctx->colT.as<uint32_t>(), ctx->pos.as<uint32_t>(), N, (uint32_t)n,
-                           (uint32_t)m, ctx->gwin.as<GWin>(), ctx->gbits.as<unsigned long long>());
+                           (uint32_t)m, ctx->gwin_rows.as<uint16_t>(), ctx->gwin.as<GWin>(), ctx->gbits.as<unsigned long long>());
     } else {
         hipLaunchKernelGGL(k_grs_ebits_gapfree, dim3(fbg_blocks(nwin * 2, 256)), dim3(256), 0, st, N, n, nwin * 2, ctx->gbits.as<unsigned long long>());
     }

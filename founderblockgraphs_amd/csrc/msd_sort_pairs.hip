@@ -429,6 +429,9 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
             const uint32_t bin = bn[r];
             const uint32_t b0 = loff[bin], c = cnt[bin];
             uint32_t smaller = 0;
+            // (four loads in flight: a bin of thousands -- keys with a rare symbol at the edge of a sub-bucket share one
+            // number -- is a long loop, and one load at a time made such a workgroup the tail of the launch)
+#pragma unroll 4
             for (uint32_t q = 0; q < c; q++) {
                 const uint64_t x = sw[b0 + q];
                 bool less = x < w[r];

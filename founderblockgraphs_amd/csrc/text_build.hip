@@ -234,7 +234,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__rest
                                                            const uint32_t *__restrict__ pos,
                                                            const uint32_t *__restrict__ tot,
                                                            uint8_t *__restrict__ T, uint32_t *__restrict__ prow,
-                                                           uint32_t *__restrict__ colT, const uint32_t *__restrict__ segoff)
+                                                           uint32_t *__restrict__ colT, const uint32_t *__restrict__ segoff,
+                                                           uint16_t *__restrict__ winrow)
 {
     // blockIdx.y = row; blockIdx.x = segment of RC_SEG columns (gapped rows: the segment's first text position comes
     // from segoff) or the whole row (gridDim.x = 1, segoff = nullptr)
@@ -260,7 +261,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_write_text(const uint8_t *__rest
             for (int k = 0; k < TB_ITEMS; k++) {
                 if (x0 + k < x_hi) {
                     if (prow) prow[i * n + x0 + k] = p0 + off;      // pos_i + rank_i(x)
-                    if (c[k] != '-') { T[p0 + off] = c[k]; colT[p0 + off] = (uint32_t)(x0 + k); off++; }
+                    if (c[k] != '-') {
+                        T[p0 + off] = c[k]; colT[p0 + off] = (uint32_t)(x0 + k);
+                        if (winrow && ((p0 + off) & 127u) == 0) winrow[(p0 + off) >> 7] = (uint16_t)i;   // the row of every window of 128 positions (gapped_rank.hip)
+                        off++;
+                    }
                 }
             }
             carry += total;
@@ -448,13 +453,15 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     if (!ctx->gapfree) {
         // (the text pointer of every cell, prow, is written on demand: fbg_build_cell_tables)
         FBG_TRY(fbg_reserve(ctx, ctx->colT, ctx->N * 4));
+        FBG_TRY(fbg_reserve(ctx, ctx->gwin_rows, ((ctx->N >> 7) + 2) * 2));
         hipLaunchKernelGGL(k_seg_offsets, dim3(fbg_blocks(m, 64)), dim3(64), 0, st, segcnt, m, nseg, segoff);
         hipLaunchKernelGGL((k_write_text<true, false>), dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
-                           pos, tot, T, (uint32_t *)nullptr, ctx->colT.as<uint32_t>(), (const uint32_t *)segoff);
+                           pos, tot, T, (uint32_t *)nullptr, ctx->colT.as<uint32_t>(), (const uint32_t *)segoff,
+                           m < 65535 ? ctx->gwin_rows.as<uint16_t>() : (uint16_t *)nullptr);
         launches++;
     } else if (ctx->reversed) {
         hipLaunchKernelGGL((k_write_text<false, true>), dim3(1, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
-                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr);
+                           pos, tot, T, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint16_t *)nullptr);
     } else if (!fused) {
         hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + CR_SEG - 1) / CR_SEG), (unsigned)m), dim3(TB_THREADS), 0, st,
                            ctx->d_msa, n, m, T);
@@ -483,7 +490,7 @@ int fbg_build_cell_tables(fbg_ctx *ctx)
         FBG_TRY(fbg_reserve(ctx, ctx->prow, m * n * 4));
         hipLaunchKernelGGL((k_write_text<true, false>), dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa, n,
                            ctx->pos.as<uint32_t>(), ctx->tot.as<uint32_t>(), ctx->text.as<uint8_t>(), ctx->prow.as<uint32_t>(),
-                           ctx->colT.as<uint32_t>(), (const uint32_t *)segoff);
+                           ctx->colT.as<uint32_t>(), (const uint32_t *)segoff, (uint16_t *)nullptr);
     }
     if (ctx->have_ignore) {
         const uint8_t *d_is_ignore = ctx->small.as<uint8_t>();
