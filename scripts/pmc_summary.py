@@ -8,13 +8,17 @@ import sys
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
-for path in sys.argv[1:]:
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+c5 = "--c5" in sys.argv
+for path in args:
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[name][r["Counter_Name"]].add(r["Dispatch_Id"])
 out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras  (scripts/gpu_round2.sh)",
        "workload": {"rows": 1000, "cols": 1000000},
+       **({"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 scripts/gpu_configs.py c5  (scripts/gpu_round2_extra.sh)",
+           "workload": {"rows": 256, "cols": 2000000, "gaps": "5 % in runs of 16", "N": "0.1 %", "ignore": "N", "builds_per_run": 2}} if c5 else {}),
        "correction": "counter unit KiB; FETCH_SIZE doubled for gfx950 (MI355X_MICROARCH.md, HBM section)", "kernels": {}}
 for name, d in sorted(acc.items()):
     k = {}
