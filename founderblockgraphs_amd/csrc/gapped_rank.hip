@@ -360,21 +360,13 @@ __device__ __forceinline__ void gr_walk(const GrsArgs &a, uint64_t s, uint32_t l
 // stage / stage_fill: the workgroup's candidates collect in LDS (GR_STAGE entries) and leave with one reservation in
 // the global list per flush -- a reservation per wave, 10^6 of them on one address, cost 12 ms.
 #define GR_STAGE 2048
-__device__ __forceinline__ void gr_slot(const GrsArgs &a, bool in, uint64_t s, uint64_t key, uint64_t kp, uint64_t kn, bool cheap_ok,
-                                        uint64_t k2p, uint64_t k2n, unsigned long long *stage, uint32_t *stage_fill)
+// The slot comes resolved: v its value (position | flag), tie / g from its keys, see_prev / see_next whether the slot
+// before / after has to be looked at (it exists and is not one the scan skips next to a regular slot with g >= t).
+__device__ __forceinline__ void gr_slot_core(const GrsArgs &a, bool in, uint64_t s, uint32_t v, uint64_t key, bool tie, uint32_t g, bool see_prev,
+                                             bool see_next, unsigned long long *stage, uint32_t *stage_fill)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
-    const uint32_t v = in ? a.vals[s] : 0u;
     const uint32_t p = v & a.vmask;
-    const bool flagged = a.vmask == 0xffffffffu || (v >> 31);
-    const bool tie = in && ((has_prev && kp == key) || (has_next && kn == key));
-    uint32_t g = 0, lp = 0, ln = 0;
-    if (in && !tie) {
-        lp = has_prev ? gr_key_lcp(kp, key, a.b, a.key_bits) : 0u;
-        ln = has_next ? gr_key_lcp(key, kn, a.b, a.key_bits) : 0u;
-        g = max(lp, ln) + 1;                                            // 1656
-    }
     bool work = in;
     uint32_t lo = 1, hi = 0, row = 0, fi0 = 0;
     GWin w;
@@ -393,14 +385,6 @@ __device__ __forceinline__ void gr_slot(const GrsArgs &a, bool in, uint64_t s, u
     if (work) {
         uint32_t r2;
         GWin w2;
-        bool see_prev = has_prev, see_next = has_next;
-        if (cheap_ok && !flagged && !tie && g >= a.t) {
-            // is the neighbour one the scan skips?  (its g from its own two neighbours' keys, its flag from its value)
-            if (has_prev && kp != key && s >= a.lim_lo + 2 && k2p != kp && !(a.vals[s - 1] >> 31))
-                see_prev = max(lp, gr_key_lcp(k2p, kp, a.b, a.key_bits)) + 1 >= a.t;
-            if (has_next && kn != key && s + 2 < a.lim_hi && k2n != kn && !(a.vals[s + 1] >> 31))
-                see_next = max(ln, gr_key_lcp(kn, k2n, a.b, a.key_bits)) + 1 >= a.t;
-        }
         if (see_prev) { gr_span(a, a.vals[s - 1] & a.vmask, pl, ph, r2, w2); pl = max(pl, lo); ph = min(ph, hi); }
         if (see_next) { gr_span(a, a.vals[s + 1] & a.vmask, nl, nh, r2, w2); nl = max(nl, lo); nh = min(nh, hi); }
         if (!tie) fi0 = gr_extent(a, p, row, g, key, true, w);
@@ -441,6 +425,18 @@ __device__ __forceinline__ void gr_slot(const GrsArgs &a, bool in, uint64_t s, u
         });
 }
 
+// the same from the slot's keys: every neighbour that exists is looked at
+__device__ __forceinline__ void gr_slot(const GrsArgs &a, bool in, uint64_t s, uint64_t key, uint64_t kp, uint64_t kn, unsigned long long *stage,
+                                        uint32_t *stage_fill)
+{
+    const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
+    const uint32_t v = in ? a.vals[s] : 0u;
+    const bool tie = in && ((has_prev && kp == key) || (has_next && kn == key));
+    uint32_t g = 0;
+    if (in && !tie) g = max(has_prev ? gr_key_lcp(kp, key, a.b, a.key_bits) : 0u, has_next ? gr_key_lcp(key, kn, a.b, a.key_bits) : 0u) + 1;   // 1656
+    gr_slot_core(a, in, s, v, key, tie, g, in && has_prev, in && has_next, stage, stage_fill);
+}
+
 // the workgroup's staged candidates -> the global list (all threads; force: whatever the fill, else only when half full)
 __device__ __forceinline__ void gr_flush(const GrsArgs &a, unsigned long long *stage, uint32_t *stage_fill, unsigned long long *gbase, bool force)
 {
@@ -471,7 +467,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_all(GrsArgs a)
     if (threadIdx.x == 1) skey[GR_THREADS + 1] = base + GR_THREADS < a.lim_hi ? a.keys[base + GR_THREADS] : 0ull;
     if (threadIdx.x == 0) stage_fill = 0;
     __syncthreads();
-    gr_slot(a, in, s, skey[me], skey[me - 1], skey[me + 1], false, 0, 0, stage, &stage_fill);
+    gr_slot(a, in, s, skey[me], skey[me - 1], skey[me + 1], stage, &stage_fill);
     gr_flush(a, stage, &stage_fill, &gbase, true);
 }
 
@@ -487,13 +483,22 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_list(GrsArgs a, const u
     const uint64_t s = in ? list[i] : 0;
     const uint64_t key = in ? a.keys[s] : 0ull;
     const uint64_t kp = in && s > a.lim_lo ? a.keys[s - 1] : 0ull, kn = in && s + 1 < a.lim_hi ? a.keys[s + 1] : 0ull;
-    gr_slot(a, in, s, key, kp, kn, false, 0, 0, stage, &stage_fill);
+    gr_slot(a, in, s, key, kp, kn, stage, &stage_fill);
     gr_flush(a, stage, &stage_fill, &gbase, true);
 }
 
 #define GR_SEG 16384                 // slots per workgroup of k_grs_classify = capacity of its stretch of the list
+// What k_grs_classify notes of a listed slot beside its index: the key, the value and what the keys around it say
+// (meta: bits 0-6 g, 7 tie, 8 / 9 the slot before / after has to be looked at).  The scan of the listed slots reads these
+// in order instead of gathering five keys and three values per slot from where they lie (250 bytes of sectors each).
+struct GrsRec { uint64_t key; uint32_t v, meta; };
+#define GR_META_TIE 0x80u
+#define GR_META_PREV 0x100u
+#define GR_META_NEXT 0x200u
+
 // the slots k_grs_classify listed, one stretch of the list per workgroup
-__global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const uint32_t *__restrict__ list, const uint32_t *__restrict__ segcnt)
+__global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const uint32_t *__restrict__ list, const GrsRec *__restrict__ recs,
+                                                             const uint32_t *__restrict__ segcnt)
 {
     __shared__ unsigned long long stage[GR_STAGE], gbase;
     __shared__ uint32_t stage_fill;
@@ -501,19 +506,17 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const ui
     __syncthreads();
     const uint32_t cnt = segcnt[blockIdx.x];
     const uint32_t *mine = list + (uint64_t)blockIdx.x * GR_SEG;
+    const GrsRec *mine_r = recs + (uint64_t)blockIdx.x * GR_SEG;
     for (uint32_t r = 0; r < cnt; r += GR_THREADS) {
         const uint32_t i = r + threadIdx.x;
         const bool in = i < cnt;
         const uint64_t s = in ? (mine[i] & ~GR_HEAD) : 0;
-        uint64_t key = 0, kp = 0, kn = 0, k2p = 0, k2n = 0;
-        if (in) {
-            key = a.keys[s];
-            if (s > a.lim_lo) kp = a.keys[s - 1];
-            if (s > a.lim_lo + 1) k2p = a.keys[s - 2];
-            if (s + 1 < a.lim_hi) kn = a.keys[s + 1];
-            if (s + 2 < a.lim_hi) k2n = a.keys[s + 2];
-        }
-        gr_slot(a, in, s, key, kp, kn, true, k2p, k2n, stage, &stage_fill);
+        GrsRec rec;
+        rec.key = 0; rec.v = 0; rec.meta = 0;
+        if (in) rec = mine_r[i];
+        if (in && (rec.meta & GR_META_TIE)) rec.v = a.vals[s];         // (the tie groups were put in text order after the note was taken)
+        gr_slot_core(a, in, s, rec.v, rec.key, (rec.meta & GR_META_TIE) != 0, rec.meta & 0x7fu, (rec.meta & GR_META_PREV) != 0, (rec.meta & GR_META_NEXT) != 0,
+                     stage, &stage_fill);
         gr_flush(a, stage, &stage_fill, &gbase, r + GR_THREADS >= cnt);
     }
 }
@@ -522,42 +525,80 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_scan_seg(GrsArgs a, const ui
 // walk through the dependent table reads while the others wait -- every wave, at 15 % of the lanes; from the list all
 // lanes do.  A workgroup takes GR_SEG slots and fills its own stretch of the list (no global counter: 10^7 waves adding
 // to one address took 90 ms).
-__global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t *__restrict__ list, uint32_t *__restrict__ segcnt)
+__global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t *__restrict__ list, GrsRec *__restrict__ recs, uint32_t *__restrict__ segcnt)
 {
-    // four consecutive slots per thread and round (keys and values by 16-byte loads where the slots allow); the keys
-    // next to a thread's four come from the adjacent lanes, at a wave's edges from memory
+    // four consecutive slots per thread and round (keys and values by 16-byte loads where the slots allow); the two keys
+    // and the value either side of a thread's four come from the adjacent lanes, at a wave's edges from memory
     __shared__ uint32_t fill;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t *mine = list + (uint64_t)blockIdx.x * GR_SEG;
+    GrsRec *mine_r = recs + (uint64_t)blockIdx.x * GR_SEG;
     if (threadIdx.x == 0) fill = 0;
     __syncthreads();
     const bool aligned = ((a.own_lo & 3) == 0) && (((uintptr_t)a.keys & 15) == 0) && (((uintptr_t)a.vals & 15) == 0);
     for (uint32_t r = 0; r < GR_SEG; r += 4 * GR_THREADS) {
         const uint64_t s0 = a.own_lo + (uint64_t)blockIdx.x * GR_SEG + r + 4 * threadIdx.x;
-        uint64_t k[4];
-        uint32_t v[4];
+        // K[j]: key of slot s0 - 2 + j (j = 0 .. 7), V[j]: value of slot s0 - 1 + j (j = 0 .. 5); 0 where no slot is
+        uint64_t K[8];
+        uint32_t V[6];
         if (aligned && s0 + 4 <= a.lim_hi) {
             const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(a.keys + s0), k23 = *reinterpret_cast<const ulonglong2 *>(a.keys + s0 + 2);
             const uint4 vv = *reinterpret_cast<const uint4 *>(a.vals + s0);
-            k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
-            v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
+            K[2] = k01.x; K[3] = k01.y; K[4] = k23.x; K[5] = k23.y;
+            V[1] = vv.x; V[2] = vv.y; V[3] = vv.z; V[4] = vv.w;
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const bool ex = s0 + i < a.lim_hi; k[i] = ex ? a.keys[s0 + i] : 0ull; v[i] = ex ? a.vals[s0 + i] : 0u; }
+            for (int i = 0; i < 4; i++) { const bool ex = s0 + i < a.lim_hi; K[2 + i] = ex ? a.keys[s0 + i] : 0ull; V[1 + i] = ex ? a.vals[s0 + i] : 0u; }
         }
-        uint64_t kprev = __shfl_up(k[3], 1, 64), knext = __shfl_down(k[0], 1, 64);
-        if (lane == 0) kprev = (s0 > a.lim_lo && s0 <= a.lim_hi) ? a.keys[s0 - 1] : 0ull;
-        if (lane == 63) knext = s0 + 4 < a.lim_hi ? a.keys[s0 + 4] : 0ull;
+        K[1] = __shfl_up(K[5], 1, 64); K[0] = __shfl_up(K[4], 1, 64); V[0] = __shfl_up(V[4], 1, 64);
+        K[6] = __shfl_down(K[2], 1, 64); K[7] = __shfl_down(K[3], 1, 64); V[5] = __shfl_down(V[1], 1, 64);
+        if (lane == 0) {
+            K[1] = (s0 >= a.lim_lo + 1 && s0 - 1 < a.lim_hi) ? a.keys[s0 - 1] : 0ull;
+            K[0] = (s0 >= a.lim_lo + 2 && s0 - 2 < a.lim_hi) ? a.keys[s0 - 2] : 0ull;
+            V[0] = (s0 >= a.lim_lo + 1 && s0 - 1 < a.lim_hi) ? a.vals[s0 - 1] : 0u;
+        }
+        if (lane == 63) {
+            K[6] = s0 + 4 < a.lim_hi ? a.keys[s0 + 4] : 0ull;
+            K[7] = s0 + 5 < a.lim_hi ? a.keys[s0 + 5] : 0ull;
+            V[5] = s0 + 4 < a.lim_hi ? a.vals[s0 + 4] : 0u;
+        }
+        // per slot j (index into K): does it exist, does it tie with the slot before; LCP with the slot before
+        bool ex[8], eq[8];
+        uint32_t L[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const uint64_t sj = s0 + j - 2; ex[j] = s0 + j >= a.lim_lo + 2 && sj < a.lim_hi; }
+        eq[0] = false; L[0] = 0;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            const bool both = ex[j - 1] && ex[j];
+            eq[j] = both && K[j - 1] == K[j];
+            L[j] = (both && !eq[j]) ? gr_key_lcp(K[j - 1], K[j], a.b, a.key_bits) : 0u;
+        }
+        // slots 1 .. 6 of K (s0 - 1 .. s0 + 4): tie, g, "the scan skips it" (regular, no tie, g < t)
+        bool tie[8], skip[8];
+        uint32_t g[8];
+#pragma unroll
+        for (int j = 1; j < 7; j++) {
+            tie[j] = eq[j] || eq[j + 1];
+            g[j] = max(L[j], L[j + 1]) + 1;
+            skip[j] = ex[j] && !tie[j] && !(V[j - 1] >> 31) && g[j] < a.t;
+        }
         uint32_t entry[4], cnt = 0;
+        GrsRec rec[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint64_t s = s0 + i, key = k[i], kp = i ? k[i - 1] : kprev, kn = i < 3 ? k[i + 1] : knext;
-            const bool in = s < a.own_hi;
-            const bool has_prev = s > a.lim_lo, has_next = s + 1 < a.lim_hi;
-            const bool tie = (has_prev && kp == key) || (has_next && kn == key);
-            bool work = in && ((v[i] >> 31) || tie);
-            if (in && !work) work = max(has_prev ? gr_key_lcp(kp, key, a.b, a.key_bits) : 0u, has_next ? gr_key_lcp(key, kn, a.b, a.key_bits) : 0u) + 1 >= a.t;
-            if (work) entry[cnt++] = (uint32_t)s | ((tie && !(has_prev && kp == key)) ? GR_HEAD : 0u);   // first slot of a tie group
+            const int j = i + 2;
+            const uint64_t sl = s0 + i;
+            const bool in = sl < a.own_hi;
+            if (in && !skip[j]) {
+                const bool regular_kept = !tie[j] && !(V[j - 1] >> 31);          // regular with g >= t: a skipped neighbour need not be looked at
+                const bool see_prev = ex[j - 1] && !(regular_kept && skip[j - 1]);
+                const bool see_next = ex[j + 1] && !(regular_kept && skip[j + 1]);
+                entry[cnt] = (uint32_t)sl | ((tie[j] && !eq[j]) ? GR_HEAD : 0u);   // first slot of a tie group
+                rec[cnt].key = K[j]; rec[cnt].v = V[j - 1];
+                rec[cnt].meta = (tie[j] ? 0u : g[j]) | (tie[j] ? GR_META_TIE : 0u) | (see_prev ? GR_META_PREV : 0u) | (see_next ? GR_META_NEXT : 0u);
+                cnt++;
+            }
         }
         uint32_t inc = cnt;
 #pragma unroll
@@ -566,7 +607,7 @@ __global__ __launch_bounds__(GR_THREADS) void k_grs_classify(GrsArgs a, uint32_t
         if (lane == 63 && inc) at = atomicAdd(&fill, inc);
         at = __shfl(at, 63, 64) + inc - cnt;
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (i < (int)cnt) mine[at + i] = entry[i];
+        for (int i = 0; i < 4; i++) if (i < (int)cnt) { mine[at + i] = entry[i]; mine_r[at + i] = rec[i]; }
     }
     __syncthreads();
     if (threadIdx.x == 0) segcnt[blockIdx.x] = fill;
@@ -952,12 +993,13 @@ static int grs_buffers(fbg_ctx *ctx, GrsArgs &a)
 
 // one pass over the own slots (list = nullptr), over a list, or over the stretches k_grs_classify filled (segcnt:
 // `count` stretches of GR_SEG) -- plus the long spans and the candidates' runs; *ok = 0: a capacity did not hold
-static int grs_pass(fbg_ctx *ctx, GrsArgs &a, const uint32_t *list, const uint32_t *segcnt, uint32_t count, int *ok, int *launches)
+static int grs_pass(fbg_ctx *ctx, GrsArgs &a, const uint32_t *list, const uint32_t *segcnt, uint32_t count, int *ok, int *launches,
+                    const GrsRec *recs = nullptr)
 {
     *ok = 0;
     hipStream_t st = ctx->stream;
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 3 * sizeof(unsigned long long), st));
-    if (segcnt) hipLaunchKernelGGL(k_grs_scan_seg, dim3(count), dim3(GR_THREADS), 0, st, a, list, segcnt);
+    if (segcnt) hipLaunchKernelGGL(k_grs_scan_seg, dim3(count), dim3(GR_THREADS), 0, st, a, list, recs, segcnt);
     else if (list) hipLaunchKernelGGL(k_grs_scan_list, dim3(fbg_blocks(count, GR_THREADS)), dim3(GR_THREADS), 0, st, a, list, count);
     else hipLaunchKernelGGL(k_grs_scan_all, dim3(fbg_blocks(a.own_hi - a.own_lo, GR_THREADS)), dim3(GR_THREADS), 0, st, a);
     unsigned long long h[3];
@@ -1029,7 +1071,9 @@ static int grs_main_pass(fbg_ctx *ctx, GrsArgs &a, bool order_ties, int *ok, int
         const uint32_t nseg = fbg_blocks(a.own_hi - a.own_lo, GR_SEG);
         FBG_TRY(fbg_reserve(ctx, ctx->grp, (size_t)nseg * GR_SEG * 4));
         FBG_TRY(fbg_reserve(ctx, ctx->flags, (size_t)nseg * 4));
-        hipLaunchKernelGGL(k_grs_classify, dim3(nseg), dim3(GR_THREADS), 0, st, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
+        FBG_TRY(fbg_reserve(ctx, ctx->msd_w, (size_t)nseg * GR_SEG * sizeof(GrsRec)));
+        GrsRec *recs = ctx->msd_w.as<GrsRec>();
+        hipLaunchKernelGGL(k_grs_classify, dim3(nseg), dim3(GR_THREADS), 0, st, a, ctx->grp.as<uint32_t>(), recs, ctx->flags.as<uint32_t>());
         *launches += 1;
         if (order_ties) {
             hipLaunchKernelGGL(k_grs_ties_listed, dim3(nseg), dim3(GR_THREADS), 0, st, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>());
@@ -1037,7 +1081,7 @@ static int grs_main_pass(fbg_ctx *ctx, GrsArgs &a, bool order_ties, int *ok, int
             FBG_TRY(ties_fit(&fit));
         }
         if (!fit) return FBG_OK;
-        return grs_pass(ctx, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>(), nseg, ok, launches);
+        return grs_pass(ctx, a, ctx->grp.as<uint32_t>(), ctx->flags.as<uint32_t>(), nseg, ok, launches, recs);
     }
     if (order_ties) {
         hipLaunchKernelGGL(k_grs_ties, dim3(fbg_blocks(a.own_hi - a.own_lo, 256)), dim3(256), 0, st, a);
