@@ -29,6 +29,8 @@
 #define PP_ITEMS (PP_FN_CAP / PP_THREADS)
 #define PP_BIG_CAP 9216                        // largest sub-bucket (k_pp_finish_big)
 #define PP_ARENA (1u << 20)
+#define PP_FN_SMALL 3072                      // LDS capacity of the finish variant for sparsely filled stretches (k_pp_finish)
+#define PP_CROWD 160                           // MODE 1 finish: a bin of more slots than this is split once more
 
 struct PpArgs {
     const uint8_t *T;
@@ -422,12 +424,72 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         if (j < have) { const uint32_t at = loff[bn[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
     __syncthreads();
+    // where every slot counts the smaller slots of its bin a bin of thousands is quadratic work -- MODE 1: the keys with a
+    // rare symbol at the edge of a sub-bucket share one number.  Such a bin is split once more, on the 8 key bits from the
+    // highest bit in which its smallest and largest key differ (monotone; even enough for a few hundred to a few thousand keys)
+    uint32_t rb0[ITEMS], rc[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) { rb0[r] = loff[bn[r]]; rc[r] = cnt[bn[r]]; }
+    if (MODE == 1 && CAP != PP_FN_SMALL) {                                // (not in the variant most sub-buckets go through: it costs that one 2 ms)
+        __shared__ uint32_t nbig, biglist[CAP / PP_CROWD + 1], sub[256];
+        __shared__ unsigned long long kmin, kmax;
+        if (threadIdx.x == 0) nbig = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < PP_FBINS; i += PP_THREADS)
+            if (cnt[i] > PP_CROWD) biglist[atomicAdd(&nbig, 1u)] = i;
+        __syncthreads();
+        const uint32_t nb = nbig;
+        for (uint32_t e = 0; e < nb; e++) {                             // uniform over the workgroup
+            const uint32_t bbin = biglist[e], b0 = loff[bbin];
+            if (threadIdx.x == 0) { kmin = ~0ull; kmax = 0ull; }
+            if (threadIdx.x < 256) sub[threadIdx.x] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const uint32_t j = threadIdx.x + r * PP_THREADS;
+                if (j < have && bn[r] == bbin) { atomicMin(&kmin, (unsigned long long)w[r]); atomicMax(&kmax, (unsigned long long)w[r]); }
+            }
+            __syncthreads();
+            const uint64_t lo = kmin, x = kmin ^ kmax;
+            if (x == 0) { __syncthreads(); continue; }                  // one key, many positions: the counting below orders them by position
+            const int hb = 63 - __clzll((long long)x), shift = hb >= 7 ? hb - 7 : 0;
+            uint32_t idx[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const uint32_t j = threadIdx.x + r * PP_THREADS;
+                idx[r] = 0;
+                if (j < have && bn[r] == bbin) idx[r] = atomicAdd(&sub[(uint32_t)((w[r] >> shift) - (lo >> shift))], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {                                      // exclusive scan of the 256 counts by one wave, four per lane; counts stay in the upper half word
+                uint32_t c4[4], tot = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { c4[q] = sub[4 * threadIdx.x + q]; tot += c4[q]; }
+                uint32_t inc = tot;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += o; }
+                uint32_t pre = inc - tot;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { sub[4 * threadIdx.x + q] = pre | (c4[q] << 16); pre += c4[q]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const uint32_t j = threadIdx.x + r * PP_THREADS;
+                if (j < have && bn[r] == bbin) {
+                    const uint32_t pc = sub[(uint32_t)((w[r] >> shift) - (lo >> shift))];
+                    rb0[r] = b0 + (pc & 0xffffu); rc[r] = pc >> 16;
+                    sw[rb0[r] + idx[r]] = w[r]; sv[rb0[r] + idx[r]] = v[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
-            const uint32_t bin = bn[r];
-            const uint32_t b0 = loff[bin], c = cnt[bin];
+            const uint32_t b0 = rb0[r], c = rc[r];
             uint32_t smaller = 0;
             // (four loads in flight: a bin of thousands -- keys with a rare symbol at the edge of a sub-bucket share one
             // number -- is a long loop, and one load at a time made such a workgroup the tail of the launch)
@@ -458,7 +520,6 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
 // CAP: slots the workgroup has room for in LDS -- PP_FN_CAP (the stretch of a sub-bucket), or PP_FN_SMALL for the
 // sub-buckets that hold no more than that (a text of 5 * 10^8 symbols fills a stretch to 40 %: with the smaller arrays
 // four workgroups share a CU instead of two and the per-thread loops are half as long); a launch of each
-#define PP_FN_SMALL 3072
 // list = nullptr: one workgroup per sub-bucket, those beyond CAP (up to the stretch) noted in `later`; else the listed ones
 template <int MODE, int CAP> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a, const uint32_t *__restrict__ list, uint32_t *__restrict__ later,
                                                                                        unsigned long long *__restrict__ later_count)
