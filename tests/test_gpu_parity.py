@@ -1073,6 +1073,17 @@ def test_partitioned_gapped_index_matches_oracle(P):
             e.close()
 
 
+def test_many_rows_with_gaps_take_the_record_path(engine):
+    """More rows than the window table's 16-bit row field holds (65535 and more): the scan in suffix order steps aside,
+    the per-cell tables of the record path are built on demand."""
+    rng = np.random.default_rng(66)
+    msa = random_msa(rng, 66000, 24, gap_p=0.03, gap_run=2)
+    assert (msa != ord("-")).sum(axis=1).min() > 0
+    got = engine.elastic_f(msa)
+    assert engine.get_option("index_kind") == 0
+    assert np.array_equal(got, O.compute_f(msa, threads=8))
+
+
 def test_gapped_v_on_a_partitioned_index():
     """segment2elasticValid's v[] (fbg_scan_gapped_v) from the key-range partitioned index of a multi-GPU job: the
     scan without tricks reads the all-reduced column maxima exactly as fbg_scan_f does."""

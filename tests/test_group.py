@@ -70,6 +70,15 @@ def test_group_more_partitions_than_members():
                 assert np.array_equal(grp.elastic_f(msa), O.compute_f(msa)), (members, parts)
                 assert grp.plan_used() == ("partitioned", parts)
                 assert np.array_equal(grp.repeatfree_v(msa), O.segment_v(msa)), (members, parts)
+            # MSAs with gaps / ignore characters: the partitions are scanned in suffix order (gapped_rank.hip), with and
+            # without the elastic tricks
+            for msa, ign in [(random_msa(rng, 60, 900, gap_p=0.02, gap_run=5, n_p=0.01), "N"), (random_msa(rng, 90, 500, gap_p=0.05, gap_run=2), "")]:
+                for off in (False, True):
+                    want = O.compute_f(msa, ignore=ign, disable_tricks=off)
+                    if off and want[0] == msa.shape[1]:
+                        continue
+                    assert np.array_equal(grp.elastic_f(msa, ignorechars=ign, disable_efg_tricks=off), want), (members, parts, off)
+                    assert grp.plan_used() == ("partitioned", parts)
 
 
 def test_group_row_pairs_and_non_elastic():
