@@ -153,6 +153,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
     __shared__ uint64_t sp[MODE == 1 ? PP_NB : 1];         // MODE 1: the bucket splitters G[512 j]
     __shared__ uint64_t sw[PP_STAGE];
     __shared__ uint32_t sv[PP_STAGE];
+    __shared__ uint16_t sd[MODE == 1 ? PP_STAGE : 1];
     __shared__ uint8_t tile[PP_TILE + 64];
     __shared__ uint8_t cd[256];
     __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
@@ -220,7 +221,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
 #pragma unroll
     for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; if (MODE == 1) sd[at] = (uint16_t)dg[r]; }
     }
     __syncthreads();
 #pragma unroll
@@ -228,7 +229,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
             const uint64_t x = sw[j];
-            const uint32_t d = MODE == 1 ? pp_digit_of_slot(loff, j) : pp_t28(a, x) >> 19;
+            const uint32_t d = MODE == 1 ? sd[j] : pp_t28(a, x) >> 19;       // (MODE 1: the digit travels with the slot; finding it again in loff was nine LDS reads)
             const uint64_t at = gbase[d] + (j - loff[d]);
             if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; if (!a.packed) a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
             else *a.flag = 1;
@@ -258,6 +259,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpA
     __shared__ uint64_t sp[MODE == 1 ? PP_NB : 1];         // MODE 1: the inner grid keys of this tile's bucket
     __shared__ uint64_t sw[PP_TILE];
     __shared__ uint32_t sv[PP_TILE];
+    __shared__ uint16_t sd[MODE == 1 ? PP_TILE : 1];
     __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
     __shared__ unsigned long long gbase[PP_NB];
     __shared__ uint32_t wsum[PP_THREADS / 64];
@@ -291,7 +293,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpA
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
-        if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
+        if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; if (MODE == 1) sd[at] = (uint16_t)dg[r]; }
     }
     __syncthreads();
 #pragma unroll
@@ -299,7 +301,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpA
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
             const uint64_t x = sw[j];
-            const uint32_t d = MODE == 1 ? pp_digit_of_slot(loff, j) : (pp_t28(a, x) >> 10) & (PP_NB - 1);
+            const uint32_t d = MODE == 1 ? sd[j] : (pp_t28(a, x) >> 10) & (PP_NB - 1);
             const uint64_t at = gbase[d] + (j - loff[d]);
             const uint64_t sb = (uint64_t)seg * PP_NB + d;
             if (at < PP_FN_CAP) { a.w2[sb * PP_FN_CAP + at] = x; if (!a.packed) a.v2[sb * PP_FN_CAP + at] = sv[j]; }
