@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict_
             const uint32_t tp_end = t >= need ? t - need + 1 : 0;
             dp_u16x2 acc_e = dp_pair(0xffffu), acc_o = acc_e;
             uint32_t g4 = 0;
+#pragma unroll 4
             for (; g4 + 4 <= tp_end; g4 += 4) {
                 const uint32_t word = *reinterpret_cast<const uint32_t *>(row + g4);
                 const uint2 m = *reinterpret_cast<const uint2 *>(mk + 2 * g4);
@@ -478,9 +479,11 @@ __global__ __launch_bounds__(256) void k_dp_compose(uint8_t *__restrict__ Wt, ui
         for (uint32_t item = tid; item < WN * WN / 8; item += 256) {
             const uint32_t t = item / (WN / 8), k8 = (item % (WN / 8)) * 8;
             dp_u16x2 a0 = dp_pair(DPB_INF), a1 = a0, a2 = a0, a3 = a0;       // sources (k8, k8+2), (k8+1, k8+3), (k8+4, k8+6), (k8+5, k8+7)
+            // (no shortcut for w = 255: max(255, p) = 255 changes nothing, and without the branch eight iterations' loads are in
+            // flight at once -- the loop was bound by the latency of its two LDS reads)
+#pragma unroll 8
             for (uint32_t u = 0; u < WN; u++) {
                 const uint32_t w = W[t * WN + u];
-                if (w == DPB_INF) continue;
                 const uint2 p8 = *reinterpret_cast<const uint2 *>(P + u * WN + k8);
                 const dp_u16x2 ww = dp_pair(w);
                 a0 = __builtin_elementwise_min(a0, __builtin_elementwise_max(ww, dp_bits(p8.x & 0x00ff00ffu)));
