@@ -27,13 +27,21 @@ def star_msa(m, n, p=0.01, seed=7):
     return out.reshape(-1)
 
 
-def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_fraction=0.0, star=False, reps=2, gapped=False):
+def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_fraction=0.0, star=False, reps=2, gapped=False, star_gaps=0.0):
     eng = F.Engine(0)
     st = torch.cuda.Stream()
     torch.cuda.set_stream(st)
     eng.set_stream(st.cuda_stream)
     if star:
         d = star_msa(m, n)
+        if star_gaps > 0:        # gap runs of 8 on top: every cell starts one with probability star_gaps / 8 (rows keep resembling each other)
+            g = torch.Generator(device="cuda").manual_seed(11)
+            dd = d.view(m, n)
+            for i0 in range(0, m, 50):
+                i1 = min(m, i0 + 50)
+                start = (torch.rand((i1 - i0, n), device="cuda", generator=g) < star_gaps / 8).to(torch.int32)
+                run_ = torch.nn.functional.max_pool1d(torch.nn.functional.pad(start.float().unsqueeze(1), (7, 0)), 8, 1).squeeze(1) > 0
+                dd[i0:i1][run_] = ord("-")
     else:
         d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
         eng.msa_synthetic(d.data_ptr(), m, n, gap_fraction=gap_fraction, gap_run=gap_run, n_fraction=n_fraction)
@@ -62,7 +70,7 @@ def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_frac
             best = (dt, stages, blocks)
     dt, stages, blocks = best
     ext = int((d_f - torch.arange(n, device="cuda")).max()) if elastic else None
-    print(json.dumps({"config": name, "rows": m, "cols": n, "ms": round(dt * 1e3, 2), "columns_per_s": round(n / dt),
+    print(json.dumps({"config": name, "index_kind": eng.get_option("index_kind"), "rows": m, "cols": n, "ms": round(dt * 1e3, 2), "columns_per_s": round(n / dt),
                       "blocks": blocks, "max_extension": ext, "stages_ms": stages,
                       "device_GB": round(eng.device_bytes() / 1e9, 1)}), flush=True)
     eng.close()
@@ -81,6 +89,8 @@ if __name__ == "__main__":
         run("C3 1000x1M, non-elastic through segment2elasticValid", 1000, 1_000_000, elastic=False, gapped=True)
     if "star" in which:
         run("star phylogeny 1000x200k p=0.01", 1000, 200_000, star=True)
+    if "stargaps" in which:
+        run("star phylogeny 1000x200k p=0.01 with 2% gap cells (runs of 8)", 1000, 200_000, star=True, star_gaps=0.02)
     if "star1m" in which:
         run("star phylogeny 1000x1M p=0.01", 1000, 1_000_000, star=True, reps=1)
     if "c3" in which:
