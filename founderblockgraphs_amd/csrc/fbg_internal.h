@@ -37,7 +37,7 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0;
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0;
 };
 
 struct fbg_ctx {
@@ -94,6 +94,7 @@ struct fbg_ctx {
     DevBuf gwin_rows;              // u16 per window of 128 positions: the row of its first position (written with the text)
     const uint64_t *grs_ebits = nullptr;   // gbits while the pack kernels are to fold it into bit 31 of the sort's values
     bool grs_flagged = false;      // the sorted values carry that bit
+    bool pairs_similar = false;    // the sample of the (key, position) sort says: rows that resemble each other (ties everywhere)
     bool grs_ties_done = false;    // the tie groups of the kept slots are in text order
     bool gpart = false;            // one key-range partition of such an index (fbg_part_*)
     bool grs_part_failed = false;  // its exact redo of a few columns ran out of room

@@ -728,6 +728,14 @@ __global__ void k_ss_sample(const uint8_t *__restrict__ T, uint64_t N, const uin
     out[i] = key;
 }
 
+__global__ void k_ss_twins(const uint64_t *__restrict__ sorted, uint64_t S, unsigned long long *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool twin = i + 1 < S && sorted[i] == sorted[i + 1];
+    const unsigned long long mask = __ballot(twin);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(out, (unsigned long long)__popcll(mask));
+}
+
 __global__ void k_ss_grid(const uint64_t *__restrict__ sorted, uint64_t S, uint64_t *__restrict__ grid)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -739,6 +747,7 @@ __global__ void k_ss_grid(const uint64_t *__restrict__ sorted, uint64_t S, uint6
 int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches)
 {
     *ok = 0;
+    ctx->pairs_similar = false;
     const uint64_t N = ctx->N;
     const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);
     const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
@@ -762,6 +771,21 @@ int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches
         size_t have = ctx->tmp.cap;
         e = rocprim::radix_sort_keys(ctx->tmp.p, have, smp, srt, (size_t)S, 0u, (unsigned)g.key_bits, st);
         if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_keys: %s", hipGetErrorString(e));
+    }
+    {
+        // rows that resemble each other tie on most keys: a suffix with a twin somewhere shows up as a twin in the sample
+        // with probability S / N.  Sub-buckets full of equal keys make the finish quadratic (52 ms for 2 * 10^8 suffixes of
+        // a star phylogeny with gaps), and the scan in suffix order that would follow declines such inputs anyway:
+        // leave them to the library sort and say so (ctx->pairs_similar)
+        unsigned long long *d_twins = ctx->scalars.as<unsigned long long>() + 104;
+        FBG_HIP_TRY(ctx, hipMemsetAsync(d_twins, 0, 8, st));
+        hipLaunchKernelGGL(k_ss_twins, dim3(fbg_blocks(S, 256)), dim3(256), 0, st, srt, S, d_twins);
+        unsigned long long twins = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&twins, d_twins, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        *launches += 1;
+        ctx->pairs_similar = (double)twins * (double)N / ((double)S * (double)S) > 0.5 && !ctx->opt.msd_min_force;
+        if (ctx->pairs_similar) return FBG_OK;
     }
     hipLaunchKernelGGL(k_ss_grid, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, srt, S, grid);
     *launches += 3;

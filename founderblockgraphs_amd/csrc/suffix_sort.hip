@@ -892,6 +892,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     ct.last = (uint32_t)(N - 1);
     // MSAs with gaps / ignore characters: the scan in rank order follows the sort (gapped_rank.hip); its table of the
     // text's irregular positions is made now, the pack kernels fold it into the values' top bit
+    ctx->pairs_similar = false;
     const bool try_grs = (!ctx->gapfree || ctx->have_ignore) && !ctx->reversed && !ctx->grs_skip && ctx->opt.gapped_rank != -1 && K <= 32;
     if (try_grs) FBG_TRY(fbg_grs_prepare(ctx, &launches));
     {
@@ -917,7 +918,8 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     }
     // ---- MSAs with gaps / ignore characters: the extension scan in rank order on these slots (gapped_rank.hip) ----
     ctx->grs_ebits = nullptr;
-    if (try_grs) {
+    if (try_grs && ctx->pairs_similar) FBG_TRY(fbg_grs_strip(ctx, valsB));    // similar rows: tie groups of hundreds, not for that scan
+    else if (try_grs) {
         int done = 0;
         FBG_TRY(fbg_grs_try(ctx, keysB, valsB, g, &done));
         if (done) {

@@ -82,6 +82,7 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   dp_literal, dp_wave, dp_tile, dp_safe_window   which sweep kernel runs the min-max-length / non-elastic DP
  *   gapped_rank        -1: MSAs with gaps / ignore characters always take the record path (no scan in suffix order)
  *   part_tricks_off    1: the partitioned index of an MSA with gaps / ignore characters is scanned without the elastic tricks
+ *   msd_min_force      1: the sample sort of (key, position) pairs also for rows that resemble each other (tests)
  *   msd_sample_bins    1: the finish of the sample sort bins by sampled keys instead of symbol ranks (the earlier method, kept for tests)
  *   gapped_rank also takes 2 (no flag bits in the sort's values), 3 (flag bits, no threshold), 4 (threshold forced: tests)
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a

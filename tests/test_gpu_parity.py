@@ -401,6 +401,7 @@ ALT_PATHS = [
     {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"},
     {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"},
     {"FBG_MSD_MIN": "1", "FBG_MSD_SAMPLE_BINS": "1"},  # sample sort whose finish bins by sampled keys instead of symbol ranks
+    {"FBG_MSD_MIN": "1", "FBG_MSD_MIN_FORCE": "1", "FBG_NO_RANKED": "1"},   # the sample sort of pairs also where rows resemble each other
     {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1", "FBG_MSD_SAMPLE_BINS": "1"},
     {"FBG_DP_WAVE": "1"},                            # wave-parallel sweep instead of the matrix chain
     {"FBG_DP_TILE": "1"},                            # 8-steps-per-iteration sweep
