@@ -610,6 +610,193 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
     if (lane == 0) { result[0] = err ? 0 : cnt; result[1] = err ? 1 : 0; }
 }
 
+// ---- wide windows: the matrix chain for block lengths of up to one or two thousand columns --------------------------
+//
+// Rows that resemble each other, with gaps: behind a deletion a row's string occurs in the other rows some columns on, the
+// minimal extensions reach hundreds of columns and so do the blocks -- beyond the byte entries and LDS-sized square
+// matrices above, and the statement-by-statement sweep walks such an input at 0.5 us per column.  The same product with
+// 16-bit entries and RECTANGULAR matrices: a block of DPW_B = 128 steps acts on the WS (1024 or 2048) values before it
+// through M_b[t][k] -- the recurrence of a source k along the block's steps only involves the block's own 128 columns
+// as intermediate candidates, so a thread owns a source and keeps 128 values in LDS, 256 sources per workgroup.
+//   k_dpw_blockM   all M_b, independently: (n / 128) * (WS / 256) workgroups; two candidates per 32-bit LDS word go
+//                  through packed 16-bit max / min, their validity comes from a per-wave mask as in k_dp_blockW
+//   k_dpw_chain    one workgroup walks the blocks: minmaxlength of a block's 128 columns = M_b (x) the ring of the last WS
+//                  values (lanes along the sources: coalesced rows, one reduction per target)
+//   k_dpw_bt       backtrack[j] from minmaxlength[] as k_dp_bt, 16-bit extensions
+// A value that reaches WS raises flag[4] (the exactness argument of fbg_dp_minmax): next size, then the literal sweep.
+#define DPW_B 128u
+#define DPW_INF 0xffffu
+typedef uint16_t __attribute__((may_alias)) dpw_u16;     // the LDS rows are written as 16-bit entries and read as pairs / quads
+typedef uint32_t __attribute__((may_alias)) dpw_u32;
+__global__ void k_dpw_prep(const uint32_t *__restrict__ e, uint32_t n, uint16_t *__restrict__ ext16)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    ext16[j] = j < n ? (uint16_t)min(e[j] - j, DPW_INF) : (uint16_t)DPW_INF;
+}
+
+template <uint32_t WS>
+__global__ __launch_bounds__(256) void k_dpw_blockM(const uint16_t *__restrict__ ext16, uint32_t n, uint16_t *__restrict__ M)
+{
+    constexpr uint32_t RP = DPW_B + 2;            // row stride in 16-bit entries: 65 words, the lanes' rows start in different banks
+    __shared__ uint32_t rows_w[256 * RP / 2];     // row k, entry t: M of inside column (block start + 1 + t) for source k
+    __shared__ uint16_t s_ext[DPW_B];
+    __shared__ uint32_t mk_w[4][DPW_B / 2];       // per wave: candidates 2g, 2g + 1 as the 16-bit lanes of word g; 0xffff = does not count yet
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t k = blockIdx.y * 256 + threadIdx.x;                   // source: prefix length xs = jb - WS + 1 + k
+    const uint32_t jb = DPW_B * b;
+    const int64_t xs = (int64_t)jb - (int64_t)(WS - 1) + k;
+    const uint32_t ext_src = xs >= 0 ? ext16[xs] : DPW_INF;
+    if (threadIdx.x < DPW_B) s_ext[threadIdx.x] = jb + 1 + threadIdx.x < n ? ext16[jb + 1 + threadIdx.x] : (uint16_t)DPW_INF;
+    __syncthreads();
+    uint32_t minext = DPW_INF;
+    for (uint32_t q = 0; q < DPW_B; q++) minext = min(minext, (uint32_t)s_ext[q]);
+    dpw_u32 *mk = reinterpret_cast<dpw_u32 *>(mk_w[wv]);
+    dpw_u16 *mk16 = reinterpret_cast<dpw_u16 *>(mk_w[wv]);
+    mk[lane] = 0xffffffffu;
+    uint32_t ready[2];                                                   // the step from which the lane's candidates (lane, lane + 64) count
+#pragma unroll
+    for (int r = 0; r < 2; r++) { const uint32_t tp = lane + 64 * r; ready[r] = tp + max(1u, (uint32_t)s_ext[tp]); }
+    dpw_u16 *row = reinterpret_cast<dpw_u16 *>(rows_w) + threadIdx.x * RP;
+    const dpw_u32 *row32 = reinterpret_cast<const dpw_u32 *>(rows_w) + threadIdx.x * (RP / 2);
+    uint16_t *out = M + (size_t)b * DPW_B * WS + k;
+    for (uint32_t t = 0; t < DPW_B; t++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (ready[r] == t) mk16[lane + 64 * r] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t age_src = t + WS - k;                             // (jb + 1 + t) - xs
+        uint32_t w = (ext_src <= age_src && age_src <= WS) ? age_src : DPW_INF;
+        const uint32_t tp_end = t >= minext ? t - minext + 1 : 0;        // inside candidates need age >= their extension >= minext
+        dp_u16x2 acc = dp_pair(DPW_INF);
+        uint32_t g2 = 0;
+#pragma unroll 4
+        for (; 2 * g2 + 2 <= tp_end; g2++) {
+            const uint32_t base = t - 2 * g2;                            // ages of candidates 2 g2 and 2 g2 + 1
+            acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(row32[g2] | mk[g2]), dp_bits(base | ((base - 1) << 16))));
+        }
+        if (2 * g2 < tp_end) {                                           // one candidate left: the odd lane does not count
+            const uint32_t base = t - 2 * g2;
+            acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(row32[g2] | mk[g2] | 0xffff0000u), dp_bits(base | 0xffff0000u)));
+        }
+        w = min(w, min((uint32_t)acc.x, (uint32_t)acc.y));
+        row[t] = (uint16_t)w;
+        out[(size_t)t * WS] = (uint16_t)w;                               // M[b][t][k]
+    }
+}
+
+template <uint32_t WS>
+__global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__ M, uint32_t n, uint32_t nblocks, uint32_t *__restrict__ mml,
+                                                    unsigned long long *__restrict__ flag)
+{
+    // ring[(x - 1) & (WS - 1)] = minmaxlength of prefix length x, for the WS prefix lengths before the current block:
+    // source k of block b (x = jb - WS + 1 + k) sits at (jb + k) & (WS - 1) -- eight sources stay 16-byte aligned.
+    // 16 waves of 8 targets each: a wave's 8 rows of M_b are contiguous, a lane holds 8 sources per 16-byte load, and the
+    // rows are loaded one stage ahead of their use (across block ends too), so the walk runs at the rate one CU takes in M
+    constexpr uint32_t NQ = WS / 512;            // 16-byte loads per lane and row
+    constexpr uint32_t TI = WS == 1024 ? 4 : 2;  // targets per stage: the rows of the next stage are loaded while this one is worked on
+    constexpr uint32_t NS = 8 / TI;              // stages per block (even: a block starts on buffer 0)
+    __shared__ uint4 ring4[WS / 8];
+    __shared__ uint32_t fresh[DPW_B];
+    dpw_u16 *ring = reinterpret_cast<dpw_u16 *>(ring4);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < WS / 8; i += 1024) ring4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    __syncthreads();
+    if (threadIdx.x == 0) { ring[WS - 1] = 0; mml[0] = 0; }              // prefix length 0
+    __syncthreads();
+    bool bad = false;
+    const uint4 *M4 = reinterpret_cast<const uint4 *>(M) + (size_t)(8 * wv) * (WS / 8) + lane;
+    uint4 rw[2][TI][NQ];
+#pragma unroll
+    for (uint32_t i = 0; i < TI; i++)
+#pragma unroll
+        for (uint32_t c = 0; c < NQ; c++) rw[0][i][c] = M4[(size_t)i * (WS / 8) + 64 * c];
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t jb = DPW_B * b;
+        uint4 st[NQ];
+#pragma unroll
+        for (uint32_t c = 0; c < NQ; c++) st[c] = ring4[((jb >> 3) + 64 * c + lane) & (WS / 8 - 1)];
+        uint32_t part[8];                        // the lane's minimum per target of the wave
+#pragma unroll
+        for (uint32_t sg = 0; sg < NS; sg++) {
+            // the next stage's rows (of the next block after the last stage: M does not depend on the state)
+            const uint32_t nb = sg + 1 < NS ? b : b + 1, ni0 = sg + 1 < NS ? TI * (sg + 1) : 0;
+            if (nb < nblocks) {
+                const uint4 *Mn = M4 + (size_t)nb * DPW_B * (WS / 8) + (size_t)ni0 * (WS / 8);
+#pragma unroll
+                for (uint32_t i = 0; i < TI; i++)
+#pragma unroll
+                    for (uint32_t c = 0; c < NQ; c++) rw[(sg + 1) & 1][i][c] = Mn[(size_t)i * (WS / 8) + 64 * c];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < TI; i++) {
+                dp_u16x2 acc = dp_pair(DPW_INF);
+#pragma unroll
+                for (uint32_t c = 0; c < NQ; c++) {
+                    const uint4 r = rw[sg & 1][i][c];
+                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].x), dp_bits(r.x)));
+                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].y), dp_bits(r.y)));
+                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].z), dp_bits(r.z)));
+                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].w), dp_bits(r.w)));
+                }
+                part[TI * sg + i] = min((uint32_t)acc.x, (uint32_t)acc.y);
+            }
+        }
+        // the eight minima over the wave in 7 exchanges instead of 48: two targets per word, and each exchange halves what a
+        // lane still carries (lanes 32.. keep targets 4..7, then lanes with bit 4 set the odd pair), before the last four
+        // steps run on one word
+        uint32_t w0 = part[0] | (part[1] << 16), w1 = part[2] | (part[3] << 16), w2 = part[4] | (part[5] << 16), w3 = part[6] | (part[7] << 16);
+        {
+            const bool up = (lane & 32) != 0;
+            const uint32_t s0 = up ? w0 : w2, s1 = up ? w1 : w3;           // what goes to the other half
+            const uint32_t k0 = up ? w2 : w0, k1 = up ? w3 : w1;
+            w0 = dp_word(__builtin_elementwise_min(dp_bits(k0), dp_bits((uint32_t)__shfl_xor((int)s0, 32, 64))));
+            w1 = dp_word(__builtin_elementwise_min(dp_bits(k1), dp_bits((uint32_t)__shfl_xor((int)s1, 32, 64))));
+            const bool odd = (lane & 16) != 0;
+            const uint32_t s = odd ? w0 : w1, k = odd ? w1 : w0;
+            w0 = dp_word(__builtin_elementwise_min(dp_bits(k), dp_bits((uint32_t)__shfl_xor((int)s, 16, 64))));
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) w0 = dp_word(__builtin_elementwise_min(dp_bits(w0), dp_bits((uint32_t)__shfl_xor((int)w0, d, 64))));
+            if ((lane & 15) == 0) {                                        // lane 0: targets 0, 1; 16: 2, 3; 32: 4, 5; 48: 6, 7
+                const uint32_t t0 = 8 * wv + 4 * (lane >> 5) + 2 * ((lane >> 4) & 1);
+                fresh[t0] = w0 & 0xffffu;
+                fresh[t0 + 1] = w0 >> 16;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < DPW_B) {
+            const uint32_t j = jb + 1 + threadIdx.x;
+            const uint32_t v = fresh[threadIdx.x];
+            ring[(j - 1) & (WS - 1)] = (uint16_t)v;                      // takes the place of prefix length j - WS
+            if (j <= n) { mml[j] = v; if (v >= WS) bad = true; }
+        }
+        __syncthreads();
+    }
+    if (bad) flag[4] = 1;
+}
+
+__global__ void k_dpw_bt(const uint32_t *__restrict__ mml, const uint16_t *__restrict__ ext16, uint32_t n, uint32_t window, uint32_t *__restrict__ bt,
+                         unsigned long long *__restrict__ flag)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    if (j == 0) { bt[0] = 0; return; }
+    const uint32_t L = mml[j];
+    uint32_t best_age = 0;                    // youngest count_solutions-kind candidate (age <= its value == L)
+    bool s_kind = false;                      // candidate of age L with a smaller value: the S / backtrack_S branch
+    const uint32_t amax = min(min(window, L), j);   // both kinds have age <= L
+    for (uint32_t a = 1; a <= amax; a++) {
+        const uint32_t x = j - a;
+        if (ext16[x] > a) continue;           // block [x, j) not valid yet: f[x]+1 > j
+        const uint32_t v = mml[x];
+        if (a > v) { if (a == L) s_kind = true; }
+        else if (v == L && best_age == 0) best_age = a;
+    }
+    if (s_kind) bt[j] = j - L;
+    else if (best_age) bt[j] = j - best_age;
+    else { bt[j] = 0; flag[4] = 1; }
+}
+
 // ---- parallel backtrack (fbg.cpp:2026-2039) by binary lifting --------------------------------------
 // backtrack[] is a forest towards column 0.  up[k][j] = the column reached from j after 2^k hops (0 absorbs),
 // dep[j] = number of hops from j to 0.  The boundary list of the reference, [.., backtrack-1, .., n], has
@@ -777,7 +964,38 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     }
     bool literal = R == 0;
     bool tiled = false;
-    if (!literal) {
+    // extensions of hundreds of columns: the matrix chain with 16-bit entries (k_dpw_*), smallest window first
+    const bool wide_ok = f0 == 0 && f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 2048 && n >= 2 * DPW_B;
+    auto try_wide = [&](bool &done) -> int {
+        const uint32_t nblocks = (uint32_t)((n + DPW_B - 1) / DPW_B);
+        uint16_t *ext16 = ctx->dp_e.as<uint16_t>();
+        hipLaunchKernelGGL(k_dpw_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext16);
+        for (uint32_t WS = max_ext + 2 <= 1024 ? 1024u : 2048u; WS <= 2048 && !done; WS *= 2) {
+            const size_t mbytes = (size_t)nblocks * DPW_B * WS * 2;
+            if (mbytes > (16ull << 30)) break;
+            FBG_TRY(fbg_reserve(ctx, ctx->tmp, mbytes));
+            uint16_t *Mw = ctx->tmp.as<uint16_t>();
+            FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+            if (WS == 1024) {
+                hipLaunchKernelGGL((k_dpw_blockM<1024>), dim3(nblocks, 1024 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
+                hipLaunchKernelGGL((k_dpw_chain<1024>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc);
+            } else {
+                hipLaunchKernelGGL((k_dpw_blockM<2048>), dim3(nblocks, 2048 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
+                hipLaunchKernelGGL((k_dpw_chain<2048>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc);
+            }
+            hipLaunchKernelGGL(k_dpw_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext16, (uint32_t)n, WS, bt, sc);
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            done = hk[4] == 0;
+        }
+        if (!done) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+        return FBG_OK;
+    };
+    if (literal && wide_ok) {
+        FBG_TRY(try_wide(tiled));
+        if (tiled) literal = false;
+    }
+    if (!literal && !tiled) {
         bool settled = false;
         if (!ctx->opt.dp_wave || f0 != 0) {
             // sweeps that work straight from f (no bucket order needed).  The window that is provably enough
@@ -833,6 +1051,10 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             }
             tiled = settled;
             if (!settled) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+            if (!settled && wide_ok) {
+                FBG_TRY(try_wide(settled));
+                tiled = settled;
+            }
         }
         if (!settled) FBG_TRY(build_buckets());        // also zeroes what the abandoned attempts left in count / bcount / mml / bt
         if (!settled && f0 == 0 && (R > 4 || ctx->opt.dp_wave)) {

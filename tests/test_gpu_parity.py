@@ -161,6 +161,21 @@ def test_dp_sweep_random_f(engine, max_ext, style):
         assert np.array_equal(gb, b)
 
 
+@pytest.mark.parametrize("max_ext", [254, 255, 300, 700, 1021, 1022, 1023, 1500, 2045, 2046, 2047, 3000])
+@pytest.mark.parametrize("style", ["uniform", "plateau", "spiky"])
+def test_dp_sweep_wide_windows(engine, max_ext, style):
+    """Extensions of hundreds of columns: the 16-bit matrix chain (k_dpw_*), its two window sizes, and the hand-over to
+    the literal sweep when a value reaches the window."""
+    rng = np.random.default_rng(max_ext * 11 + len(style))
+    for n in (255, 256, 257, 1500, 40_000):
+        f = _random_f(rng, n, max_ext, style)
+        mml, bt, b = O.minmax_dp(f)
+        gb, gmml, gbt = engine.minmax_dp(f, full=True)
+        assert np.array_equal(gmml, mml), (n, np.flatnonzero(gmml != mml)[:5])
+        assert np.array_equal(gbt, bt), (n, np.flatnonzero(gbt != bt)[:5])
+        assert np.array_equal(gb, b)
+
+
 def test_dp_sweep_f0_nonzero_uses_literal_semantics(engine):
     """f[0] != 0 (only with --disable-elastic-tricks): lazy-I quirks of fbg.cpp:2004-2013 must survive."""
     import founderblockgraphs_amd as F
