@@ -196,6 +196,7 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
         if (strcmp(k.name, key) == 0) { *value = ctx->opt.*(k.field); return FBG_OK; }
     if (strcmp(key, "grs_threshold") == 0) { *value = ctx->grs_t; return FBG_OK; }
     if (strcmp(key, "grs_redone") == 0) { *value = (int64_t)ctx->grs_redone; return FBG_OK; }
+    if (strcmp(key, "dp_kind") == 0) { *value = ctx->dp_kind; return FBG_OK; }
     if (strcmp(key, "index_kind") == 0) {      // read-only: which form the current index has
         *value = !ctx->index_valid ? -1 : ctx->part_active ? 3 : ctx->granked ? 2 : ctx->ranked ? 1 : 0;
         return FBG_OK;

@@ -687,8 +687,10 @@ __global__ __launch_bounds__(256) void k_dpw_blockM(const uint16_t *__restrict__
 
 template <uint32_t WS>
 __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__ M, uint32_t n, uint32_t nblocks, uint32_t *__restrict__ mml,
-                                                    unsigned long long *__restrict__ flag)
+                                                    unsigned long long *__restrict__ flag, uint32_t first_valid)
 {
+    // first_valid = f[0] + 1 as in k_dp_expand: the steps before it have no value (the ring keeps "none") and the reference's
+    // arrays hold the running S there
     // ring[(x - 1) & (WS - 1)] = minmaxlength of prefix length x, for the WS prefix lengths before the current block:
     // source k of block b (x = jb - WS + 1 + k) sits at (jb + k) & (WS - 1) -- eight sources stay 16-byte aligned.
     // 16 waves of 8 targets each: a wave's 8 rows of M_b are contiguous, a lane holds 8 sources per 16-byte load, and the
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
             const uint32_t j = jb + 1 + threadIdx.x;
             const uint32_t v = fresh[threadIdx.x];
             ring[(j - 1) & (WS - 1)] = (uint16_t)v;                      // takes the place of prefix length j - WS
-            if (j <= n) { mml[j] = v; if (v >= WS) bad = true; }
+            if (j <= n) { if (j < first_valid) mml[j] = n + j; else { mml[j] = v; if (v >= WS) bad = true; } }
         }
         __syncthreads();
     }
@@ -776,11 +778,12 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
 }
 
 __global__ void k_dpw_bt(const uint32_t *__restrict__ mml, const uint16_t *__restrict__ ext16, uint32_t n, uint32_t window, uint32_t *__restrict__ bt,
-                         unsigned long long *__restrict__ flag)
+                         unsigned long long *__restrict__ flag, uint32_t first_valid)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n) return;
     if (j == 0) { bt[0] = 0; return; }
+    if (j < first_valid) { bt[j] = DP_NONE; return; }
     const uint32_t L = mml[j];
     uint32_t best_age = 0;                    // youngest count_solutions-kind candidate (age <= its value == L)
     bool s_kind = false;                      // candidate of age L with a smaller value: the S / backtrack_S branch
@@ -789,6 +792,7 @@ __global__ void k_dpw_bt(const uint32_t *__restrict__ mml, const uint16_t *__res
         const uint32_t x = j - a;
         if (ext16[x] > a) continue;           // block [x, j) not valid yet: f[x]+1 > j
         const uint32_t v = mml[x];
+        if (v > n) continue;                  // a column before first_valid: no solution ends there (fbg.cpp:1973)
         if (a > v) { if (a == L) s_kind = true; }
         else if (v == L && best_age == 0) best_age = a;
     }
@@ -965,7 +969,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     bool literal = R == 0;
     bool tiled = false;
     // extensions of hundreds of columns: the matrix chain with 16-bit entries (k_dpw_*), smallest window first
-    const bool wide_ok = f0 == 0 && f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 2048 && n >= 2 * DPW_B;
+    const bool wide_ok = f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 2048 && n >= 2 * DPW_B;
     auto try_wide = [&](bool &done) -> int {
         const uint32_t nblocks = (uint32_t)((n + DPW_B - 1) / DPW_B);
         uint16_t *ext16 = ctx->dp_e.as<uint16_t>();
@@ -978,15 +982,16 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
             if (WS == 1024) {
                 hipLaunchKernelGGL((k_dpw_blockM<1024>), dim3(nblocks, 1024 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
-                hipLaunchKernelGGL((k_dpw_chain<1024>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc);
+                hipLaunchKernelGGL((k_dpw_chain<1024>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
             } else {
                 hipLaunchKernelGGL((k_dpw_blockM<2048>), dim3(nblocks, 2048 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
-                hipLaunchKernelGGL((k_dpw_chain<2048>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc);
+                hipLaunchKernelGGL((k_dpw_chain<2048>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
             }
-            hipLaunchKernelGGL(k_dpw_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext16, (uint32_t)n, WS, bt, sc);
+            hipLaunchKernelGGL(k_dpw_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext16, (uint32_t)n, WS, bt, sc, first_valid);
             FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
             done = hk[4] == 0;
+            if (done) ctx->dp_kind = WS == 1024 ? 3 : 4;
         }
         if (!done) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
         return FBG_OK;
@@ -1050,6 +1055,7 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
                 settled = hk[4] == 0;
             }
             tiled = settled;
+            if (settled) ctx->dp_kind = 1;
             if (!settled) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
             if (!settled && wide_ok) {
                 FBG_TRY(try_wide(settled));
@@ -1068,10 +1074,12 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
             settled = hk[4] == 0;
+            if (settled) ctx->dp_kind = 2;
         }
         if (!settled) literal = true;   // guards tripped: the literal sweep
     }
     if (literal) {
+        ctx->dp_kind = 0;
         FBG_TRY(build_buckets());
         FBG_HIP_TRY(ctx, hipMemsetAsync(count, 0, w, st));
         FBG_HIP_TRY(ctx, hipMemsetAsync(bcount, 0, w, st));

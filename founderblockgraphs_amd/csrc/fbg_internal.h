@@ -100,6 +100,7 @@ struct fbg_ctx {
     bool grs_part_failed = false;  // its exact redo of a few columns ran out of room
     uint32_t grs_t = 1;            // the threshold of the last scan (1: none), the columns it redid exactly
     uint64_t grs_redone = 0;
+    int dp_kind = -1;            // which sweep produced the last fbg_dp_minmax result (fbg_get_option "dp_kind")
     bool cells_built = false;      // prow / igrow hold the current MSA (built on demand: only the record path reads them)
     uint8_t ignore_tab[256] = {0};
     uint64_t *rk_keys = nullptr; // sorted slots: keys (pairs layout, positions in sa_ptr) or key << rk_pb | position (packed)

@@ -167,13 +167,21 @@ def test_dp_sweep_wide_windows(engine, max_ext, style):
     """Extensions of hundreds of columns: the 16-bit matrix chain (k_dpw_*), its two window sizes, and the hand-over to
     the literal sweep when a value reaches the window."""
     rng = np.random.default_rng(max_ext * 11 + len(style))
-    for n in (255, 256, 257, 1500, 40_000):
+    kinds = set()
+    for n in (255, 256, 257, 1500, 40_000, 40_001):
         f = _random_f(rng, n, max_ext, style)
+        if n == 40_001:               # f[0] > 0 (only without the elastic tricks): nothing ends before step f[0] + 1
+            f[0] = min(n - 1, int(rng.integers(1, max_ext + 1)))
         mml, bt, b = O.minmax_dp(f)
         gb, gmml, gbt = engine.minmax_dp(f, full=True)
         assert np.array_equal(gmml, mml), (n, np.flatnonzero(gmml != mml)[:5])
         assert np.array_equal(gbt, bt), (n, np.flatnonzero(gbt != bt)[:5])
         assert np.array_equal(gb, b)
+        kinds.add(engine.get_option("dp_kind"))
+        if n >= 40_000 and style == "uniform" and 512 <= max_ext <= 2045:
+            # extensions of every size up to max_ext: beyond the byte matrices, within the 16-bit ones (f[0] > 0 included)
+            assert engine.get_option("dp_kind") in (3, 4), (n, max_ext, engine.get_option("dp_kind"))
+    assert kinds <= {0, 1, 2, 3, 4}
 
 
 def test_dp_sweep_f0_nonzero_uses_literal_semantics(engine):
