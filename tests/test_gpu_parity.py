@@ -184,6 +184,33 @@ def test_dp_sweep_wide_windows(engine, max_ext, style):
     assert kinds <= {0, 1, 2, 3, 4}
 
 
+def test_dp_sweep_wide_windows_full_size(engine):
+    """10^6 columns whose extensions reach 900 columns (rows that resemble each other, with gaps): the 16-bit matrix chain
+    against the statement-by-statement sweep, and the properties of a valid segmentation."""
+    import torch
+    n = 1_000_000
+    rng = np.random.default_rng(99)
+    f = _random_f(rng, n, 900, "plateau").astype(np.int64)
+    d_f = torch.from_numpy(f).cuda()
+    out = []
+    for literal in (0, 1):
+        with fbg_options(engine, {"FBG_DP_LITERAL": str(literal)}):
+            d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            d_mml = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            d_bt = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            cnt = engine.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr(), d_mml.data_ptr(), d_bt.data_ptr())
+            assert engine.get_option("dp_kind") == (0 if literal else 3)
+            out.append((cnt, d_b[:cnt].clone(), d_mml, d_bt))
+    assert out[0][0] == out[1][0] and all(torch.equal(out[0][k], out[1][k]) for k in (1, 2, 3))
+    b = out[0][1]
+    assert int(b[-1]) == n and bool((b[1:] > b[:-1]).all())
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), b[:-1] + 1])
+    ends = torch.cat([b[:-1], torch.tensor([n - 1], device="cuda")])
+    assert bool((d_f[starts] <= ends).all())
+    assert int((ends - starts + 1).max()) == int(out[0][2][n]) > 256
+
+
 def test_dp_sweep_f0_nonzero_uses_literal_semantics(engine):
     """f[0] != 0 (only with --disable-elastic-tricks): lazy-I quirks of fbg.cpp:2004-2013 must survive."""
     import founderblockgraphs_amd as F
