@@ -695,9 +695,8 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
     // source k of block b (x = jb - WS + 1 + k) sits at (jb + k) & (WS - 1) -- eight sources stay 16-byte aligned.
     // 16 waves of 8 targets each: a wave's 8 rows of M_b are contiguous, a lane holds 8 sources per 16-byte load, and the
     // rows are loaded one stage ahead of their use (across block ends too), so the walk runs at the rate one CU takes in M
-    constexpr uint32_t NQ = WS / 512;            // 16-byte loads per lane and row
-    constexpr uint32_t TI = WS == 1024 ? 4 : 2;  // targets per stage: the rows of the next stage are loaded while this one is worked on
-    constexpr uint32_t NS = 8 / TI;              // stages per block (even: a block starts on buffer 0)
+    // what it has to read of it
+    constexpr uint32_t NQ = WS / 512;            // chunks of 512 sources: one 16-byte load per lane and row
     __shared__ uint4 ring4[WS / 8];
     __shared__ uint32_t fresh[DPW_B];
     dpw_u16 *ring = reinterpret_cast<dpw_u16 *>(ring4);
@@ -708,42 +707,59 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
     __syncthreads();
     bool bad = false;
     const uint4 *M4 = reinterpret_cast<const uint4 *>(M) + (size_t)(8 * wv) * (WS / 8) + lane;
-    uint4 rw[2][TI][NQ];
+    // Sources that cannot win are not read: every way from source k into the block starts with a block of at least
+    // WS - k columns (up to the block's first column), and minmaxlength grows by at most 1 per column (the last block of
+    // an optimal segmentation, one column longer, is still valid) -- so with L = minmaxlength at the column before the
+    // block no target of the block lies above L + 128, and no source with WS - k > L + 128 can give its minimum.  The
+    // chunks go from the youngest sources down; whole chunks below the bound are left out, in the chunk that holds it the
+    // lanes below it skip their load (a lane holds sources 512 c + 8 lane .. + 7; the youngest chunk of the NEXT block is
+    // asked for one block early: L + 256).  The chain reads in proportion to the block lengths, not to the window.
+    // A stage = one chunk of the wave's 8 rows; the next stage's rows are loaded while this one is worked on.
+    const uint4 none = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    uint32_t L = 0;                              // minmaxlength[jb]; "none" (f[0] > 0, or past a flagged value): no bound
+    uint4 buf[2][8];
 #pragma unroll
-    for (uint32_t i = 0; i < TI; i++)
-#pragma unroll
-        for (uint32_t c = 0; c < NQ; c++) rw[0][i][c] = M4[(size_t)i * (WS / 8) + 64 * c];
+    for (uint32_t i = 0; i < 8; i++) buf[0][i] = M4[(size_t)i * (WS / 8) + 64 * (NQ - 1)];
     for (uint32_t b = 0; b < nblocks; b++) {
         const uint32_t jb = DPW_B * b;
-        uint4 st[NQ];
+        const uint32_t kmin_here = WS - min(L + DPW_B, WS), kmin_next = WS - min(L + 2 * DPW_B, WS);
+        const uint32_t ns = NQ - min(kmin_here / 512, NQ - 1);           // chunks NQ-1 .. NQ-ns are read
+        const uint4 *Mb = M4 + (size_t)b * DPW_B * (WS / 8);
+        dp_u16x2 acc[8];
 #pragma unroll
-        for (uint32_t c = 0; c < NQ; c++) st[c] = ring4[((jb >> 3) + 64 * c + lane) & (WS / 8 - 1)];
-        uint32_t part[8];                        // the lane's minimum per target of the wave
+        for (uint32_t i = 0; i < 8; i++) acc[i] = dp_pair(DPW_INF);
 #pragma unroll
-        for (uint32_t sg = 0; sg < NS; sg++) {
-            // the next stage's rows (of the next block after the last stage: M does not depend on the state)
-            const uint32_t nb = sg + 1 < NS ? b : b + 1, ni0 = sg + 1 < NS ? TI * (sg + 1) : 0;
-            if (nb < nblocks) {
-                const uint4 *Mn = M4 + (size_t)nb * DPW_B * (WS / 8) + (size_t)ni0 * (WS / 8);
+        for (uint32_t sg = 0; sg < NQ; sg++) {
+            if (sg < ns) {                                               // uniform
+                const uint32_t c = NQ - 1 - sg;
+                if (sg + 1 < ns) {                                       // the next chunk of this block (c >= 1 here)
+                    const bool need = 512 * (c - 1) + 8 * lane + 7 >= kmin_here;
 #pragma unroll
-                for (uint32_t i = 0; i < TI; i++)
+                    for (uint32_t i = 0; i < 8; i++) buf[(sg + 1) & 1][i] = need ? Mb[(size_t)i * (WS / 8) + 64 * (c - 1)] : none;
+                } else if (b + 1 < nblocks) {                            // the youngest chunk of the next block: M does not depend on the state
+                    const bool need = 512 * (NQ - 1) + 8 * lane + 7 >= kmin_next;
 #pragma unroll
-                    for (uint32_t c = 0; c < NQ; c++) rw[(sg + 1) & 1][i][c] = Mn[(size_t)i * (WS / 8) + 64 * c];
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < TI; i++) {
-                dp_u16x2 acc = dp_pair(DPW_INF);
-#pragma unroll
-                for (uint32_t c = 0; c < NQ; c++) {
-                    const uint4 r = rw[sg & 1][i][c];
-                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].x), dp_bits(r.x)));
-                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].y), dp_bits(r.y)));
-                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].z), dp_bits(r.z)));
-                    acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(st[c].w), dp_bits(r.w)));
+                    for (uint32_t i = 0; i < 8; i++)
+                        buf[(sg + 1) & 1][i] = need ? Mb[(size_t)(DPW_B + i) * (WS / 8) + 64 * (NQ - 1)] : none;
                 }
-                part[TI * sg + i] = min((uint32_t)acc.x, (uint32_t)acc.y);
+                const uint4 s4 = ring4[((jb >> 3) + 64 * c + lane) & (WS / 8 - 1)];
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    const uint4 r = buf[sg & 1][i];
+                    acc[i] = __builtin_elementwise_min(acc[i], __builtin_elementwise_max(dp_bits(s4.x), dp_bits(r.x)));
+                    acc[i] = __builtin_elementwise_min(acc[i], __builtin_elementwise_max(dp_bits(s4.y), dp_bits(r.y)));
+                    acc[i] = __builtin_elementwise_min(acc[i], __builtin_elementwise_max(dp_bits(s4.z), dp_bits(r.z)));
+                    acc[i] = __builtin_elementwise_min(acc[i], __builtin_elementwise_max(dp_bits(s4.w), dp_bits(r.w)));
+                }
             }
         }
+        if (ns & 1) {                                                    // the next block starts on buffer 0
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) buf[0][i] = buf[1][i];
+        }
+        uint32_t part[8];                        // the lane's minimum per target of the wave
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) part[i] = min((uint32_t)acc[i].x, (uint32_t)acc[i].y);
         // the eight minima over the wave in 7 exchanges instead of 48: two targets per word, and each exchange halves what a
         // lane still carries (lanes 32.. keep targets 4..7, then lanes with bit 4 set the odd pair), before the last four
         // steps run on one word
@@ -772,6 +788,7 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
             ring[(j - 1) & (WS - 1)] = (uint16_t)v;                      // takes the place of prefix length j - WS
             if (j <= n) { if (j < first_valid) mml[j] = n + j; else { mml[j] = v; if (v >= WS) bad = true; } }
         }
+        L = fresh[DPW_B - 1];                                            // stays until the next block's minima are written, after the barrier below
         __syncthreads();
     }
     if (bad) flag[4] = 1;
@@ -969,12 +986,12 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     bool literal = R == 0;
     bool tiled = false;
     // extensions of hundreds of columns: the matrix chain with 16-bit entries (k_dpw_*), smallest window first
-    const bool wide_ok = f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 2048 && n >= 2 * DPW_B;
+    const bool wide_ok = f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 4096 && n >= 2 * DPW_B;
     auto try_wide = [&](bool &done) -> int {
         const uint32_t nblocks = (uint32_t)((n + DPW_B - 1) / DPW_B);
         uint16_t *ext16 = ctx->dp_e.as<uint16_t>();
         hipLaunchKernelGGL(k_dpw_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext16);
-        for (uint32_t WS = max_ext + 2 <= 1024 ? 1024u : 2048u; WS <= 2048 && !done; WS *= 2) {
+        for (uint32_t WS = max_ext + 2 <= 1024 ? 1024u : max_ext + 2 <= 2048 ? 2048u : 4096u; WS <= 4096 && !done; WS *= 2) {
             const size_t mbytes = (size_t)nblocks * DPW_B * WS * 2;
             if (mbytes > (16ull << 30)) break;
             FBG_TRY(fbg_reserve(ctx, ctx->tmp, mbytes));
@@ -983,15 +1000,18 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             if (WS == 1024) {
                 hipLaunchKernelGGL((k_dpw_blockM<1024>), dim3(nblocks, 1024 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
                 hipLaunchKernelGGL((k_dpw_chain<1024>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
-            } else {
+            } else if (WS == 2048) {
                 hipLaunchKernelGGL((k_dpw_blockM<2048>), dim3(nblocks, 2048 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
                 hipLaunchKernelGGL((k_dpw_chain<2048>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
+            } else {
+                hipLaunchKernelGGL((k_dpw_blockM<4096>), dim3(nblocks, 4096 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
+                hipLaunchKernelGGL((k_dpw_chain<4096>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
             }
             hipLaunchKernelGGL(k_dpw_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext16, (uint32_t)n, WS, bt, sc, first_valid);
             FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
             done = hk[4] == 0;
-            if (done) ctx->dp_kind = WS == 1024 ? 3 : 4;
+            if (done) ctx->dp_kind = WS == 1024 ? 3 : WS == 2048 ? 4 : 5;
         }
         if (!done) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
         return FBG_OK;

@@ -88,8 +88,8 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
  * gap-free MSA, 2 rank-order scan of an MSA with gaps / ignore characters, 3 one partition of a partitioned index.
  * "dp_kind" (read-only): the sweep that produced the last fbg_minmax_dp result: -1 none yet, 0 statement by statement,
- * 1 matrix chain with byte entries (windows up to 256 columns), 2 wave-parallel sweep, 3 / 4 matrix chain with 16-bit
- * entries over windows of 1024 / 2048 columns.
+ * 1 matrix chain with byte entries (windows up to 256 columns), 2 wave-parallel sweep, 3 / 4 / 5 matrix chain with 16-bit
+ * entries over windows of 1024 / 2048 / 4096 columns.
  * Unknown key: FBG_ERR_INVALID.
  */
 int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value);

@@ -161,7 +161,7 @@ def test_dp_sweep_random_f(engine, max_ext, style):
         assert np.array_equal(gb, b)
 
 
-@pytest.mark.parametrize("max_ext", [254, 255, 300, 700, 1021, 1022, 1023, 1500, 2045, 2046, 2047, 3000])
+@pytest.mark.parametrize("max_ext", [254, 255, 300, 700, 1021, 1022, 1023, 1500, 2045, 2046, 2047, 3000, 4093, 4094, 5000])
 @pytest.mark.parametrize("style", ["uniform", "plateau", "spiky"])
 def test_dp_sweep_wide_windows(engine, max_ext, style):
     """Extensions of hundreds of columns: the 16-bit matrix chain (k_dpw_*), its two window sizes, and the hand-over to
@@ -178,10 +178,10 @@ def test_dp_sweep_wide_windows(engine, max_ext, style):
         assert np.array_equal(gbt, bt), (n, np.flatnonzero(gbt != bt)[:5])
         assert np.array_equal(gb, b)
         kinds.add(engine.get_option("dp_kind"))
-        if n >= 40_000 and style == "uniform" and 512 <= max_ext <= 2045:
+        if n >= 40_000 and style == "uniform" and 512 <= max_ext <= 4093:
             # extensions of every size up to max_ext: beyond the byte matrices, within the 16-bit ones (f[0] > 0 included)
-            assert engine.get_option("dp_kind") in (3, 4), (n, max_ext, engine.get_option("dp_kind"))
-    assert kinds <= {0, 1, 2, 3, 4}
+            assert engine.get_option("dp_kind") in (3, 4, 5), (n, max_ext, engine.get_option("dp_kind"))
+    assert kinds <= {0, 1, 2, 3, 4, 5}
 
 
 def test_dp_sweep_wide_windows_full_size(engine):
