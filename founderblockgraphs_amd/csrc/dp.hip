@@ -994,6 +994,11 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         for (uint32_t WS = max_ext + 2 <= 1024 ? 1024u : max_ext + 2 <= 2048 ? 2048u : 4096u; WS <= 4096 && !done; WS *= 2) {
             const size_t mbytes = (size_t)nblocks * DPW_B * WS * 2;
             if (mbytes > (16ull << 30)) break;
+            if (ctx->tmp.cap < mbytes) {         // the matrices are an option, not a need: without room for them the literal sweep runs
+                size_t free_b = 0, total_b = 0;
+                FBG_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+                if (free_b + ctx->tmp.cap < mbytes + (1ull << 30)) break;
+            }
             FBG_TRY(fbg_reserve(ctx, ctx->tmp, mbytes));
             uint16_t *Mw = ctx->tmp.as<uint16_t>();
             FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
