@@ -16,8 +16,9 @@ EXE = os.path.join(ROOT, "founderblockgraphs_amd", "fbg_host_selftest")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def selftest(fasta, gap_limit, elastic, paths, out, boundaries=()):
-    p = subprocess.run([EXE, fasta, str(gap_limit), str(int(elastic)), str(int(paths)), out, *map(str, boundaries)],
+def selftest(fasta, gap_limit, elastic, paths, out, boundaries=(), graph=None):
+    extra = [f"GRAPH={graph}"] if graph else []
+    p = subprocess.run([EXE, fasta, str(gap_limit), str(int(elastic)), str(int(paths)), out, *extra, *map(str, boundaries)],
                        capture_output=True)
     assert p.returncode == 0, p.stderr
     lines = p.stdout.decode().split("\n")
@@ -50,6 +51,38 @@ def test_xgfa_bytes_and_statistics_match_the_oracle(case, paths, tmp_path):
     assert open(tmp_path / "host.gfa", "rb").read() == expected
     st = O.segment_stats(msa, b)
     assert stats == [st["nodes"], st["total_label_length"], st["founders"], st["edges"]]
+    # the same bytes from node / edge arrays (what fbg_block_graph hands the program): output_efg's numbering restated
+    # with dicts stands in for the GPU here
+    nb = len(b)
+    node_of = np.full((nb, m), 0xFFFFFFFF, dtype=np.uint32)
+    rep_row = np.zeros((nb, m), dtype=np.uint32)
+    first = np.zeros(nb + 1, dtype=np.uint64)
+    ecount = np.zeros(nb, dtype=np.uint64)
+    edges = np.zeros((nb, m), dtype=np.uint64)
+    nodecount, prev = 0, 0
+    for j, end in enumerate(b):
+        cur, e = {}, set()
+        for i in range(m):
+            lab = bytes(c for c in msa[i, prev:min(int(end) + 1, n)] if c != ord("-"))
+            if not lab:
+                continue
+            if lab not in cur:
+                rep_row[j, len(cur)] = i
+                cur[lab] = nodecount
+                nodecount += 1
+            node_of[j, i] = cur[lab]
+            if j > 0 and node_of[j - 1, i] != 0xFFFFFFFF:
+                e.add((int(node_of[j - 1, i]) << 32) | cur[lab])
+        first[j + 1] = nodecount
+        ecount[j] = len(e)
+        edges[j, :len(e)] = sorted(e)
+        prev = int(end) + 1
+    with open(tmp_path / "graph.bin", "wb") as fh:
+        fh.write(np.array([nb, m], dtype=np.uint64).tobytes())
+        for arr in (node_of, rep_row, first, ecount, edges):
+            fh.write(arr.tobytes())
+    selftest(fasta, 1, True, paths, str(tmp_path / "host_graph.gfa"), b.tolist(), graph=str(tmp_path / "graph.bin"))
+    assert open(tmp_path / "host_graph.gfa", "rb").read() == expected
 
 
 @pytest.mark.parametrize("name", sorted(x for x in os.listdir(GOLD) if x.endswith(".fasta")))
