@@ -125,6 +125,9 @@ int fbg_elastic_f(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n,
  * boundary is n (fbg.cpp:2027-2028).  minmaxlength_out / backtrack_out (n+1 values each) may
  * be NULL.  FBG_ERR_NO_SEGMENTATION where the reference would index backtrack[] out of range
  * (only reachable with --disable-elastic-tricks).
+ * Device scratch: 64-128 bytes per column; with extensions f[x] - x beyond 254 columns up to 2 * 4096 bytes per column
+ * (at most 16 GB) for the 16-bit matrices -- taken only when the device has the room, the statement-by-statement sweep
+ * runs otherwise; both give the reference's arrays.
  */
 int fbg_minmax_dp(fbg_ctx *ctx, const uint64_t *f, uint64_t n, uint64_t *boundaries_out,
                   uint64_t *count_out, uint64_t *minmaxlength_out, uint64_t *backtrack_out);
