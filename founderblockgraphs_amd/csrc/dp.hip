@@ -610,18 +610,19 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
     if (lane == 0) { result[0] = err ? 0 : cnt; result[1] = err ? 1 : 0; }
 }
 
-// ---- wide windows: the matrix chain for block lengths of up to one or two thousand columns --------------------------
+// ---- wide windows: the matrix chain for block lengths of up to four thousand columns -------------------------------
 //
 // Rows that resemble each other, with gaps: behind a deletion a row's string occurs in the other rows some columns on, the
 // minimal extensions reach hundreds of columns and so do the blocks -- beyond the byte entries and LDS-sized square
 // matrices above, and the statement-by-statement sweep walks such an input at 0.5 us per column.  The same product with
-// 16-bit entries and RECTANGULAR matrices: a block of DPW_B = 128 steps acts on the WS (1024 or 2048) values before it
+// 16-bit entries and RECTANGULAR matrices: a block of DPW_B = 128 steps acts on the WS (1024, 2048, 4096) values before it
 // through M_b[t][k] -- the recurrence of a source k along the block's steps only involves the block's own 128 columns
 // as intermediate candidates, so a thread owns a source and keeps 128 values in LDS, 256 sources per workgroup.
 //   k_dpw_blockM   all M_b, independently: (n / 128) * (WS / 256) workgroups; two candidates per 32-bit LDS word go
 //                  through packed 16-bit max / min, their validity comes from a per-wave mask as in k_dp_blockW
 //   k_dpw_chain    one workgroup walks the blocks: minmaxlength of a block's 128 columns = M_b (x) the ring of the last WS
-//                  values (lanes along the sources: coalesced rows, one reduction per target)
+//                  values (lanes along the sources: coalesced rows, one reduction per target); sources too old to win
+//                  in a block are not read
 //   k_dpw_bt       backtrack[j] from minmaxlength[] as k_dp_bt, 16-bit extensions
 // A value that reaches WS raises flag[4] (the exactness argument of fbg_dp_minmax): next size, then the literal sweep.
 #define DPW_B 128u
