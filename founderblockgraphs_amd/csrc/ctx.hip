@@ -96,33 +96,46 @@ static int staged_copy(fbg_ctx *ctx, void *dst, const void *src, size_t bytes, b
     const size_t nchunks = (bytes + s.slot_bytes - 1) / s.slot_bytes;
     unsigned hw = std::thread::hardware_concurrency();
     int T = (int)std::min<size_t>(std::min<unsigned>(std::max(2u, hw / 2), 8u), nchunks);
-    if (T > s.nslots / 2) T = s.nslots / 2;                           // a slot's previous use has been queued by the time it comes round
-    std::atomic<size_t> next{0};
+    if (T > s.nslots / 2) T = s.nslots / 2;
+    // Thread t owns the pinned slots t and t + T and takes the chunks t, t + T, t + 2T, ...: a slot is only ever
+    // touched by one thread, so "the slot's previous use is over" is that thread's own event, recorded by itself.
     std::atomic<int> failed{0};
-    auto worker = [&]() {
+    auto worker = [&](int t) {
         if (hipSetDevice(ctx->device) != hipSuccess) { failed = 1; return; }
-        for (;;) {
-            const size_t c = next.fetch_add(1);
-            if (c >= nchunks || failed) return;
-            const int slot = (int)(c % (size_t)s.nslots);
-            const size_t off = c * s.slot_bytes, len = std::min(s.slot_bytes, bytes - off);
-            uint8_t *pin = static_cast<uint8_t *>(s.base) + (size_t)slot * s.slot_bytes;
-            if (to_device) {
-                if (c >= (size_t)s.nslots && hipEventSynchronize(s.ev[slot]) != hipSuccess) { failed = 1; return; }
-                memcpy(pin, static_cast<const uint8_t *>(src) + off, len);
-                if (hipMemcpyAsync(static_cast<uint8_t *>(dst) + off, pin, len, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
-                    hipEventRecord(s.ev[slot], s.stream) != hipSuccess) { failed = 1; return; }
-            } else {
-                // device -> slot, wait for it, slot -> caller's memory; the thread owns the slot for the whole chunk
-                if (hipMemcpyAsync(pin, static_cast<const uint8_t *>(src) + off, len, hipMemcpyDeviceToHost, s.stream) != hipSuccess ||
-                    hipEventRecord(s.ev[slot], s.stream) != hipSuccess || hipEventSynchronize(s.ev[slot]) != hipSuccess) { failed = 1; return; }
-                memcpy(static_cast<uint8_t *>(dst) + off, pin, len);
+        const int slots[2] = {t, t + T};
+        uint8_t *pins[2] = {static_cast<uint8_t *>(s.base) + (size_t)slots[0] * s.slot_bytes,
+                            static_cast<uint8_t *>(s.base) + (size_t)slots[1] * s.slot_bytes};
+        if (to_device) {
+            size_t k = 0;
+            for (size_t c = (size_t)t; c < nchunks && !failed; c += (size_t)T, k++) {
+                const int w = (int)(k & 1);
+                const size_t off = c * s.slot_bytes, len = std::min(s.slot_bytes, bytes - off);
+                if (k >= 2 && hipEventSynchronize(s.ev[slots[w]]) != hipSuccess) { failed = 1; return; }
+                memcpy(pins[w], static_cast<const uint8_t *>(src) + off, len);
+                if (hipMemcpyAsync(static_cast<uint8_t *>(dst) + off, pins[w], len, hipMemcpyHostToDevice, s.stream) != hipSuccess ||
+                    hipEventRecord(s.ev[slots[w]], s.stream) != hipSuccess) { failed = 1; return; }
+            }
+        } else {
+            // device -> slot queued one chunk ahead; wait for a chunk's own event, then slot -> caller's memory
+            auto issue = [&](size_t c, int w) {
+                const size_t off = c * s.slot_bytes, len = std::min(s.slot_bytes, bytes - off);
+                return hipMemcpyAsync(pins[w], static_cast<const uint8_t *>(src) + off, len, hipMemcpyDeviceToHost, s.stream) == hipSuccess &&
+                       hipEventRecord(s.ev[slots[w]], s.stream) == hipSuccess;
+            };
+            if ((size_t)t < nchunks && !issue((size_t)t, 0)) { failed = 1; return; }
+            size_t k = 0;
+            for (size_t c = (size_t)t; c < nchunks && !failed; c += (size_t)T, k++) {
+                const int w = (int)(k & 1);
+                if (c + (size_t)T < nchunks && !issue(c + (size_t)T, w ^ 1)) { failed = 1; return; }
+                if (hipEventSynchronize(s.ev[slots[w]]) != hipSuccess) { failed = 1; return; }
+                const size_t off = c * s.slot_bytes, len = std::min(s.slot_bytes, bytes - off);
+                memcpy(static_cast<uint8_t *>(dst) + off, pins[w], len);
             }
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(worker);
-    worker();
+    for (int t = 1; t < T; t++) th.emplace_back(worker, t);
+    worker(0);
     for (auto &t : th) t.join();
     FBG_HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     if (failed) return fbg_fail(ctx, FBG_ERR_HIP, "staged %s copy of %zu bytes failed: %s", to_device ? "host-to-device" : "device-to-host",

@@ -280,7 +280,8 @@ int pick_partitions(fbg_group *g, int *parts)
 // ---- plan: key-range partitioned index --------------------------------------------------------------------------
 // *done = 1: member 0 (every member when each holds one partition) is ready for fbg_scan_f / fbg_scan_v.
 // *done = 0: some partition declined; nothing usable.
-int plan_partitioned(fbg_group *g, int reversed, const uint8_t *ignore, uint64_t ignore_len, int disable_tricks, int *done)
+int plan_partitioned(fbg_group *g, int reversed, const uint8_t *ignore, uint64_t ignore_len, int disable_tricks, int *done,
+                     bool is_rescan = false)
 {
     *done = 0;
     for (Member &mb : g->mem) mb.ctx->opt.part_tricks_off = disable_tricks ? 1 : 0;     // (MSAs with gaps / ignore characters: one setting per scan)
@@ -332,6 +333,9 @@ int plan_partitioned(fbg_group *g, int reversed, const uint8_t *ignore, uint64_t
         }
         return fbg_sync(mb.ctx);
     }));
+    // a partition that declined in this pass (its rebuild, or its scan) leaves nothing to reduce: with k > 1 the
+    // member's accumulator may not even have been written.  All members live in this process and see good[].
+    if (std::find(good.begin(), good.end(), 0) != good.end()) return FBG_OK;
     auto red = [&](int i) -> void * { return k > 1 ? g->mem[i].acc.p : g->mem[i].gmax.p; };
     FBG_TRY(all_reduce_max(g, red, n + 1, 4));             // word n carries every partition's verdict
     std::vector<int> verdict(nm, 0);
@@ -344,12 +348,14 @@ int plan_partitioned(fbg_group *g, int reversed, const uint8_t *ignore, uint64_t
             FBG_TRY(all_reduce_max(g, red, n + 1, 4));
             FBG_TRY(parallel(g, [&](int i) -> int { return fbg_part_finish(g->mem[i].ctx, (const uint32_t *)red(i), &verdict[i]); }));
         } else {
+            // once: the re-scan runs without thresholds, a second verdict 2 would be a defect, not a reason to go on
+            if (is_rescan) return grp_fail(g, FBG_ERR_HIP, "partitioned index: the exact re-scan asked for another re-scan");
             std::vector<int64_t> old(nm), old_g(nm);
             for (int i = 0; i < nm; i++) {
                 old[i] = g->mem[i].ctx->opt.rank_no_threshold; g->mem[i].ctx->opt.rank_no_threshold = 1;
                 old_g[i] = g->mem[i].ctx->opt.gapped_rank; if (old_g[i] == 0 || old_g[i] == 4) g->mem[i].ctx->opt.gapped_rank = 3;
             }
-            const int rc = plan_partitioned(g, reversed, ignore, ignore_len, disable_tricks, done);
+            const int rc = plan_partitioned(g, reversed, ignore, ignore_len, disable_tricks, done, true);
             for (int i = 0; i < nm; i++) { g->mem[i].ctx->opt.rank_no_threshold = old[i]; g->mem[i].ctx->opt.gapped_rank = old_g[i]; }
             return rc;
         }

@@ -903,7 +903,8 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         if (!ss_ok) {
             PackArgs pa;
             pa.T = T; pa.N = N; pa.code = g.d_code; pa.b = b; pa.K = K; pa.pb = 0;
-            pa.keys = keysA; pa.vals = valsA;
+            // the sample sort reserves larger buffers before it can decline: the pointers taken above may be stale
+            pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
             pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
             pa.ebits = ctx->grs_ebits;
             launch_pack(ctx, g, false, pa);

@@ -40,11 +40,23 @@ class RankFailed(RuntimeError):
     """Some rank's engine call failed: raised on EVERY rank, after the collective that carried the flag."""
 
 
-def agree(error, world, group=None, device="cpu"):
+def collective_device(group=None):
+    """The device a collective's tensors must live on for this process group: the rank's current GPU under the
+    "nccl" (= RCCL) backend, the CPU under "gloo".  Never derived from a result tensor: a rank whose engine call
+    failed has none, and a CPU tensor handed to an RCCL group raises on that rank alone."""
+    backend = str(dist.get_backend(group)).lower() if dist.is_initialized() else "gloo"
+    if "nccl" in backend:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def agree(error, world, group=None, device=None):
     """All ranks learn whether any of them caught an exception during the phase that just ended (one all-reduce of a
     single word) and raise together -- a rank that raised alone would leave the others waiting in the next collective
     until the process group's timeout."""
     if world > 1:
+        if device is None:
+            device = collective_device(group)
         flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         failed = bool(flag.item())
@@ -56,9 +68,10 @@ def agree(error, world, group=None, device="cpu"):
         raise RankFailed("another rank failed in this phase; see its log")
 
 
-def segment_columns_sharded(n, scan_shard, sweep, rank=None, world=None, group=None):
+def segment_columns_sharded(n, scan_shard, sweep, rank=None, world=None, group=None, device=None):
     """scan_shard(x0, x1) -> 1-D integer tensor with f[x0..x1); sweep(f_full) -> boundaries (rank 0 only).
-    Returns (f_full, boundaries or None)."""
+    Returns (f_full, boundaries or None).  `device`: where the agreement word lives (default: what the process
+    group's backend needs, collective_device)."""
     world = dist.get_world_size(group) if world is None else world
     rank = dist.get_rank(group) if rank is None else rank
     x0, x1 = shard_range(n, rank, world)
@@ -69,7 +82,7 @@ def segment_columns_sharded(n, scan_shard, sweep, rank=None, world=None, group=N
             raise ValueError(f"scan_shard returned {f_local.numel()} values for columns [{x0}, {x1})")
     except Exception as e:          # noqa: BLE001 -- carried to every rank below
         error = e
-    agree(error, world, group, device=f_local.device if f_local is not None else "cpu")
+    agree(error, world, group, device=device)
     f_full = all_gather_columns(f_local, n, rank, world, group)
     boundaries = sweep(f_full) if rank == 0 else None
     return f_full, boundaries

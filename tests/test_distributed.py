@@ -208,3 +208,51 @@ def _worker_part(rank, world, port, fail_rank, out_dir):
 def test_two_rank_partitioned_index(fail_rank, tmp_path):
     """Key-range partitioned index: halo all-gather + all-reduce(max) of the column maxima, verdict included."""
     mp.spawn(_worker_part, args=(2, _free_port(), fail_rank, str(tmp_path)), nprocs=2, join=True)
+
+
+def _worker_raises(rank, world, port, where, out_dir):
+    """One rank's engine call raises: EVERY rank must raise (the failing one its own error, the others RankFailed),
+    promptly -- not after the process group's timeout."""
+    import sys
+    import time
+    from datetime import timedelta
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from founderblockgraphs_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
+    assert D.collective_device().type == "cpu"       # gloo; under nccl it is the rank's GPU, never taken from a result
+    t0 = time.time()
+    msa = random_msa(np.random.default_rng(3), 6, 90, similar=0.8)
+    n = msa.shape[1]
+    raised = None
+    try:
+        if where == "scan_shard":
+            def scan(x0, x1):
+                if rank == 1:
+                    raise RuntimeError("engine failure on rank 1")
+                return torch.zeros(x1 - x0, dtype=torch.int64)
+            D.segment_columns_sharded(n, scan, lambda f: f)
+        else:
+            eng = _OraclePartEngine(msa)
+            if rank == 1:
+                def boom(*a, **k):
+                    raise RuntimeError("engine failure on rank 1")
+                setattr(eng, where, boom)
+            D.partitioned_index(eng, n, device="cpu")
+    except D.RankFailed as e:
+        raised = "RankFailed"
+        assert rank == 0, e
+    except RuntimeError as e:
+        raised = "own"
+        assert rank == 1 and "engine failure" in str(e)
+    assert raised == ("own" if rank == 1 else "RankFailed")
+    assert time.time() - t0 < 60
+    dist.barrier()                                   # both ranks are still in step: the next collective works
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("where", ["scan_shard", "part_index_build", "part_scan"])
+def test_two_rank_failure_is_raised_on_every_rank(where, tmp_path):
+    mp.spawn(_worker_raises, args=(2, _free_port(), where, str(tmp_path)), nprocs=2, join=True)

@@ -387,6 +387,59 @@ def test_full_size_properties(engine):
     assert bool((starts <= d_v[b]).all())                # block [start..end] is repeat-free iff start <= v[end]
 
 
+def _scan_whole(eng, n, reversed=False):
+    import torch
+    d = torch.zeros(n, dtype=torch.int64, device="cuda")        # f is max-merged into (fbg.cpp:1681): start from zeros
+    torch.cuda.synchronize()
+    (eng.scan_v if reversed else eng.scan_f)(0, n, d.data_ptr())
+    eng.sync()
+    return d
+
+
+@pytest.mark.parametrize("config", ["C3", "C5", "C2"])
+def test_full_size_independent_paths_agree(config):
+    """BASELINE configs at FULL size, each through two structurally different scans that share no scan kernel:
+    C3 (1000 x 1,000,000 elastic): rank-order scan of the packed sort words (rank_scan.hip) against the record path
+    (prefix-doubling suffix sort, 16-byte records in text order, scan.hip); C5 (256 x 2,000,000, gaps + N): scan in
+    suffix order on column spans (gapped_rank.hip) against the record path; C2 (64 x 100,000 non-elastic): v[] likewise
+    on the reversed text.  The sampled thresholds, their verification and the regime switches all depend on the size:
+    this is the check that they change nothing (fbg.cpp:1579-1695, 552-611).  index_kind: 1 rank order, 2 suffix order
+    with gaps, 0 records."""
+    import torch
+    import founderblockgraphs_amd as F
+    with F.Engine(0) as eng:
+        if config == "C3":
+            m, n, kw, build, fast, alt = 1000, 1_000_000, {}, {}, 1, {"no_ranked": 1}
+        elif config == "C5":
+            m, n, kw, build, fast, alt = 256, 2_000_000, dict(gap_fraction=0.05, gap_run=16, n_fraction=0.001), dict(ignorechars="N"), 2, {"gapped_rank": -1}
+        else:
+            m, n, kw, build, fast, alt = 64, 100_000, {}, dict(reversed=True), 1, {"no_ranked": 1}
+        rev = bool(build.get("reversed"))
+        d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
+        eng.msa_synthetic(d.data_ptr(), m, n, **kw)
+        eng.msa_set_device(d.data_ptr(), m, n)
+        eng.index_build(**build)
+        assert eng.get_option("index_kind") == fast
+        a = _scan_whole(eng, n, rev)
+        with eng.options(**alt):
+            eng.index_build(**build)
+            assert eng.get_option("index_kind") == 0             # per-position records
+            b = _scan_whole(eng, n, rev)
+        assert torch.equal(a, b), (config, torch.nonzero(a != b)[:5].flatten().tolist())
+        if config == "C5":                                       # ... and with the elastic tricks off (fbg.cpp:1605-1608)
+            eng.index_build(**build)
+            a2 = torch.zeros(n, dtype=torch.int64, device="cuda")
+            b2 = torch.zeros(n, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            eng.scan_f(0, n, a2.data_ptr(), True)
+            eng.sync()
+            with eng.options(**alt):
+                eng.index_build(**build)
+                eng.scan_f(0, n, b2.data_ptr(), True)
+                eng.sync()
+            assert torch.equal(a2, b2) and not torch.equal(a, a2)
+
+
 @pytest.mark.parametrize("max_len", [1, 3, 20, 31, 40, 100, 126, 200, 400])
 def test_nonelastic_dp_random_v(engine, max_len):
     """s[]/prev[]/boundaries of fbg.cpp:616-664 for arbitrary v[] (valid, invalid and non-monotone entries):
@@ -886,6 +939,31 @@ def test_msd_sort_capacity_fallback_is_seamless(engine, alphabet):
     small = msa[:40, :4000]
     with fbg_options(engine, {"FBG_MSD_MIN": "1"}):
         assert np.array_equal(engine.elastic_f(small), O.compute_f(small))
+
+
+def test_sample_sort_decline_on_a_fresh_context():
+    """A FRESH context (every run of the host program is one): the sample sort of the (key, position) pairs reserves
+    its larger buffers and then declines in its first pass -- one key shared by 1.6e5 suffixes (rows that end in the
+    same long run of one symbol) overflows a bucket stretch.  The fall-back must pack into the buffers as they are
+    NOW (round 2 packed through pointers taken before the reserve: a write into freed memory that the session-wide
+    engine of the other tests, whose buffers no longer move, could not show)."""
+    import founderblockgraphs_amd as F
+    rng = np.random.default_rng(606)
+    m, n = 40, 8000
+    msa = random_msa(rng, m, n, gap_p=0.01, gap_run=3)
+    msa[:, n // 2:] = ord("A")
+    f_ref = O.compute_f(msa)
+    for force in (1, 0):
+        with F.Engine(0) as e:
+            e.set_option("msd_min", 1)
+            e.set_option("msd_min_force", force)
+            assert np.array_equal(e.elastic_f(msa), f_ref), force
+            T, SA, ISA, LCP = O.msa_index(msa)
+            e.set_option("gapped_rank", -1)                       # the record path's arrays: SA as the oracle has it
+            e.msa_load_host(msa)
+            e.index_build()
+            gSA = e.index_download()[1]
+            assert np.array_equal(gSA.astype(np.int64), SA.astype(np.int64)), force
 
 
 # ---- non-elastic mode with gaps: segment2elasticValid (fbg.cpp:738-866) ------------------------------------
