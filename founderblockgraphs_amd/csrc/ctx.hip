@@ -176,6 +176,7 @@ static const OptKey g_opt_keys[] = {
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
     {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force},
+    {"span_scan", &FbgOptions::span_scan},
 };
 
 // The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of
@@ -210,6 +211,19 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (strcmp(key, "grs_threshold") == 0) { *value = ctx->grs_t; return FBG_OK; }
     if (strcmp(key, "grs_redone") == 0) { *value = (int64_t)ctx->grs_redone; return FBG_OK; }
     if (strcmp(key, "dp_kind") == 0) { *value = ctx->dp_kind; return FBG_OK; }
+    if (strcmp(key, "span_scan_used") == 0) { *value = (ctx->index_valid && ctx->granked && ctx->spanned) ? 1 : 0; return FBG_OK; }
+    if (strcmp(key, "span_scan_work") == 0) { *value = (int64_t)ctx->sp_work; return FBG_OK; }
+    if (strcmp(key, "span_groups") == 0) { *value = (int64_t)ctx->sp_G; return FBG_OK; }
+    if (strcmp(key, "span_odd_groups") == 0) { *value = (int64_t)ctx->sp_n_odd[0] + (int64_t)ctx->sp_n_odd[1]; return FBG_OK; }
+    if (strcmp(key, "span_irregular") == 0) { *value = (int64_t)ctx->sp_n_irr; return FBG_OK; }
+    if (strncmp(key, "span_dbg", 8) == 0 && ctx->scalars.p) {
+        unsigned long long v = 0;
+        if (hipMemcpy(&v, ctx->scalars.as<unsigned long long>() + 208 + 16 + (key[8] - '0'), 8, hipMemcpyDeviceToHost) != hipSuccess) return FBG_ERR_HIP;
+        *value = (int64_t)v;
+        return FBG_OK;
+    }
+    if (strcmp(key, "span_chain") == 0) { *value = (int64_t)ctx->sp_chain_n; return FBG_OK; }
+    if (strcmp(key, "span_slow_groups") == 0) { *value = (int64_t)ctx->sp_slow_n; return FBG_OK; }
     if (strcmp(key, "index_kind") == 0) {      // read-only: which form the current index has
         *value = !ctx->index_valid ? -1 : ctx->part_active ? 3 : ctx->granked ? 2 : ctx->ranked ? 1 : 0;
         return FBG_OK;
@@ -262,7 +276,9 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
                       &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->msd_w, &ctx->msd_v, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d,
-                      &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h, &ctx->gwin, &ctx->gbits, &ctx->gwin_rows};
+                      &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h, &ctx->gwin, &ctx->gbits, &ctx->gwin_rows,
+                      &ctx->sp_cells, &ctx->sp_cwin, &ctx->sp_tiles, &ctx->sp_gstart, &ctx->sp_gcol, &ctx->sp_gflags, &ctx->sp_rstart, &ctx->sp_rid,
+                      &ctx->sp_gplo, &ctx->sp_gphi, &ctx->sp_gval, &ctx->sp_odd, &ctx->sp_irr, &ctx->sp_chain, &ctx->sp_slow, &ctx->sp_mins};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     for (auto &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
@@ -324,7 +340,7 @@ int fbg_release_scratch(fbg_ctx *ctx)
     DevBuf *bufs[] = {sorted_in_A ? &ctx->keysB : &ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list, &ctx->msd_w, &ctx->msd_v,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d, &ctx->ps_e, &ctx->ps_f,
-                      &ctx->ps_g, &ctx->ps_h};
+                      &ctx->ps_g, &ctx->ps_h, &ctx->sp_cells, &ctx->sp_tiles};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     return FBG_OK;
 }
@@ -374,6 +390,7 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->index_valid = false;
     ctx->granked = false;
+    ctx->spanned = false;
     ctx->gpart = false;
     ctx->reversed = reversed ? 1 : 0;
     FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
@@ -399,6 +416,7 @@ int fbg_part_index_build_ignore(fbg_ctx *ctx, int reversed, int part, int nparts
     ctx->index_valid = false;
     ctx->ranked = false;
     ctx->granked = false;
+    ctx->spanned = false;
     ctx->reversed = reversed ? 1 : 0;
     ctx->gpart = false;
     ctx->allow_wide = true;                        // the partitions together may hold a text of 2^32 symbols and more
@@ -655,6 +673,9 @@ int fbg_index_download(fbg_ctx *ctx, uint8_t *text, uint32_t *sa, uint32_t *isa,
     if (!ctx->index_valid) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: no index");
     if (ctx->part_active) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: the index is partitioned over several GPUs");
     if (ctx->N >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_index_download: 32-bit arrays");
+    if (ctx->granked && ctx->spanned && (sa || isa || lcp_prev || lcp_next))
+        return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_download: the group-level scan (span_scan.hip) leaves the suffixes with equal keys unordered; "
+                                              "set option span_scan = -1 for an index with a suffix array");
     size_t N = ctx->N;
     // test / debugging API: plain blocking copies
     FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -37,7 +37,8 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0;
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0,
+            span_scan = 0;
 };
 
 struct fbg_ctx {
@@ -100,6 +101,15 @@ struct fbg_ctx {
     bool grs_part_failed = false;  // its exact redo of a few columns ran out of room
     uint32_t grs_t = 1;            // the threshold of the last scan (1: none), the columns it redid exactly
     uint64_t grs_redone = 0;
+    // group-level scan on column spans for similar rows with gaps / ignore characters (span_scan.hip): `granked` and `spanned`
+    bool spanned = false;
+    DevBuf sp_cells;               // u32[N]: cell | flags of every text position, the payload of the sort
+    DevBuf sp_cwin;                // 20 bytes per 128 cells of a row: text position of a cell
+    DevBuf sp_tiles, sp_gstart, sp_gcol, sp_gflags, sp_rstart, sp_rid, sp_gplo, sp_gphi, sp_gval, sp_odd, sp_irr, sp_chain, sp_slow, sp_mins;
+    uint32_t sp_chain_n = 0, sp_slow_n = 0;
+    uint64_t sp_G = 0, sp_R = 0, sp_n_irr = 0, sp_work = 0;
+    uint32_t sp_n_odd[2] = {0, 0}, sp_odd_cap = 0;
+    const uint32_t *sort_payload = nullptr;   // while set: the pack kernels of the (key, value) sorts write payload[p] instead of p | flag
     int dp_kind = -1;            // which sweep produced the last fbg_dp_minmax result (fbg_get_option "dp_kind")
     bool cells_built = false;      // prow / igrow hold the current MSA (built on demand: only the record path reads them)
     uint8_t ignore_tab[256] = {0};
@@ -180,6 +190,10 @@ int fbg_grs_strip(fbg_ctx *ctx, uint32_t *vals);
 int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);             // gapped_rank.hip
 int fbg_grs_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_out, int *ok);
 int fbg_grs_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
+bool fbg_span_eligible(fbg_ctx *ctx, const KeyGeom &g);                                                 // span_scan.hip
+int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches);
+int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);
+int fbg_span_rescan(fbg_ctx *ctx, int disable_tricks, int *ok);
 int fbg_build_cell_tables(fbg_ctx *ctx);                                                                // text_build.hip
 int fbg_key_setup(fbg_ctx *ctx, bool compact, KeyGeom *g, int *launches);                                // suffix_sort.hip
 int fbg_rank_part_classify(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t count, const KeyGeom &g, int pre_ok,

@@ -1366,7 +1366,8 @@ int fbg_grs_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, u
             return fbg_fail(ctx, FBG_ERR_INVALID, "the partitioned index of this MSA (gaps / ignore characters) was scanned %s the elastic tricks; "
                             "set option part_tricks_off before fbg_part_index_build for the other setting", ctx->grs_tricks_off ? "without" : "with");
         int launches = 0;
-        FBG_TRY(grs_scan(ctx, disable_tricks ? 1 : 0, ok, &launches));
+        if (ctx->spanned) FBG_TRY(fbg_span_rescan(ctx, disable_tricks ? 1 : 0, ok));    // (similar rows: the group-level scan, span_scan.hip)
+        else FBG_TRY(grs_scan(ctx, disable_tricks ? 1 : 0, ok, &launches));
         if (!*ok) return FBG_OK;
     }
     hipLaunchKernelGGL(k_grs_finish, dim3(fbg_blocks(x1 - x0, 256)), dim3(256), 0, ctx->stream, ctx->gmax.as<uint32_t>(), x0, x1, d_out);

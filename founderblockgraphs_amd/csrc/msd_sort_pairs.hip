@@ -52,6 +52,8 @@ struct PpArgs {
     uint64_t top;                              // MODE 1: 2^key_bits, the end of the last sub-bucket's key range
     int sigma;                                 // MODE 1: number of symbol codes in use (codes are 0 .. sigma - 1)
     const uint64_t *ebits;                     // pairs: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
+    const uint32_t *payload;                   // pairs, MODE 1: the value of position p is payload[p] (span_scan.hip: cell | flags), not p
+    int any_order;                             // MODE 1: slots with equal keys may come out in any order (the consumer works on groups of equal keys)
     // MODE 1 finish: bins from the symbols behind the prefix a sub-bucket's keys share, every symbol code replaced by its
     // rank among the FREQUENT symbols (rb bits; 0: bins from sampled keys instead).  rtab: ew bits per code = the rank;
     // mtab: 2 bits per code = 0 a frequent symbol, 1 / 2 a rare one below / above the frequent symbol whose rank it shares
@@ -205,7 +207,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
                 const uint64_t p = base + (uint64_t)threadIdx.x * MSD_ITEMS + i;
                 if (at < PP_STAGE) {
                     sw[at] = a.packed ? (key[i] << a.pb) | p : a.wide ? (key[i] << a.pb) | (p >> 32) : key[i];
-                    sv[at] = a.packed ? 0u : (uint32_t)p | (((eb >> i) & ((1ull << a.K) - 1)) ? 0x80000000u : 0u);
+                    sv[at] = a.packed ? 0u : a.payload ? a.payload[p] : (uint32_t)p | (((eb >> i) & ((1ull << a.K) - 1)) ? 0x80000000u : 0u);
                 } else *a.flag = 1;
                 at++;
             }
@@ -322,7 +324,7 @@ __global__ void k_pp_widen(const uint32_t *__restrict__ count2, unsigned long lo
 
 // slots (first n_a from a, the rest from b) -> out, sorted by (word, low position): bins on the last 9 bits of t
 // inside LDS, then every slot counts the smaller slots of its bin
-template <int CAP, int MODE>
+template <int CAP, int MODE, bool ANY>
 __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, uint32_t *sv, uint32_t *cnt, uint32_t *loff, uint32_t *wsum,
                                                const uint64_t *wa, const uint32_t *va, uint32_t n_a, const uint64_t *wb,
                                                const uint32_t *vb, uint32_t have, uint64_t *wout, uint32_t *vout, uint64_t *smp, uint64_t *srt,
@@ -432,7 +434,51 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     uint32_t rb0[ITEMS], rc[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) { rb0[r] = loff[bn[r]]; rc[r] = cnt[bn[r]]; }
-    if (MODE == 1 && CAP != PP_FN_SMALL) {                                // (not in the variant most sub-buckets go through: it costs that one 2 ms)
+    // ANY (similar rows: a bin may be one key held by hundreds of suffixes -- the rows' copies of one position -- plus a few
+    // neighbours, and nobody asks for an order among equal keys): four keys picked from the bin are pivots; a slot whose key
+    // is a pivot takes the place "slots below the pivot + its turn among the pivot's copies", both from counters, and only
+    // the few others count the smaller slots of the bin.  (Every slot counting them took 52 ms for 2 * 10^8 suffixes; a
+    // split on key bits does not part equal keys.)
+    if (MODE == 1 && ANY) {
+        __shared__ uint32_t nbig2, biglist2[CAP / PP_CROWD + 1];
+        __shared__ uint64_t pv[4];
+        __shared__ uint32_t pless[4], peq[4];
+        if (threadIdx.x == 0) nbig2 = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < PP_FBINS; i += PP_THREADS)
+            if (cnt[i] > PP_CROWD) biglist2[atomicAdd(&nbig2, 1u)] = i;
+        __syncthreads();
+        const uint32_t nb2 = nbig2;
+        for (uint32_t e = 0; e < nb2; e++) {                            // uniform over the workgroup
+            const uint32_t bbin = biglist2[e], b0 = loff[bbin], c = cnt[bbin];
+            if (threadIdx.x < 4) { pv[threadIdx.x] = sw[b0 + (threadIdx.x * c) / 4]; pless[threadIdx.x] = 0; peq[threadIdx.x] = 0; }
+            __syncthreads();
+            const uint64_t p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3];
+            const bool act[4] = {true, p1 != p0, p2 != p0 && p2 != p1, p3 != p0 && p3 != p1 && p3 != p2};
+            const uint64_t pk[4] = {p0, p1, p2, p3};
+            uint32_t turn[ITEMS];
+            int which[ITEMS];
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const uint32_t j = threadIdx.x + r * PP_THREADS;
+                which[r] = -1; turn[r] = 0;
+                if (j < have && bn[r] == bbin) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (!act[k]) continue;
+                        if (w[r] < pk[k]) atomicAdd(&pless[k], 1u);
+                        else if (w[r] == pk[k]) { which[r] = k; turn[r] = atomicAdd(&peq[k], 1u); }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++)
+                if (which[r] >= 0) { rb0[r] = b0 + pless[which[r]] + turn[r]; rc[r] = 0; }
+            __syncthreads();
+        }
+    }
+    if (MODE == 1 && CAP != PP_FN_SMALL && !ANY) {                        // (not in the variant most sub-buckets go through: it costs that one 2 ms)
         __shared__ uint32_t nbig, biglist[CAP / PP_CROWD + 1], sub[256];
         __shared__ unsigned long long kmin, kmax;
         if (threadIdx.x == 0) nbig = 0;
@@ -523,7 +569,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
 // sub-buckets that hold no more than that (a text of 5 * 10^8 symbols fills a stretch to 40 %: with the smaller arrays
 // four workgroups share a CU instead of two and the per-thread loops are half as long); a launch of each
 // list = nullptr: one workgroup per sub-bucket, those beyond CAP (up to the stretch) noted in `later`; else the listed ones
-template <int MODE, int CAP> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a, const uint32_t *__restrict__ list, uint32_t *__restrict__ later,
+template <int MODE, int CAP, bool ANY> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish(PpArgs a, const uint32_t *__restrict__ list, uint32_t *__restrict__ later,
                                                                                        unsigned long long *__restrict__ later_count)
 {
     __shared__ uint64_t sw[CAP];
@@ -542,10 +588,10 @@ template <int MODE, int CAP> __global__ __launch_bounds__(PP_THREADS) void k_pp_
     __shared__ uint64_t smp[MODE == 1 ? PP_SMP + 1 : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
     __shared__ uint32_t place[MODE == 1 ? PP_SMP + 1 : 1];
     if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
-    pp_finish_body<CAP, MODE>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place, sb);
+    pp_finish_body<CAP, MODE, ANY>(a, sw, sv, cnt, loff, wsum, wa, va, have, wa, va, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place, sb);
 }
 
-template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
+template <int MODE, bool ANY> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_big(PpArgs a, const uint32_t *__restrict__ sb_sorted,
                                                               const uint32_t *__restrict__ idx_sorted, uint32_t entries,
                                                               uint64_t *__restrict__ gw, uint32_t *__restrict__ gv)
 {
@@ -563,7 +609,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_finish_bi
     __shared__ uint64_t smp[MODE == 1 ? PP_SMP + 1 : 1], srt[MODE == 1 ? PP_SMP + 1 : 1];
     __shared__ uint32_t place[MODE == 1 ? PP_SMP + 1 : 1];
     if (MODE == 1 && threadIdx.x == 0) srt[PP_SMP] = ~0ull;
-    pp_finish_body<PP_BIG_CAP, MODE>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
+    pp_finish_body<PP_BIG_CAP, MODE, ANY>(a, sw, sv, cnt, loff, wsum, a.w2 + (uint64_t)sb * PP_FN_CAP, a.v2 + (uint64_t)sb * PP_FN_CAP, PP_FN_CAP,
                                      gw + e, gv + e, have, a.wout + a.off[sb], a.vout + a.off[sb], smp, srt, place, sb);
 }
 
@@ -603,6 +649,9 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
     a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = (g.wide || g.packed) ? g.pb : 0; a.nparts = nparts;
     a.wide = g.wide ? 1 : 0; a.packed = g.packed ? 1 : 0;
     a.ebits = (MODE == 1 && !g.wide && !g.packed && g.K <= 32) ? ctx->grs_ebits : nullptr;
+    a.payload = (MODE == 1 && !g.wide && !g.packed) ? ctx->sort_payload : nullptr;
+    a.any_order = a.payload ? 1 : 0;
+    const bool any = MODE == 1 && a.any_order;
     a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
     a.count1 = ctx->dp_a.as<unsigned long long>();
     uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + PP_NB * 8);
@@ -648,18 +697,25 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
         FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)nsub * 4));
         unsigned long long *later_count = flag + 3;
         FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
-        hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
-                           later_count);
+        if (any) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+                                    later_count);
+        else hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, false>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+                                later_count);
         unsigned long long nlater = 0;
         FBG_HIP_TRY(ctx, hipMemcpyAsync(&nlater, later_count, 8, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (nlater > 0)
-            hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP>), dim3((unsigned)nlater), dim3(PP_THREADS), 0, st, a, (const uint32_t *)ctx->ps_a.as<uint32_t>(),
-                               (uint32_t *)nullptr, (unsigned long long *)nullptr);
+        if (nlater > 0) {
+            if (any) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP, MODE == 1>), dim3((unsigned)nlater), dim3(PP_THREADS), 0, st, a, (const uint32_t *)ctx->ps_a.as<uint32_t>(),
+                                        (uint32_t *)nullptr, (unsigned long long *)nullptr);
+            else hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP, false>), dim3((unsigned)nlater), dim3(PP_THREADS), 0, st, a, (const uint32_t *)ctx->ps_a.as<uint32_t>(),
+                                    (uint32_t *)nullptr, (unsigned long long *)nullptr);
+        }
         *launches += 1;
     } else {
-        hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                           (unsigned long long *)nullptr);
+        if (any) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (unsigned long long *)nullptr);
+        else hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_CAP, false>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                (unsigned long long *)nullptr);
     }
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -678,7 +734,8 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
         uint64_t *gw = a.arena_w + PP_ARENA;
         uint32_t *gv = a_idx;                                  // the iota is consumed by the sort
         hipLaunchKernelGGL(k_pp_gather, dim3(fbg_blocks(entries, 256)), dim3(256), 0, st, idx_sorted, a.arena_w, a.arena_v, entries, gw, gv);
-        hipLaunchKernelGGL((k_pp_finish_big<MODE>), dim3(entries), dim3(PP_THREADS), 0, st, a, sb_sorted, idx_sorted, entries, gw, gv);
+        if (any) hipLaunchKernelGGL((k_pp_finish_big<MODE, MODE == 1>), dim3(entries), dim3(PP_THREADS), 0, st, a, sb_sorted, idx_sorted, entries, gw, gv);
+        else hipLaunchKernelGGL((k_pp_finish_big<MODE, false>), dim3(entries), dim3(PP_THREADS), 0, st, a, sb_sorted, idx_sorted, entries, gw, gv);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 4;
@@ -785,7 +842,7 @@ int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 1;
         ctx->pairs_similar = (double)twins * (double)N / ((double)S * (double)S) > 0.5 && !ctx->opt.msd_min_force;
-        if (ctx->pairs_similar) return FBG_OK;
+        if (ctx->pairs_similar && !ctx->sort_payload) return FBG_OK;    // (with a payload the consumer is the group-level scan: equal keys in any order)
     }
     hipLaunchKernelGGL(k_ss_grid, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, srt, S, grid);
     *launches += 3;

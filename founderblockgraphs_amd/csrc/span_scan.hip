@@ -1,0 +1,1328 @@
+// span_scan.hip -- the extension scan in suffix-array order for SIMILAR rows WITH gaps and / or ignore characters
+// (what a pangenome MSA looks like): the group-level scan of pure_scan.hip on the column spans of gapped_rank.hip.
+//
+// compute_f (fbg.cpp:1579-1695) keeps one text pointer per row; while a row shows gaps the pointer waits on the row's
+// next symbol (fbg.cpp:1687-1691), so text position p is its row's pointer for a SPAN of columns [lo(p), hi(p)]: from
+// the column after the row's previous symbol to its own.  The leaves coloured at column x are the positions whose span
+// holds x (a row's first symbol only with the elastic tricks off: fullrow[], fbg.cpp:1605-1608), and the walk of
+// fbg.cpp:1633-1678 gives a coloured leaf r the extension
+//
+//        g_x(r) = 1 + max over the suffixes u NOT coloured at x of lcp(r, u)                      
+//
+// which needs no order among the coloured ones.  After ONE sort of the suffixes by a K-symbol key (every symbol,
+// '#' and the sentinel included, has a code of its own: equal keys <=> equal first K symbols) the suffixes with equal
+// keys form a GROUP, and for a group G and a column x:
+//   * every member coloured at x ("G is pure at x": x lies in P(G), the intersection of the members' spans): all
+//     members extend by 1 + the symbols the key shares with the nearest group, on either side, that has a member not
+//     coloured at x (groups pure at x in between are coloured along, fbg.cpp:1633-1641) -- keys only, no text;
+//   * else the longest match of a coloured member is with a group mate that is not coloured at x (they share K
+//     symbols, nobody outside does): text comparison inside the group.
+// Rows that resemble each other put the m suffixes of one aligned position into one group whose members all have the
+// one-column span [h, h] -- except the rows with a gap run right before h, whose span is wider ("odd" members: 0.25 %
+// of the cells when 2 % of them are gap cells in runs of 8).  So almost every group is settled by one thread from two
+// neighbouring keys; the groups with an odd member get a workgroup: the odd members are compared with their group
+// mates (each needs its longest match with a mate for the gap columns in front of it, where it is coloured alone).
+// Prefix doubling (the record path this replaces: six rounds of global sorts to order the members of every group among
+// themselves, 105 ms for 1000 x 200 000) answers a question the scan never asks.
+//
+// What a slot must say about itself without a table lookup is its column: the sort's 32-bit payload is therefore not the
+// text position but the CELL, row * (n + 1) + column (column n: the row's '#'; the sentinel: row m), plus two flags
+// computed in text order: W -- the span is wider than one column or the position is a row's first symbol -- and I --
+// the K symbols from here on are not K consecutive columns of the row (a gap run, the row's end, among them), i.e.
+// fi = column + g - 1 (fbg.cpp:1666) does not hold and the member looks its extent up.  The text position of a cell,
+// needed only for text comparisons and lookups, comes from a table of 20 bytes per 128 cells (symbols before the window,
+// bitmap of its symbols).  (m + 1) * (n + 1) < 2^30; '-' among the ignore characters is not for this scan.
+#include "fbg_internal.h"
+#include "text_cmp.h"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+
+#define SP_THREADS 256
+#define SP_ITEMS 8
+#define SP_TILE (SP_THREADS * SP_ITEMS)
+#define SP_CELL 0x3fffffffu
+#define SP_I 0x40000000u
+#define SP_W 0x80000000u
+#define SPG_ODD 1u                   // not every member has the one-column span of the group's first member
+#define SPG_IRR 2u                   // some member is irregular (flag I)
+#define SPG_SEP 4u                   // '#' / sentinel slots: never row pointers that matter, share nothing with a symbol's key
+#define SPG_REG 8u                   // some member is regular
+#define SP_MAX_ODD 1024              // odd members of a group (LDS): a deletion shared by a third of 1000 rows makes hundreds
+#define SP_MAX_PURE 4096             // columns of a pure interval worked off one after the other
+#define SP_NONE 0xffffffffu
+
+struct CWin { uint32_t rank0, b0, b1, b2, b3; };      // 128 cells of a row: symbols before them in the row, bitmap of the symbols
+
+struct SpArgs {
+    const uint64_t *keys;
+    const uint32_t *vals;
+    uint64_t N;
+    uint32_t n, m, row_len, magic;   // row_len = n + 1; magic = floor(2^32 / row_len)
+    int b, K, key_bits, disable_tricks;
+    const uint8_t *T;
+    const uint32_t *colT, *pos, *tot;   // colT = nullptr: rows without gaps (cell == text position)
+    const CWin *cwin;
+    uint32_t wpr;                    // windows per row
+    const uint8_t *is_ignore;        // by byte; nullptr: no ignore characters
+    uint32_t ign_lo, ign_hi;         // by symbol code
+    unsigned long long *tile_cnt;    // per tile of slots: group heads (low word), irregular slots (high word) -> exclusive offsets
+    uint32_t *gstart, *gcol, *gflags;
+    uint64_t G;
+    uint32_t *rtile, *rstart, *rid;  // runs of groups that are pure in one column
+    uint64_t R;
+    uint32_t *gplo, *gphi;           // odd groups: the columns at which every member is coloured (plo > phi: none)
+    uint32_t *gval;                  // the other groups: g at their column
+    uint32_t *odd, *odd_big;         // lists of the odd groups (up to 1024 members / more)
+    uint2 *irr;                      // (slot, group) of the irregular slots
+    uint64_t n_irr;
+    uint32_t *fmax;                  // per column: largest fi
+    unsigned long long *counters;    // [0] odd groups (small), [1] odd groups (big), [2] comparisons ahead, [3] decline flag, [4] min last column,
+                                     // [5] odd members in all, [6] entries of the chain list, [7] groups of the slow list
+    const uint8_t *code;             // symbol codes of the sort's keys, by byte
+    struct SpChain *chain;           // odd members whose longest match is found along the chain of groups (k_sp_chain)
+    uint32_t chain_cap;
+    uint32_t *slow;                  // odd groups that need every pair compared (k_sp_odd_slow)
+    uint32_t slow_cap;
+    uint32_t *mins32;                // per 32 columns: the fewest symbols any row has there (nullptr: rows without gaps)
+    int dbg;
+};
+
+// An odd member q on the chain list.  OWN: at the columns [xlo, xhi] \ [plo, phi] of its span the same mates are coloured
+// with it throughout -- the nex members at the text positions ex[] (rows with the same gap run in front of them), nobody
+// else.  EVENT: q is NOT coloured at the majority column evcol of its group, whose members therefore extend by their
+// longest match with q (and the likes of it): worked out only if that could raise the column's maximum at all.
+#define SP_CHAIN_EX 7
+#define SP_CH_OWN 0x100u
+#define SP_CH_EVENT 0x200u
+struct SpChain { uint32_t p, row, xlo, xhi, plo, phi, group, nex, evcol, ex[SP_CHAIN_EX]; };
+
+__device__ __forceinline__ uint32_t sp_key_lcp(uint64_t a, uint64_t c, int b, int key_bits)
+{
+    const uint64_t d = a ^ c;
+    const uint32_t bits = (uint32_t)(__clzll((long long)d) - (64 - key_bits));
+    return (bits * ((65536u + (uint32_t)b - 1) / (uint32_t)b)) >> 16;
+}
+
+__device__ __forceinline__ void sp_decode(const SpArgs &a, uint32_t v, uint32_t &row, uint32_t &col)
+{
+    const uint32_t c = v & SP_CELL;
+    row = __umulhi(c, a.magic);
+    col = c - row * a.row_len;
+    if (col >= a.row_len) { col -= a.row_len; row++; }
+}
+
+// text position of cell (row, col); col = n: the row's '#', row = m: the sentinel
+__device__ __forceinline__ uint32_t sp_pos(const SpArgs &a, uint32_t row, uint32_t col)
+{
+    if (row >= a.m) return (uint32_t)(a.N - 1);
+    if (!a.cwin) return row * a.row_len + col;
+    if (col >= a.n) return a.pos[row] + a.tot[row];
+    const CWin w = a.cwin[(size_t)row * a.wpr + (col >> 7)];
+    const uint32_t o = col & 127u;
+    const uint32_t bits[4] = {w.b0, w.b1, w.b2, w.b3};
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t lo = 32u * q;
+        if (o >= lo + 32) cnt += (uint32_t)__popc(bits[q]);
+        else if (o > lo) cnt += (uint32_t)__popc(bits[q] & ((1u << (o - lo)) - 1));
+    }
+    return a.pos[row] + w.rank0 + cnt;
+}
+
+__device__ __forceinline__ uint32_t sp_col_of(const SpArgs &a, uint32_t q, uint32_t row)
+{
+    return a.colT ? a.colT[q] : q - row * a.row_len;
+}
+
+// the columns [lo, hi] at which the symbol of cell (row, col), flagged W, is a coloured pointer (lo > hi: never)
+__device__ __forceinline__ void sp_wide_span(const SpArgs &a, uint32_t row, uint32_t col, uint32_t p, uint32_t &lo, uint32_t &hi)
+{
+    hi = col;
+    if (p == a.pos[row]) {                                   // the row's first symbol: only with the tricks off (fbg.cpp:1605-1608)
+        if (a.disable_tricks) lo = 0; else { lo = 1; hi = 0; }
+    } else lo = a.colT ? a.colT[p - 1] + 1 : col;
+}
+
+// first of the `reach` symbols of the key that is an ignore character; SP_NONE if none
+__device__ __forceinline__ uint32_t sp_key_first_ignore(const SpArgs &a, uint64_t key, uint32_t reach)
+{
+    if (!a.is_ignore) return SP_NONE;
+    for (uint32_t k = 0; k < reach && k < (uint32_t)a.K; k++) {
+        const uint32_t c = (uint32_t)(key >> (a.b * (a.K - 1 - (int)k))) & ((1u << a.b) - 1);
+        if ((c < 32 ? a.ign_lo >> c : a.ign_hi >> (c - 32)) & 1u) return k;
+    }
+    return SP_NONE;
+}
+
+// fi of fbg.cpp:1657-1670 for the pointer p of row `row` extended by g; ign: offset from p of the row's first ignore
+// character (at least as far as g symbols were looked at; SP_NONE: none)
+__device__ __forceinline__ uint32_t sp_extent(const SpArgs &a, uint32_t p, uint32_t row, uint32_t g, uint32_t ign)
+{
+    const uint32_t p0 = a.pos[row], tt = a.tot[row];
+    const unsigned long long gg = (unsigned long long)(p - p0) + g;                      // 1657
+    uint32_t fi, reach = g;
+    if (gg > tt) {                                                                       // 1659-1664
+        fi = a.disable_tricks ? a.n : (tt ? sp_col_of(a, p0 + tt - 1, row) : 0u);
+        reach = p0 + tt - p;
+    } else fi = sp_col_of(a, p + g - 1, row);                                            // 1666
+    if (ign < reach) fi = min(fi, sp_col_of(a, p + ign, row));                           // 1669-1670
+    return fi;
+}
+
+// symbols of the row from p on that may be looked at for an ignore character when the extension is g
+__device__ __forceinline__ uint32_t sp_reach(const SpArgs &a, uint32_t p, uint32_t row, uint32_t g)
+{
+    const uint32_t left = a.pos[row] + a.tot[row] - p;
+    return g < left ? g : left;
+}
+
+__device__ __forceinline__ uint32_t sp_first_ignore(const SpArgs &a, uint32_t p, uint32_t reach)
+{
+    if (!a.is_ignore) return SP_NONE;
+    for (uint32_t k = 0; k < reach; k++)
+        if (a.is_ignore[a.T[(uint64_t)p + k]]) return k;
+    return SP_NONE;
+}
+
+__device__ __forceinline__ void sp_update(const SpArgs &a, uint32_t x, uint32_t fi)
+{
+    if (fi > x && a.fmax[x] < fi) atomicMax(&a.fmax[x], fi);
+}
+
+// ---- text order: the window table of the cells and the payload of the sort --------------------------------------
+__global__ __launch_bounds__(256) void k_sp_cwin(const uint8_t *__restrict__ msa, uint32_t n, uint32_t wpr, CWin *__restrict__ cwin, uint32_t *__restrict__ mins32)
+{
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, row = blockIdx.y;
+    if (w >= wpr) return;
+    const uint8_t *r = msa + (size_t)row * n;
+    const uint32_t c0 = w * 128 + lane, c1 = c0 + 64;
+    const unsigned long long m0 = __ballot(c0 < n && r[c0] != '-'), m1 = __ballot(c1 < n && r[c1] != '-');
+    if (lane == 0) {
+        CWin e;
+        e.rank0 = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);      // the count for now; k_sp_cwin_scan turns it into the prefix
+        e.b0 = (uint32_t)m0; e.b1 = (uint32_t)(m0 >> 32); e.b2 = (uint32_t)m1; e.b3 = (uint32_t)(m1 >> 32);
+        cwin[(size_t)row * wpr + w] = e;
+        const uint32_t words[4] = {e.b0, e.b1, e.b2, e.b3};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t c = (uint32_t)__popc(words[q]);
+            if (w * 128 + 32 * q < n && mins32[w * 4 + q] > c) atomicMin(&mins32[w * 4 + q], c);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sp_cwin_scan(uint32_t wpr, CWin *__restrict__ cwin)
+{
+    CWin *r = cwin + (size_t)blockIdx.x * wpr;
+    const uint32_t lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t w0 = 0; w0 < wpr; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        const uint32_t c = w < wpr ? r[w].rank0 : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+        if (w < wpr) r[w].rank0 = carry + inc - c;
+        carry += __shfl(inc, 63, 64);
+    }
+}
+
+// cell | flags of every text position; a wave takes 64 consecutive positions: the row of the first by binary search,
+// the others count the separators in between
+__global__ __launch_bounds__(256) void k_sp_cells(const uint32_t *__restrict__ colT, const uint32_t *__restrict__ pos, uint64_t N, uint32_t n, uint32_t m,
+                                                  int K, const unsigned long long *__restrict__ ebits, uint32_t *__restrict__ cellT)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t p0 = p - lane;
+    if (p0 >= N) return;
+    const bool in = p < N;
+    uint32_t row, col;
+    if (colT) {
+        col = in ? colT[p] : n;
+        if (col > n) col = n;
+        uint32_t lo = 0, hi = m;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pos[mid] <= p0) lo = mid; else hi = mid; }
+        const unsigned long long seps = __ballot(col >= n);
+        row = lo + (uint32_t)__popcll(seps & ((1ull << lane) - 1));
+    } else {
+        row = (uint32_t)(p / (n + 1));
+        col = (uint32_t)(p - (uint64_t)row * (n + 1));
+        if (p == N - 1) { row = m; col = n; }
+    }
+    if (!in) return;
+    // irregular positions: bit p -> W, bits (p, p + K) -> I
+    const unsigned long long *e = ebits + (p >> 6);
+    const unsigned sh = (unsigned)(p & 63);
+    unsigned long long bits = e[0] >> sh;
+    if (sh) bits |= e[1] << (64 - sh);
+    uint32_t w = (bits & 1ull) ? SP_W : 0u;
+    uint32_t i = ((bits >> 1) & ((1ull << (K - 1)) - 1)) ? SP_I : 0u;
+    if (col >= n) w = i = 0;                                   // '#' / sentinel: no flags (the column says what they are)
+    cellT[p] = (row * (n + 1) + col) | w | i;
+}
+
+// the values back to text positions (the record path reads them as the suffix array)
+__global__ void k_sp_to_positions(SpArgs a, uint32_t *__restrict__ vals)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.N) return;
+    uint32_t row, col;
+    sp_decode(a, vals[k], row, col);
+    vals[k] = sp_pos(a, row, col);
+}
+
+__global__ void k_sp_check(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ cells, uint64_t N,
+                           unsigned long long *__restrict__ out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    atomicAdd(&out[0], (unsigned long long)vals[k]);
+    atomicAdd(&out[1], (unsigned long long)cells[k]);
+    atomicXor(&out[2], (unsigned long long)vals[k] * 0x9E3779B97F4A7C15ull);
+    atomicXor(&out[3], (unsigned long long)cells[k] * 0x9E3779B97F4A7C15ull);
+    if (k > 0 && keys[k] < keys[k - 1]) atomicAdd(&out[4], 1ull);
+}
+
+// ---- groups: maximal stretches of equal keys --------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long sp_block_excl(unsigned long long v, unsigned long long *total, unsigned long long *lds)
+{
+    // both words of v (two counts) at once: the sums stay below 2^32 each
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < SP_THREADS / 64; k++) { const unsigned long long s = lds[k]; if (k < w) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_groups(SpArgs a)
+{
+    __shared__ unsigned long long lds[SP_THREADS / 64];
+    const uint64_t N = a.N;
+    const uint64_t k0 = (uint64_t)blockIdx.x * SP_TILE + (uint64_t)threadIdx.x * SP_ITEMS;
+    uint64_t key[SP_ITEMS + 1];
+    uint32_t v[SP_ITEMS + 1];
+    {
+        const bool ok = k0 > 0 && k0 - 1 < N;
+        key[0] = ok ? a.keys[k0 - 1] : 0ull;
+        v[0] = (FILL && ok) ? a.vals[k0 - 1] : 0u;
+    }
+    uint32_t heads = 0, irr = 0;
+#pragma unroll
+    for (int j = 0; j < SP_ITEMS; j++) {
+        const uint64_t k = k0 + j;
+        const bool ok = k < N;
+        key[j + 1] = ok ? a.keys[k] : 0ull;
+        v[j + 1] = ok ? a.vals[k] : 0u;
+        if (ok && (k == 0 || key[j + 1] != key[j])) heads |= 1u << j;
+        if (ok && (v[j + 1] & SP_I)) irr |= 1u << j;
+    }
+    unsigned long long total;
+    const unsigned long long before = sp_block_excl((unsigned long long)__popc(heads) | ((unsigned long long)__popc(irr) << 32), &total, lds);
+    if (!FILL) {
+        if (threadIdx.x == 0) a.tile_cnt[blockIdx.x] = total;
+        return;
+    }
+    const unsigned long long base = a.tile_cnt[blockIdx.x] + before;
+    uint32_t gid = (uint32_t)base - 1;                        // group of the slot before the thread's first (wraps for slot 0: unused)
+    uint32_t iat = (uint32_t)(base >> 32);
+    uint32_t acc = 0, prow, pcol;
+    sp_decode(a, v[0], prow, pcol);
+#pragma unroll
+    for (int j = 0; j < SP_ITEMS; j++) {
+        const uint64_t k = k0 + j;
+        if (k >= N) break;
+        uint32_t row, col;
+        sp_decode(a, v[j + 1], row, col);
+        const bool sep = col >= a.n;
+        if ((heads >> j) & 1u) {
+            if (acc) atomicOr(&a.gflags[gid], acc);
+            acc = 0;
+            gid++;
+            a.gstart[gid] = (uint32_t)k;
+            a.gcol[gid] = col;
+        } else if (col != pcol) acc |= SPG_ODD;
+        if (sep) acc |= SPG_SEP;
+        else {
+            if (v[j + 1] & SP_W) acc |= SPG_ODD;
+            acc |= (v[j + 1] & SP_I) ? SPG_IRR : SPG_REG;
+            if ((irr >> j) & 1u) a.irr[iat++] = make_uint2((uint32_t)k, gid);
+        }
+        pcol = col;
+    }
+    if (acc) atomicOr(&a.gflags[gid], acc);
+}
+
+// ---- runs: maximal stretches of groups whose members all have the same one-column span ---------------------------
+__device__ __forceinline__ bool sp_run_head(const SpArgs &a, uint64_t g)
+{
+    if (g == 0) return true;
+    return ((a.gflags[g] | a.gflags[g - 1]) & (SPG_ODD | SPG_SEP)) || a.gcol[g] != a.gcol[g - 1];
+}
+
+template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_runs(SpArgs a)
+{
+    __shared__ unsigned long long lds[SP_THREADS / 64];
+    const uint64_t g0 = (uint64_t)blockIdx.x * SP_TILE + (uint64_t)threadIdx.x * SP_ITEMS;
+    uint32_t heads = 0;
+#pragma unroll
+    for (int j = 0; j < SP_ITEMS; j++)
+        if (g0 + j < a.G && sp_run_head(a, g0 + j)) heads |= 1u << j;
+    unsigned long long total;
+    const unsigned long long before = sp_block_excl((unsigned long long)__popc(heads), &total, lds);
+    if (!FILL) {
+        if (threadIdx.x == 0) a.rtile[blockIdx.x] = (uint32_t)total;
+        return;
+    }
+    uint32_t run = a.rtile[blockIdx.x] + (uint32_t)before - 1;
+#pragma unroll
+    for (int j = 0; j < SP_ITEMS; j++) {
+        const uint64_t g = g0 + j;
+        if (g >= a.G) break;
+        if ((heads >> j) & 1u) { run++; a.rstart[run] = (uint32_t)g; }
+        a.rid[g] = run;
+    }
+}
+
+// the odd groups, listed by size class (one reservation per wave: 5 * 10^5 single additions to one address took 5 ms)
+__global__ void k_sp_oddlist(SpArgs a, uint32_t cap)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    int cls = -1;
+    if (g < a.G) {
+        const uint32_t fl = a.gflags[g];
+        if ((fl & SPG_ODD) && !(fl & SPG_SEP)) cls = (a.gstart[g + 1] - a.gstart[g]) > 1024 ? 1 : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (!mask) continue;
+        unsigned long long base = 0;
+        if (lane == (uint32_t)__ffsll(mask) - 1) base = atomicAdd(&a.counters[c], (unsigned long long)__popcll(mask));
+        base = __shfl(base, __ffsll(mask) - 1, 64);
+        if (cls == c) {
+            const unsigned long long e = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1));
+            if (e < cap) (c ? a.odd_big : a.odd)[e] = (uint32_t)g; else a.counters[3] = 1;
+        }
+    }
+}
+
+// the pure interval of an odd group (one wave per group): the columns at which every member is coloured
+__global__ __launch_bounds__(256) void k_sp_odd_spans(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t max_group)
+{
+    const uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool have = e < count;
+    const uint32_t g = have ? list[e] : 0u;
+    const uint32_t s0 = a.gstart[g], s = have ? a.gstart[g + 1] - s0 : 0u, c0 = a.gcol[g];
+    uint32_t lo_max = 0, hi_min = SP_NONE, nodd = 0;
+    for (uint32_t i = lane; i < s; i += 64) {
+        const uint32_t v = a.vals[s0 + i];
+        uint32_t row, col, lo, hi;
+        sp_decode(a, v, row, col);
+        lo = hi = col;
+        if (v & SP_W) sp_wide_span(a, row, col, sp_pos(a, row, col), lo, hi);
+        if ((v & SP_W) || col != c0) nodd++;
+        if (lo > hi) { lo_max = SP_NONE; hi_min = 0; }       // a member that is never coloured
+        lo_max = max(lo_max, lo); hi_min = min(hi_min, hi);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo_max = max(lo_max, (uint32_t)__shfl_xor(lo_max, d, 64));
+        hi_min = min(hi_min, (uint32_t)__shfl_xor(hi_min, d, 64));
+        nodd += (uint32_t)__shfl_xor(nodd, d, 64);
+    }
+    __shared__ unsigned long long work, members;
+    if (threadIdx.x == 0) { work = 0; members = 0; }
+    __syncthreads();
+    if (lane == 0 && have) {
+        const bool none = lo_max > hi_min;
+        a.gplo[g] = none ? 1u : lo_max;
+        a.gphi[g] = none ? 0u : hi_min;
+        atomicAdd(&work, (unsigned long long)nodd * s);
+        atomicAdd(&members, (unsigned long long)nodd);
+        if (s > max_group || (!none && hi_min - lo_max >= SP_MAX_PURE)) a.counters[3] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && work) { atomicAdd(&a.counters[2], work); atomicAdd(&a.counters[5], members); }
+}
+
+// Nearest group beyond g (dir -1 / +1) with a member that is NOT coloured at column x: the symbols `key` shares with
+// its key (0: none, or a separator group).  Groups pure at x are coloured along; whole runs of them are jumped.
+__device__ uint32_t sp_outside(const SpArgs &a, uint64_t g, uint64_t key, uint32_t x, int dir)
+{
+    for (uint64_t h = g;;) {
+        if (dir < 0) { if (h == 0) return 0; h--; } else { h++; if (h >= a.G) return 0; }
+        const uint32_t fl = a.gflags[h];
+        if (fl & SPG_SEP) return 0;
+        if (fl & SPG_ODD) {
+            if (a.gplo[h] <= x && x <= a.gphi[h]) continue;
+        } else if (a.gcol[h] == x) {
+            const uint32_t run = a.rid[h];
+            h = dir < 0 ? a.rstart[run] : a.rstart[run + 1] - 1;
+            continue;
+        }
+        return sp_key_lcp(key, a.keys[a.gstart[h]], a.b, a.key_bits);
+    }
+}
+
+// the groups whose members all sit in one column with one-column spans: one thread each
+__global__ void k_sp_values(SpArgs a)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.G) return;
+    const uint32_t fl = a.gflags[g];
+    if (fl & (SPG_ODD | SPG_SEP)) return;
+    const uint32_t x = a.gcol[g];
+    const uint64_t key = a.keys[a.gstart[g]];
+    const uint32_t run = a.rid[g];
+    // (the groups of the run are coloured along: start beyond it)
+    const uint32_t gv = 1 + max(sp_outside(a, a.rstart[run], key, x, -1), sp_outside(a, (uint64_t)a.rstart[run + 1] - 1, key, x, +1));   // 1656
+    a.gval[g] = gv;
+    if (fl & SPG_REG) {
+        const uint32_t ign = sp_key_first_ignore(a, key, gv);
+        sp_update(a, x, x + (ign < gv ? ign : gv - 1));                                  // 1666, 1669-1670
+    }
+}
+
+// their irregular members: the extent by lookup
+__global__ void k_sp_irr(SpArgs a)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_irr) return;
+    const uint2 sg = a.irr[e];
+    if (a.gflags[sg.y] & (SPG_ODD | SPG_SEP)) return;
+    const uint32_t gv = a.gval[sg.y];
+    uint32_t row, col;
+    sp_decode(a, a.vals[sg.x], row, col);
+    const uint32_t p = sp_pos(a, row, col);
+    sp_update(a, col, sp_extent(a, p, row, gv, sp_key_first_ignore(a, a.keys[sg.x], gv)));
+}
+
+// ---- the odd groups: one workgroup each ---------------------------------------------------------------------------
+// k_sp_odd: the members' values in LDS, the odd members (flag W, or another column than the majority's) listed with
+// their spans; the columns of the group's pure interval as above, per member.  Every other column x of an odd member q
+// asks for 1 + the longest match of q with a member that is not coloured at x.  Where q is coloured ALONE at those
+// columns (the usual case: a row's symbol behind a gap run that no other row shares), that is its longest match with any
+// group mate, found without looking at the mates (k_sp_chain, below).  Else -- several odd members coloured together (a
+// deletion common to many rows), members of the majority column that are not all coloured there (a stray suffix of
+// another column in the group, a row's first symbol with the tricks on) -- every pair that matters is compared
+// (k_sp_odd_slow): the texts beyond the K symbols of the key, 128 bytes at a time, 16 lanes per mate, four mates per wave
+// and load, all four waves on the same q.  (All 5 * 10^5 odd members of the star phylogeny that way, 810 mates each:
+// 130 GB of scattered text lines, 48 ms and more.)
+__device__ __forceinline__ uint64_t sp_load8(const SpArgs &a, uint64_t p)
+{
+    return p + 8 <= a.N + 56 ? fbg_load8(a.T, p) : 0ull;       // (the text is padded by 64 bytes; no match runs beyond the sentinel)
+}
+
+#define SP_CHAIN_SCAN 16u             // members of a group looked at per step of the chain
+template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
+{
+    __shared__ uint32_t sv[CAP];
+    __shared__ uint16_t oidx[SP_MAX_ODD];
+    __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], opos[SP_MAX_ODD];
+    __shared__ uint32_t n_odd, s_gv, s_slow;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t g = list[e];
+        const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
+        __syncthreads();
+        if (s > CAP) continue;                                 // (flagged by k_sp_odd_spans)
+        if (threadIdx.x == 0) { n_odd = 0; s_slow = 0; }
+        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) sv[i] = a.vals[s0 + i];
+        __syncthreads();
+        uint32_t major;
+        {
+            uint32_t r0, c0, r1, c1, r2, c2;
+            sp_decode(a, sv[0], r0, c0); sp_decode(a, sv[s / 2], r1, c1); sp_decode(a, sv[s - 1], r2, c2);
+            major = (c0 == c1 || c0 == c2) ? c0 : c1;
+        }
+        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+            uint32_t row, col;
+            sp_decode(a, sv[i], row, col);
+            if ((sv[i] & SP_W) || col != major) {
+                const uint32_t o = atomicAdd(&n_odd, 1u);
+                if (o < SP_MAX_ODD) {
+                    const uint32_t p = sp_pos(a, row, col);
+                    uint32_t lo = col, hi = col;
+                    if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+                    oidx[o] = (uint16_t)i; olo[o] = lo; ohi[o] = hi; opos[o] = p;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t no = n_odd;
+        if (no > SP_MAX_ODD) { if (threadIdx.x == 0) a.counters[3] = 1; continue; }
+        const uint32_t plo = a.gplo[g], phi = a.gphi[g];
+        const uint64_t key = a.keys[s0];
+        const bool has_narrow = no < s;
+        // -- the pure interval (usually one column, the majority's): every member is coloured, keys decide
+        for (uint32_t x = plo; x <= phi && plo <= phi; x++) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_gv = 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1));
+            __syncthreads();
+            const uint32_t gv = s_gv;
+            const uint32_t kign = sp_key_first_ignore(a, key, gv);
+            for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+                uint32_t row, col;
+                sp_decode(a, sv[i], row, col);
+                const uint32_t fi = (sv[i] & SP_I) ? sp_extent(a, sp_pos(a, row, col), row, gv, kign) : col + (kign < gv ? kign : gv - 1);
+                sp_update(a, x, fi);
+            }
+        }
+        // -- the other columns of the odd members, and the majority column where an odd member is not coloured there: the
+        // chain list where the partners do not change from column to column; else the whole group -> the slow list
+        const bool major_open = has_narrow && !(plo <= major && major <= phi);   // members of the majority column with a mate that is not coloured there
+        bool slow = false;
+        for (uint32_t o = threadIdx.x; o < no; o += SP_THREADS) {
+            const uint32_t lo = olo[o], hi = ohi[o];
+            SpChain c;
+            c.nex = 0; c.evcol = 0;
+            if (major_open && !(lo <= major && major <= hi)) { c.nex |= SP_CH_EVENT; c.evcol = major; }
+            if (lo <= hi) {
+                // its columns outside the pure interval: [lo, xa] and [xb, hi]
+                const bool none = plo > phi;
+                const uint32_t xa = none ? hi : (plo > 0 ? min(hi, plo - 1) : 0u), xb = none ? hi + 1 : max(lo, phi + 1);
+                const bool left = none ? true : (plo > lo), right = !none && hi > phi;
+                if (left || right) {
+                    bool alone = !(has_narrow && ((left && lo <= major && major <= xa) || (right && xb <= major && major <= hi)));
+                    // the other odd members: never coloured at those columns (a mate like any other), or at all of them
+                    // (coloured along: no partner); one that is coloured at some of them only makes the partners change
+                    uint32_t nex = 0;
+                    for (uint32_t o2 = 0; o2 < no && alone; o2++) {
+                        if (o2 == o || olo[o2] > ohi[o2]) continue;
+                        const bool hitl = left && olo[o2] <= xa && lo <= ohi[o2], hitr = right && olo[o2] <= hi && xb <= ohi[o2];
+                        if (!hitl && !hitr) continue;
+                        const bool whole = (!left || (olo[o2] <= lo && xa <= ohi[o2])) && (!right || (olo[o2] <= xb && hi <= ohi[o2]));
+                        if (whole && nex < SP_CHAIN_EX) c.ex[nex++] = opos[o2]; else alone = false;
+                    }
+                    if (alone && hi - lo <= 1024) c.nex |= nex | SP_CH_OWN; else slow = true;
+                }
+            }
+            if (c.nex & (SP_CH_OWN | SP_CH_EVENT)) {
+                uint32_t row, col;
+                sp_decode(a, sv[oidx[o]], row, col);
+                const unsigned long long at = atomicAdd(&a.counters[6], 1ull);
+                if (at < a.chain_cap) {
+                    c.p = opos[o]; c.row = row; c.xlo = lo; c.xhi = hi; c.plo = plo; c.phi = phi; c.group = g;
+                    a.chain[at] = c;
+                } else a.counters[3] = 1;
+            }
+        }
+        if (slow) s_slow = 1;
+        __syncthreads();
+        if (threadIdx.x == 0 && s_slow) {
+            const unsigned long long at = atomicAdd(&a.counters[7], 1ull);
+            if (at < a.slow_cap) a.slow[at] = g; else a.counters[3] = 1;
+        }
+    }
+}
+
+// The longest match of the suffix at text position pq with any OTHER suffix that shares its first K symbols (its group
+// mates; but for those at the positions ex[]), without looking at the mates one by one.  A mate that matches L + 1 symbols and more has, at offset L - K + 1,
+// the same K symbols as pq has there: it sits L - K + 1 positions before a member of THAT key's group -- found by binary
+// search in the sorted keys.  So from L = K: the members of the group of the K symbols that end at offset L are tried
+// (shifted back, compared with pq from the start); the best of them lifts L to where the two part, and so on.  While the
+// rows go along with each other that group is the rows' copies of a later position and any few of its members lift L by a
+// mutation's distance; where pq itself leaves the others the group is small -- the rows that share the deviation -- and when
+// none of ALL its members goes on, L is the answer.  *fail: a large group none of whose first members goes on (repeats
+// inside the rows): every pair has to be compared.
+__device__ uint32_t sp_chain_max(const SpArgs &a, uint32_t pq, const uint32_t *ex, uint32_t nex, bool *fail)
+{
+    uint32_t L = (uint32_t)a.K;
+    *fail = false;
+    for (int step = 0; step < 4096; step++) {
+        const uint32_t shift = L - (uint32_t)a.K + 1;
+        const uint64_t t = (uint64_t)pq + shift;
+        if (t + 1 >= a.N) return L;                            // the sentinel: nothing matches beyond
+        uint64_t key = 0;
+        for (int k0 = 0; k0 < a.K; k0 += 8) {
+            const uint64_t x = sp_load8(a, t + k0);
+            for (int k = k0; k < a.K && k < k0 + 8; k++) key = (key << a.b) | (t + k < a.N ? (uint64_t)a.code[(x >> (8 * (k - k0))) & 255u] : 0ull);
+        }
+        uint64_t lo = 0, hi = a.N;                             // first slot whose key is not below
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a.keys[mid] < key) lo = mid + 1; else hi = mid; }
+        uint32_t best = L;
+        bool all = true;
+        for (uint64_t k = lo; k < a.N; k++) {
+            if (a.keys[k] != key) break;
+            if (k - lo >= SP_CHAIN_SCAN) { all = false; break; }
+            uint32_t row, col;
+            sp_decode(a, a.vals[k], row, col);
+            const uint32_t pv = sp_pos(a, row, col);
+            if (pv == t || pv < shift) continue;
+            const uint32_t u = pv - shift;
+            bool coloured = false;                             // a mate that is coloured along with pq is no partner
+            for (uint32_t i = 0; i < nex; i++) coloured = coloured || ex[i] == u;
+            if (coloured) continue;
+            best = max(best, fbg_clamp_lcp(fbg_extend_match(a.T, pq, (uint64_t)u, 0)));
+        }
+        if (best > L) { L = best; continue; }
+        if (!all) *fail = true;
+        return L;
+    }
+    *fail = true;
+    return L;
+}
+
+// a column that no row, extended by g symbols from its symbol at column x, gets beyond: whole 32-column windows with the
+// fewest symbols any row has in them
+__device__ uint32_t sp_upper(const SpArgs &a, uint32_t x, uint32_t g)
+{
+    if (!a.mins32) { const unsigned long long u = (unsigned long long)x + g - 1; return u < a.n ? (uint32_t)u : a.n; }
+    const uint32_t nwin = (a.n + 31) / 32;
+    uint32_t need = g - 1, w = (x >> 5) + 1;
+    while (w < nwin && need > a.mins32[w]) { need -= a.mins32[w]; w++; }
+    if (w >= nwin) return a.n;                                 // may run out of its row: fi = n with the tricks off
+    return min(a.n - 1, w * 32 + 31);
+}
+
+// pass 0: the OWN columns of the entries; pass 1 (after pass 0 of ALL entries, and whatever else raises the columns'
+// maxima): the EVENT entries -- a bound on what the members of the majority column could reach against q is compared
+// with the column's maximum so far; only where it is higher does the group go to the slow list
+__global__ void k_sp_chain(SpArgs a, uint32_t count, int pass)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const SpChain c = a.chain[e];
+    bool fail = false;
+    if (pass == 0) {
+        if (!(c.nex & SP_CH_OWN)) return;
+        const uint32_t g = sp_chain_max(a, c.p, c.ex, c.nex & 0xffu, &fail) + 1;         // 1656
+        if (!fail) {
+            const uint32_t fi = sp_extent(a, c.p, c.row, g, sp_first_ignore(a, c.p, sp_reach(a, c.p, c.row, g)));
+            for (uint64_t x = c.xlo; x <= c.xhi; x++)
+                if (!(c.plo <= x && x <= c.phi)) sp_update(a, (uint32_t)x, fi);
+        }
+    } else {
+        if (!(c.nex & SP_CH_EVENT)) return;
+        const uint32_t g = sp_chain_max(a, c.p, nullptr, 0, &fail) + 1;                 // no member of the majority column extends further
+        if (!fail && sp_upper(a, c.evcol, g) > a.fmax[c.evcol]) fail = true;
+    }
+    if (fail) {
+        const unsigned long long at = atomicAdd(&a.counters[7], 1ull);
+        if (at < a.slow_cap) a.slow[at] = c.group; else a.counters[3] = 1;
+    }
+}
+
+#define SP_WIN 128u
+
+template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
+{
+    __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
+    __shared__ uint16_t omap[CAP];                             // member -> its place in the odd list (0xffff: a member of the majority)
+    __shared__ uint16_t oidx[SP_MAX_ODD];
+    __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], Lq[SP_MAX_ODD];
+    __shared__ uint32_t n_odd, s_mn, s_any, s_gmax, s_ign;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t sub = lane >> 4, sl = lane & 15;            // mate of the wave's four, place in its 128-byte window
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t g = list[e];
+        const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
+        __syncthreads();
+        if (s > CAP) continue;                                 // (flagged by k_sp_odd_spans)
+        if (threadIdx.x == 0) n_odd = 0;
+        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
+        __syncthreads();
+        uint32_t major;
+        {
+            uint32_t r0, c0, r1, c1, r2, c2;
+            sp_decode(a, sv[0], r0, c0); sp_decode(a, sv[s / 2], r1, c1); sp_decode(a, sv[s - 1], r2, c2);
+            major = (c0 == c1 || c0 == c2) ? c0 : c1;
+        }
+        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+            uint32_t row, col;
+            sp_decode(a, sv[i], row, col);
+            const uint32_t p = sp_pos(a, row, col);
+            sp[i] = p;
+            if ((sv[i] & SP_W) || col != major) {
+                const uint32_t o = atomicAdd(&n_odd, 1u);
+                if (o < SP_MAX_ODD) {
+                    oidx[o] = (uint16_t)i;
+                    omap[i] = (uint16_t)o;
+                    uint32_t lo = col, hi = col;
+                    if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+                    olo[o] = lo; ohi[o] = hi;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t no = n_odd;
+        if (no > SP_MAX_ODD) { if (threadIdx.x == 0) a.counters[3] = 1; continue; }
+        const uint32_t plo = a.gplo[g], phi = a.gphi[g];
+        const bool has_narrow = no < s;
+        // -- the other columns of the odd members, one odd member after the other
+        for (uint32_t o = 0; o < no; o++) {
+            const uint32_t q = oidx[o], pq = sp[q], lo = olo[o], hi = ohi[o];
+            const bool at_major = lo <= major && major <= hi;  // coloured at the majority column: no partner for its members there
+            const bool own = lo <= hi && (plo > phi || lo < plo || hi > phi);   // has columns outside the pure interval
+            if (!own && (at_major || !has_narrow)) continue;   // (uniform over the workgroup)
+            __syncthreads();
+            if (threadIdx.x == 0) { s_mn = 0; s_any = 0; s_gmax = 0; s_ign = SP_NONE; }
+            __syncthreads();
+            // four rounds of loads in flight per wave (a round: 4 mates x 128 bytes), window after window until every one of
+            // the 16 mates has shown its first difference (a lane walking on alone, 8 bytes a step, made the other lanes of its
+            // wave wait through two dependent loads a step: 7 % of the mates match beyond the first window)
+            for (uint32_t u0 = wv * 4; u0 < s; u0 += 4 * (SP_THREADS / 16)) {
+                uint32_t Lr[4] = {0, 0, 0, 0};
+                bool lives[4], pend[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t u = u0 + r * (SP_THREADS / 16) + sub;
+                    lives[r] = u < s && u != q && (own || omap[u] == 0xffffu);
+                    pend[r] = lives[r];
+                }
+                for (uint32_t off = 0;; off += SP_WIN) {
+                    const uint64_t qtext = sp_load8(a, (uint64_t)pq + a.K + off + 8 * sl);
+                    uint64_t xs[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t u = u0 + r * (SP_THREADS / 16) + sub;
+                        xs[r] = pend[r] ? sp_load8(a, (uint64_t)sp[u] + a.K + off + 8 * sl) : qtext;
+                    }
+                    bool more = false;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint64_t diff = xs[r] ^ qtext;
+                        const uint32_t seg = (uint32_t)(__ballot(diff != 0) >> (16 * sub)) & 0xffffu;
+                        const uint32_t f = seg ? (uint32_t)__ffs(seg) - 1 : 0u;
+                        const uint64_t dfirst = __shfl(diff, (int)(16 * sub + f), 64);
+                        if (pend[r] && seg) { Lr[r] = off + 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8; pend[r] = false; }
+                        more = more || pend[r];
+                    }
+                    if (!__ballot(more)) break;                // (two suffixes differ at the sentinel at the latest)
+                }
+                if (sl != 0) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (!lives[r]) continue;
+                    const uint32_t u = u0 + r * (SP_THREADS / 16) + sub;
+                    const uint32_t L = fbg_clamp_lcp(Lr[r] + (uint32_t)a.K);
+                    const uint32_t ou = omap[u];
+                    if (ou == 0xffffu) {
+                        atomicMax(&s_mn, L);
+                        s_any = 1;
+                        if (!at_major) atomicMax(&nbest[u], L);
+                    } else Lq[ou] = L;
+                }
+            }
+            __syncthreads();
+            if (!own) continue;
+            const uint32_t mn = s_mn;
+            const bool any_narrow = s_any != 0;
+            // g at column x of the span: the majority members count everywhere but at their own column
+            auto g_at = [&](uint32_t x) -> uint32_t {
+                uint32_t best = (any_narrow && x != major) ? mn : 0u;
+                for (uint32_t o2 = 0; o2 < no; o2++)
+                    if (o2 != o && !(olo[o2] <= x && x <= ohi[o2])) best = max(best, Lq[o2]);
+                return best + 1;                                                         // 1656 (a partner exists: x is outside the pure interval)
+            };
+            uint32_t gm = 0;
+            for (uint64_t x = (uint64_t)lo + threadIdx.x; x <= hi; x += SP_THREADS)
+                if (!(plo <= x && x <= phi)) gm = max(gm, g_at((uint32_t)x));
+            if (gm) atomicMax(&s_gmax, gm);
+            __syncthreads();
+            uint32_t qrow, qcol;
+            sp_decode(a, sv[q], qrow, qcol);
+            // the row's first ignore character among the symbols any of those extensions reaches (one wave looks)
+            if (a.is_ignore && wv == 0) {
+                const uint32_t reach = sp_reach(a, pq, qrow, s_gmax);
+                uint32_t ign = SP_NONE;
+                for (uint32_t k0 = 0; k0 < reach && ign == SP_NONE; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    const unsigned long long hit = __ballot(k < reach && a.is_ignore[a.T[(uint64_t)pq + k]]);
+                    if (hit) ign = k0 + (uint32_t)__ffsll((unsigned long long)hit) - 1;
+                }
+                if (lane == 0) s_ign = ign;
+            }
+            __syncthreads();
+            const uint32_t ign = s_ign;
+            for (uint64_t x = (uint64_t)lo + threadIdx.x; x <= hi; x += SP_THREADS)
+                if (!(plo <= x && x <= phi)) sp_update(a, (uint32_t)x, sp_extent(a, pq, qrow, g_at((uint32_t)x), ign));
+        }
+        __syncthreads();
+        // -- the members of the majority column where some odd member is not coloured there
+        if (has_narrow && !(plo <= major && major <= phi)) {
+            for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+                uint32_t row, col;
+                sp_decode(a, sv[i], row, col);
+                if (omap[i] != 0xffffu || nbest[i] == 0) continue;
+                const uint32_t gv = nbest[i] + 1;
+                sp_update(a, major, sp_extent(a, sp[i], row, gv, sp_first_ignore(a, sp[i], sp_reach(a, sp[i], row, gv))));
+            }
+        }
+    }
+}
+
+// ---- the odd groups of up to 1024 members: everything in one workgroup, the mates' texts in registers ---------------
+// What made the kernel above slow is not the bytes but the waiting: every odd member walks its mates again, two or three
+// dependent rounds of scattered loads per 64 mates.  Here the 128 bytes behind the key of EVERY member are loaded once, in
+// one batch (a lane holds 8 bytes of each of up to 64 mates: 16 lanes per mate, four mates per wave and row), and the odd
+// members are then compared with them from registers; only the pairs that match beyond those 128 bytes (7 % when the rows
+// differ in 1 % of their symbols) go back to memory, gathered in a list and walked window by window.
+#define SPP_ROWS 64                  // 1024 members / (4 waves x 4 mates per wave and row)
+#define SPP_QW 64                    // odd members whose own 128 bytes wait in LDS
+__global__ __launch_bounds__(SP_THREADS) void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
+{
+    constexpr int CAP = 1024;
+    __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
+    __shared__ uint16_t omap[CAP];
+    __shared__ uint16_t oidx[SP_MAX_ODD];
+    __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], Lq[SP_MAX_ODD];
+    __shared__ uint64_t qwin[SPP_QW][16];
+    __shared__ uint16_t tails[SP_THREADS / 64][64];
+    __shared__ uint32_t ntail[SP_THREADS / 64];
+    __shared__ uint32_t n_odd, s_gv, s_mn, s_any, s_gmax, s_ign, s_need;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t sub = lane >> 4, sl = lane & 15;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint32_t g = list[e];
+        const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
+        __syncthreads();
+        if (s > CAP) continue;
+        if (threadIdx.x == 0) { n_odd = 0; s_need = 0; }
+        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
+        __syncthreads();
+        uint32_t major;
+        {
+            uint32_t r0, c0, r1, c1, r2, c2;
+            sp_decode(a, sv[0], r0, c0); sp_decode(a, sv[s / 2], r1, c1); sp_decode(a, sv[s - 1], r2, c2);
+            major = (c0 == c1 || c0 == c2) ? c0 : c1;
+        }
+        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+            uint32_t row, col;
+            sp_decode(a, sv[i], row, col);
+            const uint32_t p = sp_pos(a, row, col);
+            sp[i] = p;
+            if ((sv[i] & SP_W) || col != major) {
+                const uint32_t o = atomicAdd(&n_odd, 1u);
+                if (o < SP_MAX_ODD) {
+                    oidx[o] = (uint16_t)i;
+                    omap[i] = (uint16_t)o;
+                    uint32_t lo = col, hi = col;
+                    if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+                    olo[o] = lo; ohi[o] = hi;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t no = n_odd;
+        if (no > SP_MAX_ODD) { if (threadIdx.x == 0) a.counters[3] = 1; continue; }
+        const uint32_t plo = a.gplo[g], phi = a.gphi[g];
+        const uint64_t key = a.keys[s0];
+        const bool has_narrow = no < s;
+        // -- the pure interval (usually one column, the majority's): every member is coloured, keys decide
+        for (uint32_t x = plo; x <= phi && plo <= phi && !(a.dbg & 1); x++) {
+            __syncthreads();
+            if (threadIdx.x == 0) s_gv = 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1));
+            __syncthreads();
+            const uint32_t gv = s_gv;
+            const uint32_t kign = sp_key_first_ignore(a, key, gv);
+            for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+                uint32_t row, col;
+                sp_decode(a, sv[i], row, col);
+                const uint32_t fi = (sv[i] & SP_I) ? sp_extent(a, sp[i], row, gv, kign) : col + (kign < gv ? kign : gv - 1);
+                sp_update(a, x, fi);
+            }
+        }
+        // does any odd member have a column of its own, or is one a partner of the majority's members?
+        for (uint32_t o = threadIdx.x; o < no; o += SP_THREADS) {
+            const uint32_t lo = olo[o], hi = ohi[o];
+            const bool at_major = lo <= major && major <= hi;
+            const bool own = lo <= hi && (plo > phi || lo < plo || hi > phi);
+            if (own || (!at_major && has_narrow)) s_need = 1;
+        }
+        __syncthreads();
+        if (!s_need || (a.dbg & 2)) continue;
+        // -- the 128 bytes behind the key of every member -> registers; of the first odd members -> LDS
+        uint64_t mt[SPP_ROWS];
+#pragma unroll
+        for (int r = 0; r < SPP_ROWS; r++) {
+            const uint32_t u = (uint32_t)r * 16 + wv * 4 + sub;
+            mt[r] = ((uint32_t)r * 16 < s && u < s) ? sp_load8(a, (uint64_t)sp[u] + a.K + 8 * sl) : 0ull;
+        }
+        for (uint32_t o = wv * 4 + sub; o < no && o < SPP_QW; o += SP_THREADS / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
+        // -- the other columns of the odd members, one odd member after the other
+        for (uint32_t o = 0; o < no && !(a.dbg & 4); o++) {
+            const uint32_t q = oidx[o], pq = sp[q], lo = olo[o], hi = ohi[o];
+            const bool at_major = lo <= major && major <= hi;  // coloured at the majority column: no partner for its members there
+            const bool own = lo <= hi && (plo > phi || lo < plo || hi > phi);   // has columns outside the pure interval
+            if (!own && (at_major || !has_narrow)) continue;   // (uniform over the workgroup)
+            __syncthreads();
+            if (threadIdx.x == 0) { s_mn = 0; s_any = 0; s_gmax = 0; s_ign = SP_NONE; }
+            if (lane == 0) ntail[wv] = 0;
+            __syncthreads();
+            const uint64_t qtext = o < SPP_QW ? qwin[o][sl] : sp_load8(a, (uint64_t)pq + a.K + 8 * sl);
+            auto note = [&](uint32_t u, uint32_t Lbeyond) {    // the match of q with member u beyond the key
+                const uint32_t L = fbg_clamp_lcp(Lbeyond + (uint32_t)a.K);
+                const uint32_t ou = omap[u];
+                if (ou == 0xffffu) {
+                    atomicMax(&s_mn, L);
+                    s_any = 1;
+                    if (!at_major) atomicMax(&nbest[u], L);
+                } else Lq[ou] = L;
+            };
+#pragma unroll
+            for (int r = 0; r < SPP_ROWS; r++) {
+                if ((uint32_t)r * 16 >= s) break;              // (uniform)
+                const uint32_t u = (uint32_t)r * 16 + wv * 4 + sub;
+                const bool live = u < s && u != q && (own || omap[u] == 0xffffu);
+                const uint64_t diff = live ? mt[r] ^ qtext : 1ull;
+                const uint32_t seg = (uint32_t)(__ballot(diff != 0) >> (16 * sub)) & 0xffffu;
+                const uint32_t f = seg ? (uint32_t)__ffs(seg) - 1 : 0u;
+                const uint64_t dfirst = __shfl(diff, (int)(16 * sub + f), 64);
+                if (live && sl == 0) {
+                    if (seg) note(u, 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8);
+                    else { const uint32_t at = atomicAdd(&ntail[wv], 1u); if (at < 64) tails[wv][at] = (uint16_t)u; else note(u, fbg_extend_match(a.T, (uint64_t)pq + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN); }
+                }
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            // the pairs that match beyond the first window: four at a time, window after window
+            const uint32_t nt = min(ntail[wv], 64u);
+            for (uint32_t t0 = 0; t0 < nt; t0 += 4) {
+                const bool live = t0 + sub < nt;
+                const uint32_t u = live ? tails[wv][t0 + sub] : 0u;
+                bool pend = live;
+                uint32_t Lb = 0;
+                for (uint32_t off = SP_WIN;; off += SP_WIN) {
+                    const uint64_t qx = sp_load8(a, (uint64_t)pq + a.K + off + 8 * sl);
+                    const uint64_t x = pend ? sp_load8(a, (uint64_t)sp[u] + a.K + off + 8 * sl) : qx;
+                    const uint64_t diff = x ^ qx;
+                    const uint32_t seg = (uint32_t)(__ballot(diff != 0) >> (16 * sub)) & 0xffffu;
+                    const uint32_t f = seg ? (uint32_t)__ffs(seg) - 1 : 0u;
+                    const uint64_t dfirst = __shfl(diff, (int)(16 * sub + f), 64);
+                    if (pend && seg) { Lb = off + 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8; pend = false; }
+                    if (!__ballot(pend)) break;                // (two suffixes differ at the sentinel at the latest)
+                }
+                if (live && sl == 0) note(u, Lb);
+            }
+            __syncthreads();
+            if (!own) continue;
+            const uint32_t mn = s_mn;
+            const bool any_narrow = s_any != 0;
+            // g at column x of the span: the majority members count everywhere but at their own column
+            auto g_at = [&](uint32_t x) -> uint32_t {
+                uint32_t best = (any_narrow && x != major) ? mn : 0u;
+                for (uint32_t o2 = 0; o2 < no; o2++)
+                    if (o2 != o && !(olo[o2] <= x && x <= ohi[o2])) best = max(best, Lq[o2]);
+                return best + 1;                                                         // 1656 (a partner exists: x is outside the pure interval)
+            };
+            uint32_t gm = 0;
+            for (uint64_t x = (uint64_t)lo + threadIdx.x; x <= hi; x += SP_THREADS)
+                if (!(plo <= x && x <= phi)) gm = max(gm, g_at((uint32_t)x));
+            if (gm) atomicMax(&s_gmax, gm);
+            __syncthreads();
+            uint32_t qrow, qcol;
+            sp_decode(a, sv[q], qrow, qcol);
+            if (a.is_ignore && wv == 0) {                      // the row's first ignore character among the symbols any of those extensions reaches
+                const uint32_t reach = sp_reach(a, pq, qrow, s_gmax);
+                uint32_t ign = SP_NONE;
+                for (uint32_t k0 = 0; k0 < reach && ign == SP_NONE; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    const unsigned long long hit = __ballot(k < reach && a.is_ignore[a.T[(uint64_t)pq + k]]);
+                    if (hit) ign = k0 + (uint32_t)__ffsll((unsigned long long)hit) - 1;
+                }
+                if (lane == 0) s_ign = ign;
+            }
+            __syncthreads();
+            const uint32_t ign = s_ign;
+            for (uint64_t x = (uint64_t)lo + threadIdx.x; x <= hi; x += SP_THREADS)
+                if (!(plo <= x && x <= phi)) sp_update(a, (uint32_t)x, sp_extent(a, pq, qrow, g_at((uint32_t)x), ign));
+        }
+        __syncthreads();
+        // -- the members of the majority column where some odd member is not coloured there
+        if (has_narrow && !(plo <= major && major <= phi)) {
+            for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+                uint32_t row, col;
+                sp_decode(a, sv[i], row, col);
+                if (omap[i] != 0xffffu || nbest[i] == 0) continue;
+                const uint32_t gv = nbest[i] + 1;
+                sp_update(a, major, sp_extent(a, sp[i], row, gv, sp_first_ignore(a, sp[i], sp_reach(a, sp[i], row, gv))));
+            }
+        }
+    }
+}
+
+// With the tricks off a row that has ended keeps its '#' as the pointer: gg > tot, fi = n (fbg.cpp:1659-1664) for every
+// column behind the row's last symbol -- from the smallest such column on
+__global__ void k_sp_row_ends(SpArgs a)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.m) return;
+    const uint32_t tt = a.tot[row];
+    const unsigned long long first = tt ? (unsigned long long)sp_col_of(a, a.pos[row] + tt - 1, row) + 1 : 0ull;
+    atomicMin(&a.counters[4], first);
+}
+__global__ void k_sp_fill_ends(SpArgs a)
+{
+    const uint64_t x = a.counters[4] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < a.n) a.fmax[x] = a.n;
+}
+
+template <class F> static int sp_with_tmp(fbg_ctx *ctx, F &&call)
+{
+    size_t bytes = 0;
+    hipError_t e = call(nullptr, bytes);
+    if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim size query: %s", hipGetErrorString(e));
+    FBG_TRY(fbg_reserve(ctx, ctx->tmp, bytes));
+    size_t have = ctx->tmp.cap;
+    e = call(ctx->tmp.p, have);
+    if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim call: %s", hipGetErrorString(e));
+    return FBG_OK;
+}
+
+static void sp_args(fbg_ctx *ctx, SpArgs &a, int disable_tricks)
+{
+    a.keys = ctx->rk_keys; a.vals = ctx->sa_ptr; a.N = ctx->N;
+    a.n = (uint32_t)ctx->n; a.m = (uint32_t)ctx->m; a.row_len = (uint32_t)(ctx->n + 1);
+    a.magic = (uint32_t)((1ull << 32) / (ctx->n + 1));
+    a.b = ctx->rk_b; a.K = ctx->rk_K; a.key_bits = ctx->rk_key_bits; a.disable_tricks = disable_tricks;
+    a.T = ctx->text.as<uint8_t>();
+    a.colT = ctx->gapfree ? nullptr : ctx->colT.as<uint32_t>();
+    a.pos = ctx->pos.as<uint32_t>(); a.tot = ctx->tot.as<uint32_t>();
+    a.cwin = ctx->gapfree ? nullptr : ctx->sp_cwin.as<CWin>();
+    a.wpr = (uint32_t)((ctx->n + 127) / 128);
+    a.is_ignore = ctx->have_ignore ? ctx->small.as<uint8_t>() : nullptr;
+    a.ign_lo = ctx->grs_ign_lo; a.ign_hi = ctx->grs_ign_hi;
+    a.tile_cnt = ctx->sp_tiles.as<unsigned long long>();
+    a.gstart = ctx->sp_gstart.as<uint32_t>(); a.gcol = ctx->sp_gcol.as<uint32_t>(); a.gflags = ctx->sp_gflags.as<uint32_t>();
+    a.G = ctx->sp_G;
+    a.rtile = nullptr; a.rstart = ctx->sp_rstart.as<uint32_t>(); a.rid = ctx->sp_rid.as<uint32_t>(); a.R = ctx->sp_R;
+    a.gplo = ctx->sp_gplo.as<uint32_t>(); a.gphi = ctx->sp_gphi.as<uint32_t>(); a.gval = ctx->sp_gval.as<uint32_t>();
+    a.odd = ctx->sp_odd.as<uint32_t>(); a.odd_big = a.odd + ctx->sp_odd_cap;
+    a.irr = ctx->sp_irr.as<uint2>(); a.n_irr = ctx->sp_n_irr;
+    a.fmax = ctx->gmax.as<uint32_t>();
+    a.counters = ctx->scalars.as<unsigned long long>() + 208;     // (gapped_rank.hip: 128 .. 202)
+    a.code = ctx->small.as<uint8_t>() + 2048;                     // (fbg_key_setup's table)
+    a.chain = ctx->sp_chain.as<SpChain>(); a.chain_cap = (uint32_t)(ctx->sp_chain.cap / sizeof(SpChain));
+    a.slow = ctx->sp_slow.as<uint32_t>(); a.slow_cap = (uint32_t)(ctx->sp_slow.cap / 4);
+    a.mins32 = ctx->gapfree ? nullptr : ctx->sp_mins.as<uint32_t>();
+    a.dbg = ctx->opt.span_scan >= 16 ? (int)ctx->opt.span_scan : 0;
+}
+
+// May this MSA go through the group-level scan on spans at all?  (the caller has decided that its rows are similar)
+bool fbg_span_eligible(fbg_ctx *ctx, const KeyGeom &g)
+{
+    if (ctx->opt.span_scan == -1 || ctx->grs_skip || ctx->reversed) return false;   // (span_scan = 2: as 0, plus a check of the sort)
+    if (ctx->gapfree && !ctx->have_ignore) return false;
+    if (g.compact || g.packed || g.wide || g.K > 32 || g.K < 2) return false;
+    if ((ctx->m + 1) * (ctx->n + 1) >= (1ull << 30) || ctx->m >= 65535) return false;
+    if (ctx->have_ignore && ctx->ignore_tab[(unsigned char)'-']) return false;          // gap cells that clamp: the record path's per-cell table
+    return true;
+}
+
+// Before the sort (fbg_grs_prepare has made the bitmap of irregular positions): the payload of every text position ->
+// ctx->sp_cells, the window table of the cells.
+int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches)
+{
+    const uint64_t N = ctx->N, n = ctx->n, m = ctx->m;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_reserve(ctx, ctx->sp_cells, N * 4));
+    if (!ctx->gapfree) {
+        const uint32_t wpr = (uint32_t)((n + 127) / 128);
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_cwin, (size_t)m * wpr * sizeof(CWin)));
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_mins, (size_t)wpr * 4 * 4));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->sp_mins.p, 0x7f, (size_t)wpr * 4 * 4, st));
+        hipLaunchKernelGGL(k_sp_cwin, dim3((wpr + 3) / 4, (unsigned)m), dim3(256), 0, st, ctx->d_msa, (uint32_t)n, wpr, ctx->sp_cwin.as<CWin>(), ctx->sp_mins.as<uint32_t>());
+        hipLaunchKernelGGL(k_sp_cwin_scan, dim3((unsigned)m), dim3(64), 0, st, wpr, ctx->sp_cwin.as<CWin>());
+        *launches += 2;
+    }
+    hipLaunchKernelGGL(k_sp_cells, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, ctx->gapfree ? (const uint32_t *)nullptr : ctx->colT.as<uint32_t>(),
+                       ctx->pos.as<uint32_t>(), N, (uint32_t)n, (uint32_t)m, g.K, ctx->gbits.as<unsigned long long>(), ctx->sp_cells.as<uint32_t>());
+    *launches += 1;
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    return FBG_OK;
+}
+
+// the tricks-dependent part: pure intervals of the odd groups, values, odd groups; *ok = 0: a capacity did not hold
+static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
+{
+    *ok = 0;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = ctx->n, G = ctx->sp_G;
+    SpArgs a;
+    sp_args(ctx, a, disable_tricks);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 2, 0, 6 * sizeof(unsigned long long), st));
+    const uint32_t n_small = ctx->sp_n_odd[0], n_big = ctx->sp_n_odd[1];
+    if (n_small) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(n_small, 4)), dim3(256), 0, st, a, (const uint32_t *)a.odd, n_small, 1024u);
+    if (n_big) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(n_big, 4)), dim3(256), 0, st, a, (const uint32_t *)a.odd_big, n_big, 8192u);
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *launches += 2;
+    ctx->sp_work = h[0];
+    // text comparisons ahead (odd members x group size): beyond a few dozen per suffix of the text the record path is cheaper
+    if (h[1] != 0 || h[0] > std::max<unsigned long long>(32 * ctx->N, 1ull << 26)) return FBG_OK;
+    // the larger groups' odd members: a list for those that are coloured alone, a list of the groups that need every pair compared
+    const uint64_t members = h[3];
+    FBG_TRY(fbg_reserve(ctx, ctx->sp_chain, (members + 1) * sizeof(SpChain)));
+    FBG_TRY(fbg_reserve(ctx, ctx->sp_slow, ((uint64_t)n_small + n_big + members + 1) * 4));
+    sp_args(ctx, a, disable_tricks);
+    hipLaunchKernelGGL(k_sp_values, dim3(fbg_blocks(G, 256)), dim3(256), 0, st, a);
+    if (a.n_irr) hipLaunchKernelGGL(k_sp_irr, dim3(fbg_blocks(a.n_irr, 256)), dim3(256), 0, st, a);
+    // the odd groups of up to 1024 members: one kernel, everything; the larger ones (more than 1024 rows): pure interval and
+    // lists (k_sp_odd), the chains (k_sp_chain), every pair where that does not do (k_sp_odd_slow)
+    if (n_small) hipLaunchKernelGGL(k_sp_odd_pairs, dim3(std::min<uint32_t>(n_small, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.odd, n_small);
+    *launches += 3;
+    ctx->sp_chain_n = 0; ctx->sp_slow_n = 0;
+    if (n_big) {
+        hipLaunchKernelGGL((k_sp_odd<8192>), dim3(std::min<uint32_t>(n_big, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.odd_big, n_big);
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (h[1] != 0) return FBG_OK;
+        const uint32_t n_chain = (uint32_t)h[4];
+        if (n_chain) {
+            hipLaunchKernelGGL(k_sp_chain, dim3(fbg_blocks(n_chain, 64)), dim3(64), 0, st, a, n_chain, 0);
+            hipLaunchKernelGGL(k_sp_chain, dim3(fbg_blocks(n_chain, 64)), dim3(64), 0, st, a, n_chain, 1);
+        }
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (h[1] != 0) return FBG_OK;
+        const uint32_t n_slow = (uint32_t)h[5];
+        ctx->sp_chain_n = n_chain; ctx->sp_slow_n = n_slow;
+        if (n_slow) hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow);
+        *launches += 4;
+    }
+    if (disable_tricks) {
+        const unsigned long long none = n;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(a.counters + 4, &none, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_sp_row_ends, dim3(fbg_blocks(ctx->m, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_sp_fill_ends, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a);
+        *launches += 2;
+    }
+    unsigned long long flag = 0;
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&flag, a.counters + 3, 8, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+    FBG_HIP_TRY(ctx, hipGetLastError());
+    if (flag != 0) return FBG_OK;
+    ctx->grs_tricks_off = disable_tricks;
+    *ok = 1;
+    return FBG_OK;
+}
+
+// the ignore characters as a mask over the key's symbol codes (ranks of the bytes that occur)
+static bool sp_ignore_mask(fbg_ctx *ctx, uint64_t *by_code)
+{
+    *by_code = 0;
+    if (!ctx->have_ignore) return true;
+    int code = 0;
+    for (int c = 0; c < 256; c++) {
+        const bool occurs = ctx->byte_hist[c] != 0;
+        if (ctx->ignore_tab[c] && occurs) { if (code >= 64) return false; *by_code |= 1ull << code; }
+        if (occurs) code++;
+    }
+    return true;
+}
+
+// After the sort of the (key, cell) pairs.  *done = 1: the index is the sorted slots, the group tables and the
+// per-column maxima (ctx->granked, ctx->spanned); 0: vals hold text positions again, continue with the record path.
+int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done)
+{
+    *done = 0;
+    ctx->granked = false; ctx->spanned = false;
+    const uint64_t N = ctx->N, n = ctx->n;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
+    int launches = 0;
+    uint64_t by_code = 0;
+    bool good = sp_ignore_mask(ctx, &by_code);
+    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
+    ctx->rk_keys = keys; ctx->sa_ptr = vals;
+    ctx->rk_layout = FBG_SLOTS_PAIRS; ctx->rk_pb = 0; ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
+    ctx->grs_ign_lo = (uint32_t)by_code; ctx->grs_ign_hi = (uint32_t)(by_code >> 32);
+    ctx->sp_G = 0; ctx->sp_R = 0; ctx->sp_n_irr = 0; ctx->sp_n_odd[0] = ctx->sp_n_odd[1] = 0; ctx->sp_odd_cap = 0;
+    SpArgs a;
+    if (good && ctx->opt.span_scan == 2) {
+        // debugging aid: the sorted values are a permutation of the cells (sum and xor agree), the keys ascend
+        sp_args(ctx, a, 0);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 16, 0, 8 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_sp_check, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keys, (const uint32_t *)vals, ctx->sp_cells.as<uint32_t>(), N, a.counters + 16);
+    }
+    if (good) {
+        // groups
+        const unsigned tiles = fbg_blocks(N, SP_TILE);
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_tiles, ((size_t)tiles + 1) * 8));
+        sp_args(ctx, a, 0);
+        hipLaunchKernelGGL((k_sp_groups<false>), dim3(tiles), dim3(SP_THREADS), 0, st, a);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.tile_cnt + tiles, 0, 8, st));
+        FBG_TRY(sp_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::exclusive_scan(tmp, bytes, a.tile_cnt, a.tile_cnt, 0ull, (size_t)tiles + 1, rocprim::plus<unsigned long long>(), st);
+        }));
+        unsigned long long tot = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot, a.tile_cnt + tiles, 8, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        launches += 2;
+        const uint64_t G = (uint32_t)tot, n_irr = tot >> 32;
+        ctx->sp_G = G; ctx->sp_n_irr = n_irr;
+        for (DevBuf *b : {&ctx->sp_gstart, &ctx->sp_gcol, &ctx->sp_gflags, &ctx->sp_rid, &ctx->sp_gplo, &ctx->sp_gphi, &ctx->sp_gval})
+            FBG_TRY(fbg_reserve(ctx, *b, (G + 1) * 4));
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_irr, (n_irr + 1) * 8));
+        sp_args(ctx, a, 0);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.gflags, 0, (G + 1) * 4, st));
+        hipLaunchKernelGGL((k_sp_groups<true>), dim3(tiles), dim3(SP_THREADS), 0, st, a);
+        const uint32_t N32 = (uint32_t)N;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(a.gstart + G, &N32, 4, hipMemcpyHostToDevice, st));
+        // runs
+        const unsigned gtiles = fbg_blocks(G, SP_TILE);
+        FBG_TRY(fbg_reserve(ctx, ctx->ps_e, ((size_t)gtiles + 1) * 4));
+        a.rtile = ctx->ps_e.as<uint32_t>();
+        hipLaunchKernelGGL((k_sp_runs<false>), dim3(gtiles), dim3(SP_THREADS), 0, st, a);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.rtile + gtiles, 0, 4, st));
+        FBG_TRY(sp_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::exclusive_scan(tmp, bytes, a.rtile, a.rtile, 0u, (size_t)gtiles + 1, rocprim::plus<uint32_t>(), st);
+        }));
+        uint32_t R32 = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&R32, a.rtile + gtiles, 4, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));               // (also: N32 above lives on this frame)
+        launches += 3;
+        ctx->sp_R = R32;
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_rstart, ((size_t)R32 + 1) * 4));
+        a.rstart = ctx->sp_rstart.as<uint32_t>(); a.R = R32;
+        hipLaunchKernelGGL((k_sp_runs<true>), dim3(gtiles), dim3(SP_THREADS), 0, st, a);
+        const uint32_t G32 = (uint32_t)G;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(a.rstart + R32, &G32, 4, hipMemcpyHostToDevice, st));
+        // the odd groups, listed
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(G, 1u << 24);
+        ctx->sp_odd_cap = cap;
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_odd, (size_t)cap * 8));
+        sp_args(ctx, a, 0);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 16 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_sp_oddlist, dim3(fbg_blocks(G, 256)), dim3(256), 0, st, a, cap);
+        unsigned long long h[4];
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        launches += 2;
+        if (h[3] != 0) good = false;
+        ctx->sp_n_odd[0] = (uint32_t)std::min<unsigned long long>(h[0], cap);
+        ctx->sp_n_odd[1] = (uint32_t)std::min<unsigned long long>(h[1], cap);
+    }
+    int ok = 0;
+    if (good) FBG_TRY(sp_scan(ctx, 0, &ok, &launches));
+    if (ok) {
+        ctx->granked = true; ctx->spanned = true;
+        ctx->ranked = false; ctx->part_active = false;
+        *done = 1;
+    } else {
+        sp_args(ctx, a, 0);
+        hipLaunchKernelGGL(k_sp_to_positions, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a, vals);
+        launches++;
+        FBG_HIP_TRY(ctx, hipGetLastError());
+    }
+    return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+}
+
+// the scan again for the other setting of the elastic tricks (fbg_scan_f); *ok = 0: a capacity did not hold
+int fbg_span_rescan(fbg_ctx *ctx, int disable_tricks, int *ok)
+{
+    int launches = 0;
+    return sp_scan(ctx, disable_tricks, ok, &launches);
+}

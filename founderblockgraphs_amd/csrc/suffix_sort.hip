@@ -58,6 +58,7 @@ struct PackArgs {
     int nohi;
     unsigned long long *counter;
     const uint64_t *ebits = nullptr;   // PAIRS: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
+    const uint32_t *payload = nullptr; // PAIRS: the value of position p is payload[p] (span_scan.hip: cell | flags)
 };
 
 // any irregular position among [p, p + K)?  (K <= 32; the bitmap is padded beyond the text)
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
             if (p < a.N) {
                 if (LAYOUT == FBG_SLOTS_PACKED) a.keys[p] = (skeys[j] << a.pb) | p;
                 else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[p] = (skeys[j] << a.pb) | (p >> 32); a.vals[p] = (uint32_t)p; }
-                else { a.keys[p] = skeys[j]; a.vals[p] = (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
+                else { a.keys[p] = skeys[j]; a.vals[p] = a.payload ? a.payload[p] : (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
             }
         }
         return;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
                 const uint64_t p = base + j;
                 if (LAYOUT == FBG_SLOTS_PACKED) a.keys[o] = (skeys[j] << a.pb) | p;
                 else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[o] = (skeys[j] << a.pb) | (p >> 32); a.vals[o] = (uint32_t)p; }
-                else { a.keys[o] = skeys[j]; a.vals[o] = (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
+                else { a.keys[o] = skeys[j]; a.vals[o] = a.payload ? a.payload[p] : (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
             }
         }
         off += (uint64_t)__popcll(keep[i]);
@@ -893,8 +894,23 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     // MSAs with gaps / ignore characters: the scan in rank order follows the sort (gapped_rank.hip); its table of the
     // text's irregular positions is made now, the pack kernels fold it into the values' top bit
     ctx->pairs_similar = false;
-    const bool try_grs = (!ctx->gapfree || ctx->have_ignore) && !ctx->reversed && !ctx->grs_skip && ctx->opt.gapped_rank != -1 && K <= 32;
-    if (try_grs) FBG_TRY(fbg_grs_prepare(ctx, &launches));
+    ctx->spanned = false;
+    ctx->sort_payload = nullptr;
+    // rows that resemble each other (twins among the keys of a sample; option span_scan = 1: whatever the rows): the
+    // group-level scan on column spans (span_scan.hip), whose sort carries cells instead of positions
+    bool try_span = fbg_span_eligible(ctx, g);
+    if (try_span && ctx->opt.span_scan != 1) {
+        bool similar = false;
+        FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
+        try_span = similar;
+    }
+    const bool try_grs = !try_span && (!ctx->gapfree || ctx->have_ignore) && !ctx->reversed && !ctx->grs_skip && ctx->opt.gapped_rank != -1 && K <= 32;
+    if (try_grs || try_span) FBG_TRY(fbg_grs_prepare(ctx, &launches));
+    if (try_span) {
+        ctx->grs_ebits = nullptr; ctx->grs_flagged = false;           // (the bitmap goes into the cells' flags instead)
+        FBG_TRY(fbg_span_prepare(ctx, g, &launches));
+        ctx->sort_payload = ctx->sp_cells.as<uint32_t>();
+    }
     {
         // three passes of a sample sort fused with the key packing (msd_sort_pairs.hip) where the sizes suit it; else,
         // or when a capacity does not hold, pack and sort with rocPRIM's onesweep
@@ -907,10 +923,12 @@ int fbg_suffix_sort(fbg_ctx *ctx)
             pa.keys = ctx->keysA.as<uint64_t>(); pa.vals = ctx->valsA.as<uint32_t>();
             pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
             pa.ebits = ctx->grs_ebits;
+            pa.payload = ctx->sort_payload;
             launch_pack(ctx, g, false, pa);
             launches++;
             FBG_TRY(sort_slots(ctx, g, N, 0));
         }
+        ctx->sort_payload = nullptr;
         // the sample sort sizes its buffers itself: take the pointers again
         keysA = ctx->keysA.as<uint64_t>(); keysB = ctx->keysB.as<uint64_t>();
         valsA = ctx->valsA.as<uint32_t>(); valsB = ctx->valsB.as<uint32_t>();
@@ -919,7 +937,15 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     }
     // ---- MSAs with gaps / ignore characters: the extension scan in rank order on these slots (gapped_rank.hip) ----
     ctx->grs_ebits = nullptr;
-    if (try_grs && ctx->pairs_similar) FBG_TRY(fbg_grs_strip(ctx, valsB));    // similar rows: tie groups of hundreds, not for that scan
+    if (try_span) {
+        int done = 0;
+        FBG_TRY(fbg_span_try(ctx, keysB, valsB, g, &done));
+        if (done) {
+            FBG_HIP_TRY(ctx, hipGetLastError());
+            return fbg_stage_end(ctx, FBG_STAGE_SUFFIX_SORT, launches);
+        }
+        // declined: the values are text positions again, the record path goes on from here
+    } else if (try_grs && ctx->pairs_similar) FBG_TRY(fbg_grs_strip(ctx, valsB));    // similar rows: tie groups of hundreds, not for that scan
     else if (try_grs) {
         int done = 0;
         FBG_TRY(fbg_grs_try(ctx, keysB, valsB, g, &done));

@@ -1236,3 +1236,97 @@ def test_gapped_v_on_a_partitioned_index():
     finally:
         for e in engines:
             e.close()
+
+
+# ---- similar rows WITH gaps / ignore characters: the group-level scan on column spans (span_scan.hip) -----------------
+
+def star_msa(rng, m, n, sub=0.01, gap_cells=0.02, gap_run=8, n_p=0.0, shared=0.0, lead=0, alphabet="ACGT"):
+    """A star phylogeny: one random ancestor, every row substitutes each position with probability `sub`; `gap_cells` of
+    the cells lie in gap runs of `gap_run` (each row its own; `shared`: that fraction of the runs is copied into a third
+    of the rows -- deletions common to many rows, as in a real pangenome); `lead`: some rows start / end with gaps."""
+    alpha = np.frombuffer(alphabet.encode(), dtype=np.uint8)
+    anc = alpha[rng.integers(0, len(alpha), n)]
+    a = np.tile(anc, (m, 1))
+    mut = rng.random((m, n)) < sub
+    a[mut] = alpha[rng.integers(0, len(alpha), int(mut.sum()))]
+    if n_p > 0:
+        a[rng.random((m, n)) < n_p] = ord("N")
+    if gap_cells > 0:
+        for i, j in np.argwhere(rng.random((m, n)) < gap_cells / gap_run):
+            a[i, j:j + gap_run] = ord("-")
+            if shared > 0 and rng.random() < shared:
+                rows = rng.random(m) < 0.33
+                a[rows, j:j + gap_run] = ord("-")
+    for i in range(m):
+        if lead and rng.random() < 0.3:
+            a[i, :rng.integers(1, lead + 1)] = ord("-")
+        if lead and rng.random() < 0.3:
+            a[i, n - rng.integers(1, lead + 1):] = ord("-")
+    return a
+
+
+SPAN_CASES = [
+    dict(m=200, n=20000, gap_cells=0.02, gap_run=8),
+    dict(m=1000, n=4000, gap_cells=0.03, gap_run=12),
+    dict(m=60, n=5000, gap_cells=0.05, gap_run=30, lead=40),
+    dict(m=120, n=6000, gap_cells=0.01, gap_run=4, n_p=0.002),
+    dict(m=300, n=3000, gap_cells=0.02, gap_run=6, shared=0.5),
+    dict(m=40, n=3000, gap_cells=0.0, n_p=0.004),                       # rows without gaps, ignore characters only
+    dict(m=25, n=900, gap_cells=0.04, gap_run=5, sub=0.0),              # identical rows up to the gaps
+    dict(m=16, n=1200, gap_cells=0.03, gap_run=7, alphabet="AC", sub=0.002, lead=9),   # long repeats by chance: strays in the groups
+    dict(m=1, n=700, gap_cells=0.05, gap_run=3),
+    dict(m=3, n=64, gap_cells=0.2, gap_run=2, lead=5),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SPAN_CASES)))
+def test_span_scan_matches_oracle(engine, case):
+    """Star-phylogeny rows with gap runs -- the shape of a pangenome MSA -- through the group-level scan on column spans
+    (option span_scan = 1 takes it whatever the size; at scale the sample of the sort decides): f with and without
+    --ignore-chars, with the elastic tricks on and off, in 3 column shards; against the oracle (fbg.cpp:1579-1695,
+    esp. 1687-1691: the pointer that waits through a gap run)."""
+    import torch
+    kw = dict(SPAN_CASES[case])
+    m, n = kw.pop("m"), kw.pop("n")
+    msa = star_msa(np.random.default_rng(9000 + case), m, n, **kw)
+    with fbg_options(engine, {"span_scan": 1}):
+        for ignore in ("", "N"):
+            if ignore == "" and ord("N") in msa and case != 3:
+                continue
+            f_on, f_off = O.compute_f(msa, ignore=ignore), O.compute_f(msa, ignore=ignore, disable_tricks=True)
+            engine.msa_load_host(msa)
+            engine.index_build(ignorechars=ignore)
+            if ord("-") in msa or ignore:
+                assert engine.get_option("span_scan_used") == 1 and engine.get_option("index_kind") == 2, (case, ignore)
+            for tricks_off, ref in ((False, f_on), (True, f_off), (False, f_on)):
+                d = torch.zeros(n, dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                for r in range(3):
+                    engine.scan_f(n * r // 3, n * (r + 1) // 3, d.data_ptr(), tricks_off)
+                engine.sync()
+                got = d.cpu().numpy().astype(np.uint64)
+                bad = np.flatnonzero(got != ref)
+                assert bad.size == 0, (case, ignore, tricks_off, bad[:8].tolist(), got[bad[:8]].tolist(), ref[bad[:8]].tolist())
+
+
+def test_span_scan_through_a_group_and_at_scale():
+    """(a) the host-buffer group API on a star phylogeny with gaps: two members on one device -- the key-range partitions
+    decline such rows, the members scan column shards of the group-level index -- equals the oracle; (b) a text large
+    enough that the sample of the sort decides by itself (2^22 symbols and more) and the three-pass sample sort carries the
+    cells: equal to the record path's f."""
+    import founderblockgraphs_amd as F
+    rng = np.random.default_rng(515)
+    msa = star_msa(rng, 150, 9000, gap_cells=0.02, gap_run=8)
+    with F.Group([0, 0]) as grp:
+        for mb in range(2):
+            grp.member(mb).set_option("span_scan", 1)
+        assert np.array_equal(grp.elastic_f(msa), O.compute_f(msa))
+        assert grp.plan_used()[0] == "columns"
+    big = star_msa(rng, 400, 50000, gap_cells=0.02, gap_run=8)           # 2e7 symbols
+    with F.Engine(0) as e:
+        a = e.elastic_f(big)
+        assert e.get_option("span_scan_used") == 1
+        with e.options(span_scan=-1):
+            b = e.elastic_f(big)
+            assert e.get_option("span_scan_used") == 0
+        assert np.array_equal(a, b)
