@@ -65,6 +65,26 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """(logical CPUs, physical cores) of the box, from /proc/cpuinfo -- stated next to the cores the baseline may use."""
+    logical, phys = os.cpu_count() or 1, set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    return logical, (len(phys) or logical)
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota if there is one."""
     try:
@@ -107,8 +127,11 @@ def cpu_baseline(m, n_total, sample_cols):
     dt1, t1 = legs[1]
     T = max(legs)
     dtT, tT = legs[T]
+    logical, phys = physical_cores()
     return {
         "value": sample_cols / dt1, "unit": "columns/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+        "host": {"logical_cpus": logical, "physical_cores": phys, "usable_by_this_process": host_cores(),
+                 "note": "usable = affinity mask cut to the cgroup quota; the threaded leg runs on that many threads"},
         "sample": f"first {sample_cols} columns of the same {m}-row synthetic MSA, elastic, "
                   f"index {t1.get('index_s', 0):.2f}s + scan {t1.get('scan_s', 0):.2f}s + DP, {dt1:.2f}s total",
         "threaded": {"value": sample_cols / dtT, "unit": "columns/s", "cores": T,
@@ -134,6 +157,11 @@ def boundary_and_latency(F, torch, dev, m, n, d_msa):
             eng.minmax_dp(f)
             ms.append(1e3 * (time.perf_counter() - t0))
         out["boundary_ms"] = {"first_call": ms[0], "warm": min(ms[1:]), "host_memory": "pageable (library stages it through pinned buffers)"}
+        # SURVEY.md 8(d)'s T_seg: MSA resident in host RAM -> boundaries on the host (index build + scan + sweep, the copies
+        # over PCIe included), warm context; columns / s
+        out["t_seg"] = {"definition": "n / T_seg, T_seg = MSA in host RAM -> boundaries in host RAM through the C ABI "
+                                      "(fbg_elastic_f + fbg_minmax_dp), warm context",
+                        "unit": "columns/s", "pageable": n / (1e-3 * min(ms[1:]))}
         L = _lib.lib()
         p = L.fbg_host_alloc(m * n)
         if p:
@@ -146,6 +174,7 @@ def boundary_and_latency(F, torch, dev, m, n, d_msa):
                 eng.minmax_dp(f)
                 ms.append(1e3 * (time.perf_counter() - t0))
             out["boundary_ms"]["warm_pinned"] = min(ms)
+            out["t_seg"]["pinned"] = n / (1e-3 * min(ms))
             del pinned
             L.fbg_host_free(C.c_void_p(p))
         del host
@@ -191,7 +220,8 @@ def other_workloads(F, torch, dev):
                 if best is None or dt < best:
                     best, stages = dt, {k: round(v[0], 3) for k, v in eng.stage_ms().items()}
             res.append({"workload": name, "rows": m, "cols": n, "ms_per_step": 1e3 * best, "columns_per_s": n / best,
-                        "blocks": blocks, "stages_ms": stages})
+                        "blocks": blocks, "stages_ms": stages, "index_kind": eng.get_option("index_kind"),
+                        "span_scan_used": eng.get_option("span_scan_used"), "dp_kind": eng.get_option("dp_kind")})
 
     m, n = 1000, 200_000
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -204,16 +234,15 @@ def other_workloads(F, torch, dev):
         sub = torch.randint(0, 4, (i1 - i0, n), device="cuda", generator=g, dtype=torch.uint8)
         d[i0:i1] = lut[torch.where(mut, sub, anc.expand(i1 - i0, n)).long()]
     run("star phylogeny 1000 x 200000, p = 0.01 (similar rows), --elastic", m, n, d.reshape(-1))
-    # the same rows with 2 % of the cells in gap runs of 8 -- what a pangenome MSA looks like, and the input no fast path
-    # takes yet: similar rows tie everywhere (the scan in suffix order for gapped MSAs declines), so the per-position
-    # records and their doubling rounds run, and the extensions (a row's string behind a deletion occurs in the other rows,
-    # eight columns on) reach hundreds of columns, beyond the windows of the matrix-chain sweep
+    # the same rows with 2 % of the cells in gap runs of 8 -- what a pangenome MSA looks like: the group-level scan on column
+    # spans (span_scan.hip; round 2: per-position records with six doubling rounds, 158 ms); the extensions (a row's string
+    # behind a deletion occurs in the other rows, eight columns on) reach hundreds of columns: the 16-bit wide-window sweep
     for i0 in range(0, m, 50):
         i1 = min(m, i0 + 50)
         start = (torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.02 / 8).float().unsqueeze(1)
         gap = torch.nn.functional.max_pool1d(torch.nn.functional.pad(start, (7, 0)), 8, 1).squeeze(1) > 0
         d[i0:i1][gap] = ord("-")
-    run("star phylogeny 1000 x 200000, p = 0.01, 2 % gap cells in runs of 8 (similar rows WITH gaps: slow path), --elastic", m, n, d.reshape(-1))
+    run("star phylogeny 1000 x 200000, p = 0.01, 2 % gap cells in runs of 8 (similar rows WITH gaps), --elastic", m, n, d.reshape(-1))
     del d
     m, n = 256, 2_000_000
     d = torch.empty(m * n, dtype=torch.uint8, device="cuda")
@@ -248,7 +277,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1000)
     ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample-cols", type=int, default=40_000)
+    ap.add_argument("--cpu-sample-cols", type=int, default=100_000, help="column prefix the CPU port is timed on (SURVEY.md 8d: n' >= 10^5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip boundary_ms / latency_ms / other_workloads (N=1 extras outside the timed region)")
     ap.add_argument("--force-row-pairs", type=int, default=0, help="debug: use the row-group-pair plan with this many rows per pair text")
@@ -452,6 +481,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"synthetic {m} rows x {n} cols iid ACGT (seed 0x5EED0001), --elastic"
                                    f"{'' if world == 1 else f', {args.cols_per_gpu} columns per GPU, {mode_used}'}",
+                       "value_is": "columns of the whole job / wall time of the timed steps, MSA resident in HBM, boundaries left on the "
+                                   "device, the sweep of a step running beside the next step's index build; T_seg of SURVEY.md 8(d) "
+                                   "(host RAM to host RAM) is `t_seg`, one job alone is `latency_ms`",
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
             "roofline": {"bound": "hbm", "kernel": "k_rank_scan" if ranked else "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -472,7 +504,10 @@ def main():
         if world == 1 and not args.no_extras:
             if sweeper is not None:
                 sweeper.eng.release_scratch()
-            out.update(boundary_and_latency(F, torch, dev, m, n, whole_msa()))
+            extras = boundary_and_latency(F, torch, dev, m, n, whole_msa())
+            if "t_seg" in extras:
+                out["t_seg_columns_per_s"] = extras["t_seg"].get("pinned", extras["t_seg"]["pageable"])
+            out.update(extras)
             bufs.clear()
             eng.release_scratch()
             out["other_workloads"] = other_workloads(F, torch, dev)

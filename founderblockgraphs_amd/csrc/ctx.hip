@@ -214,14 +214,8 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (strcmp(key, "span_scan_used") == 0) { *value = (ctx->index_valid && ctx->granked && ctx->spanned) ? 1 : 0; return FBG_OK; }
     if (strcmp(key, "span_scan_work") == 0) { *value = (int64_t)ctx->sp_work; return FBG_OK; }
     if (strcmp(key, "span_groups") == 0) { *value = (int64_t)ctx->sp_G; return FBG_OK; }
-    if (strcmp(key, "span_odd_groups") == 0) { *value = (int64_t)ctx->sp_n_odd[0] + (int64_t)ctx->sp_n_odd[1]; return FBG_OK; }
+    if (strcmp(key, "span_odd_groups") == 0) { *value = (int64_t)ctx->sp_n_odd[0] + ctx->sp_n_odd[1] + ctx->sp_n_odd[2] + ctx->sp_n_odd[3]; return FBG_OK; }
     if (strcmp(key, "span_irregular") == 0) { *value = (int64_t)ctx->sp_n_irr; return FBG_OK; }
-    if (strncmp(key, "span_dbg", 8) == 0 && ctx->scalars.p) {
-        unsigned long long v = 0;
-        if (hipMemcpy(&v, ctx->scalars.as<unsigned long long>() + 208 + 16 + (key[8] - '0'), 8, hipMemcpyDeviceToHost) != hipSuccess) return FBG_ERR_HIP;
-        *value = (int64_t)v;
-        return FBG_OK;
-    }
     if (strcmp(key, "span_chain") == 0) { *value = (int64_t)ctx->sp_chain_n; return FBG_OK; }
     if (strcmp(key, "span_slow_groups") == 0) { *value = (int64_t)ctx->sp_slow_n; return FBG_OK; }
     if (strcmp(key, "index_kind") == 0) {      // read-only: which form the current index has

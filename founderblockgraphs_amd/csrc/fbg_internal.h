@@ -108,7 +108,7 @@ struct fbg_ctx {
     DevBuf sp_tiles, sp_gstart, sp_gcol, sp_gflags, sp_rstart, sp_rid, sp_gplo, sp_gphi, sp_gval, sp_odd, sp_irr, sp_chain, sp_slow, sp_mins;
     uint32_t sp_chain_n = 0, sp_slow_n = 0;
     uint64_t sp_G = 0, sp_R = 0, sp_n_irr = 0, sp_work = 0;
-    uint32_t sp_n_odd[2] = {0, 0}, sp_odd_cap = 0;
+    uint32_t sp_n_odd[4] = {0, 0, 0, 0}, sp_odd_cap = 0;
     const uint32_t *sort_payload = nullptr;   // while set: the pack kernels of the (key, value) sorts write payload[p] instead of p | flag
     int dp_kind = -1;            // which sweep produced the last fbg_dp_minmax result (fbg_get_option "dp_kind")
     bool cells_built = false;      // prow / igrow hold the current MSA (built on demand: only the record path reads them)

@@ -431,9 +431,9 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     // where every slot counts the smaller slots of its bin a bin of thousands is quadratic work -- MODE 1: the keys with a
     // rare symbol at the edge of a sub-bucket share one number.  Such a bin is split once more, on the 8 key bits from the
     // highest bit in which its smallest and largest key differ (monotone; even enough for a few hundred to a few thousand keys)
-    uint32_t rb0[ITEMS], rc[ITEMS];
+    uint32_t rb0[ITEMS], rc[ITEMS], radd[ITEMS];
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) { rb0[r] = loff[bn[r]]; rc[r] = cnt[bn[r]]; }
+    for (int r = 0; r < ITEMS; r++) { rb0[r] = loff[bn[r]]; rc[r] = cnt[bn[r]]; radd[r] = 0; }
     // ANY (similar rows: a bin may be one key held by hundreds of suffixes -- the rows' copies of one position -- plus a few
     // neighbours, and nobody asks for an order among equal keys): four keys picked from the bin are pivots; a slot whose key
     // is a pivot takes the place "slots below the pivot + its turn among the pivot's copies", both from counters, and only
@@ -442,7 +442,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     if (MODE == 1 && ANY) {
         __shared__ uint32_t nbig2, biglist2[CAP / PP_CROWD + 1];
         __shared__ uint64_t pv[4];
-        __shared__ uint32_t pless[4], peq[4];
+        __shared__ uint32_t pless[4], peq[4], nother;
         if (threadIdx.x == 0) nbig2 = 0;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < PP_FBINS; i += PP_THREADS)
@@ -452,29 +452,44 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         for (uint32_t e = 0; e < nb2; e++) {                            // uniform over the workgroup
             const uint32_t bbin = biglist2[e], b0 = loff[bbin], c = cnt[bbin];
             if (threadIdx.x < 4) { pv[threadIdx.x] = sw[b0 + (threadIdx.x * c) / 4]; pless[threadIdx.x] = 0; peq[threadIdx.x] = 0; }
+            if (threadIdx.x == 0) nother = 0;
             __syncthreads();
             const uint64_t p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3];
             const bool act[4] = {true, p1 != p0, p2 != p0 && p2 != p1, p3 != p0 && p3 != p1 && p3 != p2};
             const uint64_t pk[4] = {p0, p1, p2, p3};
+            __syncthreads();                                            // (the pivots are read: the bin's stretch of sw / sv is free)
             uint32_t turn[ITEMS];
             int which[ITEMS];
 #pragma unroll
             for (int r = 0; r < ITEMS; r++) {
                 const uint32_t j = threadIdx.x + r * PP_THREADS;
-                which[r] = -1; turn[r] = 0;
+                which[r] = -2; turn[r] = 0;
                 if (j < have && bn[r] == bbin) {
+                    which[r] = -1;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (!act[k]) continue;
                         if (w[r] < pk[k]) atomicAdd(&pless[k], 1u);
                         else if (w[r] == pk[k]) { which[r] = k; turn[r] = atomicAdd(&peq[k], 1u); }
                     }
+                    if (which[r] < 0) {                                 // no pivot's copy: into the compact list at the head of the bin's stretch
+                        const uint32_t oi = atomicAdd(&nother, 1u);
+                        sw[b0 + oi] = w[r]; sv[b0 + oi] = v[r];
+                    }
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < ITEMS; r++)
+            for (int r = 0; r < ITEMS; r++) {
                 if (which[r] >= 0) { rb0[r] = b0 + pless[which[r]] + turn[r]; rc[r] = 0; }
+                else if (which[r] == -1) {
+                    // the pivots' copies below this slot are counted here, the other slots below it by the loop over the list
+                    uint32_t below = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (act[k] && pk[k] < w[r]) below += peq[k];
+                    radd[r] = below; rc[r] = nother;
+                }
+            }
             __syncthreads();
         }
     }
@@ -548,7 +563,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
                 if (x == w[r]) less = sv[b0 + q] < v[r];           // equal keys are rare: the second array is seldom read
                 smaller += less ? 1u : 0u;
             }
-            rk[r] = b0 + smaller;
+            rk[r] = b0 + smaller + radd[r];
         }
     }
     __syncthreads();

@@ -72,7 +72,8 @@ struct SpArgs {
     uint64_t R;
     uint32_t *gplo, *gphi;           // odd groups: the columns at which every member is coloured (plo > phi: none)
     uint32_t *gval;                  // the other groups: g at their column
-    uint32_t *odd, *odd_big;         // lists of the odd groups (up to 1024 members / more)
+    uint32_t *odd;                   // lists of the odd groups, one per size class (up to 64 / 896 / 1024 members, more), odd_cap entries each
+    uint32_t odd_cap;
     uint2 *irr;                      // (slot, group) of the irregular slots
     uint64_t n_irr;
     uint32_t *fmax;                  // per column: largest fi
@@ -84,7 +85,6 @@ struct SpArgs {
     uint32_t *slow;                  // odd groups that need every pair compared (k_sp_odd_slow)
     uint32_t slow_cap;
     uint32_t *mins32;                // per 32 columns: the fewest symbols any row has there (nullptr: rows without gaps)
-    int dbg;
 };
 
 // An odd member q on the chain list.  OWN: at the columns [xlo, xhi] \ [plo, phi] of its span the same mates are coloured
@@ -393,25 +393,28 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_runs(SpA
 }
 
 // the odd groups, listed by size class (one reservation per wave: 5 * 10^5 single additions to one address took 5 ms)
-__global__ void k_sp_oddlist(SpArgs a, uint32_t cap)
+__global__ void k_sp_oddlist(SpArgs a)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     int cls = -1;
     if (g < a.G) {
         const uint32_t fl = a.gflags[g];
-        if ((fl & SPG_ODD) && !(fl & SPG_SEP)) cls = (a.gstart[g + 1] - a.gstart[g]) > 1024 ? 1 : 0;
+        if ((fl & SPG_ODD) && !(fl & SPG_SEP)) {
+            const uint32_t s = a.gstart[g + 1] - a.gstart[g];
+            cls = s <= 64 ? 0 : s <= 896 ? 1 : s <= 1024 ? 2 : 3;
+        }
     }
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
+    for (int c = 0; c < 4; c++) {
         const unsigned long long mask = __ballot(cls == c);
         if (!mask) continue;
         unsigned long long base = 0;
-        if (lane == (uint32_t)__ffsll(mask) - 1) base = atomicAdd(&a.counters[c], (unsigned long long)__popcll(mask));
+        if (lane == (uint32_t)__ffsll(mask) - 1) base = atomicAdd(&a.counters[8 + c], (unsigned long long)__popcll(mask));
         base = __shfl(base, __ffsll(mask) - 1, 64);
         if (cls == c) {
             const unsigned long long e = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1));
-            if (e < cap) (c ? a.odd_big : a.odd)[e] = (uint32_t)g; else a.counters[3] = 1;
+            if (e < a.odd_cap) a.odd[(size_t)c * a.odd_cap + e] = (uint32_t)g; else a.counters[3] = 1;
         }
     }
 }
@@ -480,7 +483,14 @@ __global__ void k_sp_values(SpArgs a)
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.G) return;
     const uint32_t fl = a.gflags[g];
-    if (fl & (SPG_ODD | SPG_SEP)) return;
+    if (fl & SPG_SEP) return;
+    if (fl & SPG_ODD) {
+        // an odd group whose pure interval is one column: g there, for its workgroup to pick up (the walk is a chain of
+        // dependent reads that one thread of a workgroup would make with the other 255 waiting)
+        const uint32_t x = a.gplo[g];
+        if (x == a.gphi[g]) { const uint64_t key = a.keys[a.gstart[g]]; a.gval[g] = 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1)); }
+        return;
+    }
     const uint32_t x = a.gcol[g];
     const uint64_t key = a.keys[a.gstart[g]];
     const uint32_t run = a.rid[g];
@@ -523,13 +533,41 @@ __device__ __forceinline__ uint64_t sp_load8(const SpArgs &a, uint64_t p)
     return p + 8 <= a.N + 56 ? fbg_load8(a.T, p) : 0ull;       // (the text is padded by 64 bytes; no match runs beyond the sentinel)
 }
 
+// The column most members of a group sit in (any choice is correct: it only says who counts as "odd"; a poor one makes
+// nearly every member odd -- three probes did, in a few dozen of 170 000 groups, and each of those took 100 ms): five probes,
+// every one counted over all members.  votes: 8 words of LDS; all threads call, all get the answer.
+__device__ __forceinline__ uint32_t sp_major(const SpArgs &a, const uint32_t *sv, uint32_t s, uint32_t *votes)
+{
+    uint32_t cand[5], row;
+    const uint32_t at[5] = {0u, s / 4, s / 2, (3 * s) / 4, s - 1};
+#pragma unroll
+    for (int k = 0; k < 5; k++) sp_decode(a, sv[at[k]], row, cand[k]);
+    __syncthreads();
+    if (threadIdx.x < 5) votes[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mine[5] = {0, 0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < s; i += blockDim.x) {
+        uint32_t col;
+        sp_decode(a, sv[i], row, col);
+#pragma unroll
+        for (int k = 0; k < 5; k++) mine[k] += col == cand[k] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) if (mine[k]) atomicAdd(&votes[k], mine[k]);
+    __syncthreads();
+    uint32_t best = 0;
+#pragma unroll
+    for (int k = 1; k < 5; k++) if (votes[k] > votes[best]) best = k;
+    return cand[best];
+}
+
 #define SP_CHAIN_SCAN 16u             // members of a group looked at per step of the chain
 template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
 {
     __shared__ uint32_t sv[CAP];
     __shared__ uint16_t oidx[SP_MAX_ODD];
     __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], opos[SP_MAX_ODD];
-    __shared__ uint32_t n_odd, s_gv, s_slow;
+    __shared__ uint32_t n_odd, s_gv, s_slow, votes[8];
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
         const uint32_t g = list[e];
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
@@ -538,12 +576,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd(SpArgs
         if (threadIdx.x == 0) { n_odd = 0; s_slow = 0; }
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) sv[i] = a.vals[s0 + i];
         __syncthreads();
-        uint32_t major;
-        {
-            uint32_t r0, c0, r1, c1, r2, c2;
-            sp_decode(a, sv[0], r0, c0); sp_decode(a, sv[s / 2], r1, c1); sp_decode(a, sv[s - 1], r2, c2);
-            major = (c0 == c1 || c0 == c2) ? c0 : c1;
-        }
+        const uint32_t major = sp_major(a, sv, s, votes);
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
             uint32_t row, col;
             sp_decode(a, sv[i], row, col);
@@ -720,7 +753,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
     __shared__ uint16_t omap[CAP];                             // member -> its place in the odd list (0xffff: a member of the majority)
     __shared__ uint16_t oidx[SP_MAX_ODD];
     __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], Lq[SP_MAX_ODD];
-    __shared__ uint32_t n_odd, s_mn, s_any, s_gmax, s_ign;
+    __shared__ uint32_t n_odd, s_mn, s_any, s_gmax, s_ign, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;            // mate of the wave's four, place in its 128-byte window
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
@@ -731,12 +764,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
         if (threadIdx.x == 0) n_odd = 0;
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
         __syncthreads();
-        uint32_t major;
-        {
-            uint32_t r0, c0, r1, c1, r2, c2;
-            sp_decode(a, sv[0], r0, c0); sp_decode(a, sv[s / 2], r1, c1); sp_decode(a, sv[s - 1], r2, c2);
-            major = (c0 == c1 || c0 == c2) ? c0 : c1;
-        }
+        const uint32_t major = sp_major(a, sv, s, votes);
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
             uint32_t row, col;
             sp_decode(a, sv[i], row, col);
@@ -863,39 +891,41 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
 
 // ---- the odd groups of up to 1024 members: everything in one workgroup, the mates' texts in registers ---------------
 // What made the kernel above slow is not the bytes but the waiting: every odd member walks its mates again, two or three
-// dependent rounds of scattered loads per 64 mates.  Here the 128 bytes behind the key of EVERY member are loaded once, in
-// one batch (a lane holds 8 bytes of each of up to 64 mates: 16 lanes per mate, four mates per wave and row), and the odd
-// members are then compared with them from registers; only the pairs that match beyond those 128 bytes (7 % when the rows
-// differ in 1 % of their symbols) go back to memory, gathered in a list and walked window by window.
-#define SPP_ROWS 64                  // 1024 members / (4 waves x 4 mates per wave and row)
-#define SPP_QW 64                    // odd members whose own 128 bytes wait in LDS
-__global__ __launch_bounds__(SP_THREADS) void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
+// dependent rounds of scattered loads per 64 mates, one odd member after the other.  Here the 128 bytes behind the key of
+// EVERY member are loaded once, in one batch (a lane holds 16 bytes of each of up to 32 mates: 8 lanes per mate, eight
+// mates per wave and row), and the odd members -- up to SPP_MAXO of them; a group with more goes to the slow list -- are
+// compared with them from registers (A).  The pairs that match beyond those 128 bytes (7 % when the rows differ in 1 % of
+// their symbols) are listed and walked together, 32 pairs' loads in flight (B).  Then every (odd member, column) of the
+// spans gets a thread (C).
+#define SPP_MAXO 32
+#define SPP_TAILS 1024
+// SPP_ROWS: rows of 32 members (4 waves x 8 mates per wave and row, 16 bytes of a mate per lane) the registers hold: 2 (the
+// small groups, more than half of the odd ones: few registers, many workgroups per compute unit), 28 (896 members) or 32
+// (up to 1024); an instance takes the groups of more than MINS members that it has room for
+template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
+void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
 {
-    constexpr int CAP = 1024;
+    constexpr int CAP = SPP_ROWS * 32;
     __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
     __shared__ uint16_t omap[CAP];
-    __shared__ uint16_t oidx[SP_MAX_ODD];
-    __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], Lq[SP_MAX_ODD];
-    __shared__ uint64_t qwin[SPP_QW][16];
-    __shared__ uint16_t tails[SP_THREADS / 64][64];
-    __shared__ uint32_t ntail[SP_THREADS / 64];
-    __shared__ uint32_t n_odd, s_gv, s_mn, s_any, s_gmax, s_ign, s_need;
+    __shared__ uint16_t oidx[SPP_MAXO];
+    __shared__ uint32_t olo[SPP_MAXO], ohi[SPP_MAXO], omn[SPP_MAXO], oany[SPP_MAXO], ogmax[SPP_MAXO], oign[SPP_MAXO];
+    __shared__ uint32_t LQ[SPP_MAXO][SPP_MAXO];
+    __shared__ uint64_t qwin[SPP_MAXO][16];
+    __shared__ uint32_t tl[SPP_TAILS];
+    __shared__ uint32_t n_odd, ntl, s_gv, s_need, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t sub = lane >> 4, sl = lane & 15;
+    const uint32_t sub = lane >> 4, sl = lane & 15;       // B: 16 lanes per pair, 8 bytes each
+    const uint32_t sub8 = lane >> 3, sl8 = lane & 7;      // A: 8 lanes per mate, 16 bytes each
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
         const uint32_t g = list[e];
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
         __syncthreads();
-        if (s > CAP) continue;
-        if (threadIdx.x == 0) { n_odd = 0; s_need = 0; }
+        if (s > CAP || s <= MINS) continue;                    // (another instance's)
+        if (threadIdx.x == 0) { n_odd = 0; s_need = 0; ntl = 0; }
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
         __syncthreads();
-        uint32_t major;
-        {
-            uint32_t r0, c0, r1, c1, r2, c2;
-            sp_decode(a, sv[0], r0, c0); sp_decode(a, sv[s / 2], r1, c1); sp_decode(a, sv[s - 1], r2, c2);
-            major = (c0 == c1 || c0 == c2) ? c0 : c1;
-        }
+        const uint32_t major = sp_major(a, sv, s, votes);
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
             uint32_t row, col;
             sp_decode(a, sv[i], row, col);
@@ -903,7 +933,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_pairs(SpArgs a, const uin
             sp[i] = p;
             if ((sv[i] & SP_W) || col != major) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
-                if (o < SP_MAX_ODD) {
+                if (o < SPP_MAXO) {
                     oidx[o] = (uint16_t)i;
                     omap[i] = (uint16_t)o;
                     uint32_t lo = col, hi = col;
@@ -914,14 +944,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_pairs(SpArgs a, const uin
         }
         __syncthreads();
         const uint32_t no = n_odd;
-        if (no > SP_MAX_ODD) { if (threadIdx.x == 0) a.counters[3] = 1; continue; }
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
         const uint64_t key = a.keys[s0];
         const bool has_narrow = no < s;
         // -- the pure interval (usually one column, the majority's): every member is coloured, keys decide
-        for (uint32_t x = plo; x <= phi && plo <= phi && !(a.dbg & 1); x++) {
+        for (uint32_t x = plo; x <= phi && plo <= phi; x++) {
             __syncthreads();
-            if (threadIdx.x == 0) s_gv = 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1));
+            if (threadIdx.x == 0) s_gv = plo == phi ? a.gval[g] : 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1));
             __syncthreads();
             const uint32_t gv = s_gv;
             const uint32_t kign = sp_key_first_ignore(a, key, gv);
@@ -932,112 +961,139 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_pairs(SpArgs a, const uin
                 sp_update(a, x, fi);
             }
         }
-        // does any odd member have a column of its own, or is one a partner of the majority's members?
-        for (uint32_t o = threadIdx.x; o < no; o += SP_THREADS) {
-            const uint32_t lo = olo[o], hi = ohi[o];
-            const bool at_major = lo <= major && major <= hi;
-            const bool own = lo <= hi && (plo > phi || lo < plo || hi > phi);
-            if (own || (!at_major && has_narrow)) s_need = 1;
+        if (no > SPP_MAXO) {                                   // many odd members (a deletion common to many rows): k_sp_odd_slow
+            if (threadIdx.x == 0) {
+                const unsigned long long at = atomicAdd(&a.counters[7], 1ull);
+                if (at < a.slow_cap) a.slow[at] = g; else a.counters[3] = 1;
+            }
+            continue;
         }
+        auto own_of = [&](uint32_t o) { return olo[o] <= ohi[o] && (plo > phi || olo[o] < plo || ohi[o] > phi); };   // has columns outside the pure interval
+        auto at_major_of = [&](uint32_t o) { return olo[o] <= major && major <= ohi[o]; };      // coloured at the majority column: no partner for its members there
+        if (threadIdx.x < no) {
+            const uint32_t o = threadIdx.x;
+            omn[o] = 0; oany[o] = 0; ogmax[o] = 0; oign[o] = SP_NONE;
+            if (own_of(o) || (!at_major_of(o) && has_narrow)) s_need = 1;
+        }
+        for (uint32_t i = threadIdx.x; i < no * SPP_MAXO; i += SP_THREADS) LQ[i / SPP_MAXO][i % SPP_MAXO] = 0;
         __syncthreads();
-        if (!s_need || (a.dbg & 2)) continue;
-        // -- the 128 bytes behind the key of every member -> registers; of the first odd members -> LDS
-        uint64_t mt[SPP_ROWS];
+        if (!s_need) continue;
+        // -- the 128 bytes behind the key of every member -> registers; of the odd members -> LDS
+        uint64_t mlo[SPP_ROWS], mhi[SPP_ROWS];
+        uint32_t valid = 0, narrow = 0;                        // per row: the lane's mate exists / is a member of the majority
 #pragma unroll
         for (int r = 0; r < SPP_ROWS; r++) {
-            const uint32_t u = (uint32_t)r * 16 + wv * 4 + sub;
-            mt[r] = ((uint32_t)r * 16 < s && u < s) ? sp_load8(a, (uint64_t)sp[u] + a.K + 8 * sl) : 0ull;
+            const uint32_t u = (uint32_t)r * 32 + wv * 8 + sub8;
+            const bool ex = (uint32_t)r * 32 < s && u < s;
+            mlo[r] = ex ? sp_load8(a, (uint64_t)sp[u] + a.K + 16 * sl8) : 0ull;
+            mhi[r] = ex ? sp_load8(a, (uint64_t)sp[u] + a.K + 16 * sl8 + 8) : 0ull;
+            if (ex) { valid |= 1u << r; if (omap[u] == 0xffffu) narrow |= 1u << r; }
         }
-        for (uint32_t o = wv * 4 + sub; o < no && o < SPP_QW; o += SP_THREADS / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
-        // -- the other columns of the odd members, one odd member after the other
-        for (uint32_t o = 0; o < no && !(a.dbg & 4); o++) {
-            const uint32_t q = oidx[o], pq = sp[q], lo = olo[o], hi = ohi[o];
-            const bool at_major = lo <= major && major <= hi;  // coloured at the majority column: no partner for its members there
-            const bool own = lo <= hi && (plo > phi || lo < plo || hi > phi);   // has columns outside the pure interval
-            if (!own && (at_major || !has_narrow)) continue;   // (uniform over the workgroup)
-            __syncthreads();
-            if (threadIdx.x == 0) { s_mn = 0; s_any = 0; s_gmax = 0; s_ign = SP_NONE; }
-            if (lane == 0) ntail[wv] = 0;
-            __syncthreads();
-            const uint64_t qtext = o < SPP_QW ? qwin[o][sl] : sp_load8(a, (uint64_t)pq + a.K + 8 * sl);
-            auto note = [&](uint32_t u, uint32_t Lbeyond) {    // the match of q with member u beyond the key
-                const uint32_t L = fbg_clamp_lcp(Lbeyond + (uint32_t)a.K);
-                const uint32_t ou = omap[u];
-                if (ou == 0xffffu) {
-                    atomicMax(&s_mn, L);
-                    s_any = 1;
-                    if (!at_major) atomicMax(&nbest[u], L);
-                } else Lq[ou] = L;
-            };
+        for (uint32_t o = wv * 4 + sub; o < no; o += SP_THREADS / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
+        __syncthreads();
+        auto note = [&](uint32_t o, uint32_t u, uint32_t Lbeyond) {   // the match of odd member o with member u beyond the key
+            const uint32_t L = fbg_clamp_lcp(Lbeyond + (uint32_t)a.K);
+            const uint32_t ou = omap[u];
+            if (ou == 0xffffu) {
+                atomicMax(&omn[o], L);
+                oany[o] = 1;
+                if (!at_major_of(o)) atomicMax(&nbest[u], L);
+            } else LQ[o][ou] = L;
+        };
+        // -- A: every odd member against the registers
+        for (uint32_t o = 0; o < no; o++) {
+            const bool own = own_of(o);
+            if (!own && (at_major_of(o) || !has_narrow)) continue;   // (uniform over the workgroup)
+            const uint32_t q = oidx[o];
+            const uint64_t qlo = qwin[o][2 * sl8], qhi = qwin[o][2 * sl8 + 1];
+            const uint32_t rows_live = own ? valid : (valid & narrow);
 #pragma unroll
             for (int r = 0; r < SPP_ROWS; r++) {
-                if ((uint32_t)r * 16 >= s) break;              // (uniform)
-                const uint32_t u = (uint32_t)r * 16 + wv * 4 + sub;
-                const bool live = u < s && u != q && (own || omap[u] == 0xffffu);
-                const uint64_t diff = live ? mt[r] ^ qtext : 1ull;
-                const uint32_t seg = (uint32_t)(__ballot(diff != 0) >> (16 * sub)) & 0xffffu;
-                const uint32_t f = seg ? (uint32_t)__ffs(seg) - 1 : 0u;
-                const uint64_t dfirst = __shfl(diff, (int)(16 * sub + f), 64);
-                if (live && sl == 0) {
-                    if (seg) note(u, 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8);
-                    else { const uint32_t at = atomicAdd(&ntail[wv], 1u); if (at < 64) tails[wv][at] = (uint16_t)u; else note(u, fbg_extend_match(a.T, (uint64_t)pq + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN); }
+                if ((uint32_t)r * 32 >= s) break;              // (uniform)
+                const uint32_t u = (uint32_t)r * 32 + wv * 8 + sub8;
+                const bool live = ((rows_live >> r) & 1u) && u != q;
+                const uint64_t dlo = mlo[r] ^ qlo, dhi = mhi[r] ^ qhi;
+                const uint32_t seg = (uint32_t)(__ballot(!live || (dlo | dhi) != 0) >> (8 * sub8)) & 0xffu;
+                if (live && seg && sl8 == (uint32_t)__ffs(seg) - 1)       // the lane that holds the first difference
+                    note(o, u, 16 * sl8 + (dlo ? ((uint32_t)__ffsll((unsigned long long)dlo) - 1) / 8 : 8 + ((uint32_t)__ffsll((unsigned long long)dhi) - 1) / 8));
+                if (live && !seg && sl8 == 0) {
+                    const uint32_t at = atomicAdd(&ntl, 1u);
+                    if (at < SPP_TAILS) tl[at] = o << 16 | u;
+                    else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[q] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
                 }
             }
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
-            // the pairs that match beyond the first window: four at a time, window after window
-            const uint32_t nt = min(ntail[wv], 64u);
-            for (uint32_t t0 = 0; t0 < nt; t0 += 4) {
-                const bool live = t0 + sub < nt;
-                const uint32_t u = live ? tails[wv][t0 + sub] : 0u;
-                bool pend = live;
-                uint32_t Lb = 0;
-                for (uint32_t off = SP_WIN;; off += SP_WIN) {
-                    const uint64_t qx = sp_load8(a, (uint64_t)pq + a.K + off + 8 * sl);
-                    const uint64_t x = pend ? sp_load8(a, (uint64_t)sp[u] + a.K + off + 8 * sl) : qx;
-                    const uint64_t diff = x ^ qx;
+        }
+        __syncthreads();
+        // -- B: the pairs that match beyond the first window, 64 at a time, window after window
+        const uint32_t nt = min(ntl, (uint32_t)SPP_TAILS);
+        for (uint32_t t0 = 0; t0 < nt; t0 += 32) {
+            uint32_t po[2], pu[2], Lb[2];
+            bool live4[2], pend[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const uint32_t idx = t0 + (uint32_t)rr * 16 + wv * 4 + sub;
+                live4[rr] = idx < nt;
+                const uint32_t ent = live4[rr] ? tl[idx] : 0u;
+                po[rr] = ent >> 16; pu[rr] = ent & 0xffffu; Lb[rr] = 0; pend[rr] = live4[rr];
+            }
+            for (uint32_t off = SP_WIN;; off += SP_WIN) {
+                uint64_t qx[2], x[2];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    qx[rr] = pend[rr] ? sp_load8(a, (uint64_t)sp[oidx[po[rr]]] + a.K + off + 8 * sl) : 0ull;
+                    x[rr] = pend[rr] ? sp_load8(a, (uint64_t)sp[pu[rr]] + a.K + off + 8 * sl) : 0ull;
+                }
+                bool more = false;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const uint64_t diff = x[rr] ^ qx[rr];
                     const uint32_t seg = (uint32_t)(__ballot(diff != 0) >> (16 * sub)) & 0xffffu;
                     const uint32_t f = seg ? (uint32_t)__ffs(seg) - 1 : 0u;
                     const uint64_t dfirst = __shfl(diff, (int)(16 * sub + f), 64);
-                    if (pend && seg) { Lb = off + 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8; pend = false; }
-                    if (!__ballot(pend)) break;                // (two suffixes differ at the sentinel at the latest)
+                    if (pend[rr] && seg) { Lb[rr] = off + 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8; pend[rr] = false; }
+                    more = more || pend[rr];
                 }
-                if (live && sl == 0) note(u, Lb);
+                if (!__ballot(more)) break;                    // (two suffixes differ at the sentinel at the latest)
             }
-            __syncthreads();
-            if (!own) continue;
-            const uint32_t mn = s_mn;
-            const bool any_narrow = s_any != 0;
-            // g at column x of the span: the majority members count everywhere but at their own column
-            auto g_at = [&](uint32_t x) -> uint32_t {
-                uint32_t best = (any_narrow && x != major) ? mn : 0u;
-                for (uint32_t o2 = 0; o2 < no; o2++)
-                    if (o2 != o && !(olo[o2] <= x && x <= ohi[o2])) best = max(best, Lq[o2]);
-                return best + 1;                                                         // 1656 (a partner exists: x is outside the pure interval)
-            };
-            uint32_t gm = 0;
-            for (uint64_t x = (uint64_t)lo + threadIdx.x; x <= hi; x += SP_THREADS)
-                if (!(plo <= x && x <= phi)) gm = max(gm, g_at((uint32_t)x));
-            if (gm) atomicMax(&s_gmax, gm);
-            __syncthreads();
-            uint32_t qrow, qcol;
-            sp_decode(a, sv[q], qrow, qcol);
-            if (a.is_ignore && wv == 0) {                      // the row's first ignore character among the symbols any of those extensions reaches
-                const uint32_t reach = sp_reach(a, pq, qrow, s_gmax);
-                uint32_t ign = SP_NONE;
-                for (uint32_t k0 = 0; k0 < reach && ign == SP_NONE; k0 += 64) {
-                    const uint32_t k = k0 + lane;
-                    const unsigned long long hit = __ballot(k < reach && a.is_ignore[a.T[(uint64_t)pq + k]]);
-                    if (hit) ign = k0 + (uint32_t)__ffsll((unsigned long long)hit) - 1;
-                }
-                if (lane == 0) s_ign = ign;
-            }
-            __syncthreads();
-            const uint32_t ign = s_ign;
-            for (uint64_t x = (uint64_t)lo + threadIdx.x; x <= hi; x += SP_THREADS)
-                if (!(plo <= x && x <= phi)) sp_update(a, (uint32_t)x, sp_extent(a, pq, qrow, g_at((uint32_t)x), ign));
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+                if (live4[rr] && sl == 0) note(po[rr], pu[rr], Lb[rr]);
         }
         __syncthreads();
+        // -- C: the columns of the odd members' spans outside the pure interval, a thread per (odd member, column)
+        // g at column x: the majority members count everywhere but at their own column
+        auto g_at = [&](uint32_t o, uint32_t x) -> uint32_t {
+            uint32_t best = (oany[o] && x != major) ? omn[o] : 0u;
+            for (uint32_t o2 = 0; o2 < no; o2++)
+                if (o2 != o && !(olo[o2] <= x && x <= ohi[o2])) best = max(best, LQ[o][o2]);
+            return best + 1;                                                             // 1656 (a partner exists: x is outside the pure interval)
+        };
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t idx = threadIdx.x; idx < no * 64; idx += SP_THREADS) {
+                const uint32_t o = idx >> 6;
+                if (!own_of(o)) continue;
+                uint32_t qrow, qcol;
+                sp_decode(a, sv[oidx[o]], qrow, qcol);
+                uint32_t gm = 0;
+                for (uint64_t x = (uint64_t)olo[o] + (idx & 63); x <= ohi[o]; x += 64) {
+                    if (plo <= x && x <= phi) continue;
+                    const uint32_t gx = g_at(o, (uint32_t)x);
+                    if (pass == 0) gm = max(gm, gx);
+                    else sp_update(a, (uint32_t)x, sp_extent(a, sp[oidx[o]], qrow, gx, oign[o]));
+                }
+                if (pass == 0 && gm) atomicMax(&ogmax[o], gm);
+            }
+            __syncthreads();
+            if (pass == 0 && a.is_ignore) {                    // the row's first ignore character among the symbols any of those extensions reaches
+                if (threadIdx.x < no && own_of(threadIdx.x)) {
+                    const uint32_t o = threadIdx.x, pq = sp[oidx[o]];
+                    uint32_t qrow, qcol;
+                    sp_decode(a, sv[oidx[o]], qrow, qcol);
+                    oign[o] = sp_first_ignore(a, pq, sp_reach(a, pq, qrow, ogmax[o]));
+                }
+                __syncthreads();
+            }
+        }
         // -- the members of the majority column where some odd member is not coloured there
         if (has_narrow && !(plo <= major && major <= phi)) {
             for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
@@ -1097,7 +1153,7 @@ static void sp_args(fbg_ctx *ctx, SpArgs &a, int disable_tricks)
     a.G = ctx->sp_G;
     a.rtile = nullptr; a.rstart = ctx->sp_rstart.as<uint32_t>(); a.rid = ctx->sp_rid.as<uint32_t>(); a.R = ctx->sp_R;
     a.gplo = ctx->sp_gplo.as<uint32_t>(); a.gphi = ctx->sp_gphi.as<uint32_t>(); a.gval = ctx->sp_gval.as<uint32_t>();
-    a.odd = ctx->sp_odd.as<uint32_t>(); a.odd_big = a.odd + ctx->sp_odd_cap;
+    a.odd = ctx->sp_odd.as<uint32_t>(); a.odd_cap = ctx->sp_odd_cap;
     a.irr = ctx->sp_irr.as<uint2>(); a.n_irr = ctx->sp_n_irr;
     a.fmax = ctx->gmax.as<uint32_t>();
     a.counters = ctx->scalars.as<unsigned long long>() + 208;     // (gapped_rank.hip: 128 .. 202)
@@ -1105,7 +1161,6 @@ static void sp_args(fbg_ctx *ctx, SpArgs &a, int disable_tricks)
     a.chain = ctx->sp_chain.as<SpChain>(); a.chain_cap = (uint32_t)(ctx->sp_chain.cap / sizeof(SpChain));
     a.slow = ctx->sp_slow.as<uint32_t>(); a.slow_cap = (uint32_t)(ctx->sp_slow.cap / 4);
     a.mins32 = ctx->gapfree ? nullptr : ctx->sp_mins.as<uint32_t>();
-    a.dbg = ctx->opt.span_scan >= 16 ? (int)ctx->opt.span_scan : 0;
 }
 
 // May this MSA go through the group-level scan on spans at all?  (the caller has decided that its rows are similar)
@@ -1152,9 +1207,12 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     sp_args(ctx, a, disable_tricks);
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 2, 0, 6 * sizeof(unsigned long long), st));
-    const uint32_t n_small = ctx->sp_n_odd[0], n_big = ctx->sp_n_odd[1];
-    if (n_small) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(n_small, 4)), dim3(256), 0, st, a, (const uint32_t *)a.odd, n_small, 1024u);
-    if (n_big) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(n_big, 4)), dim3(256), 0, st, a, (const uint32_t *)a.odd_big, n_big, 8192u);
+    const uint32_t *lists[4];
+    uint32_t cnts[4];
+    for (int c = 0; c < 4; c++) { lists[c] = a.odd + (size_t)c * a.odd_cap; cnts[c] = ctx->sp_n_odd[c]; }
+    const uint32_t n_small = cnts[0] + cnts[1] + cnts[2], n_big = cnts[3];
+    for (int c = 0; c < 4; c++)
+        if (cnts[c]) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(cnts[c], 4)), dim3(256), 0, st, a, lists[c], cnts[c], c == 3 ? 8192u : 1024u);
     unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1171,11 +1229,27 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     if (a.n_irr) hipLaunchKernelGGL(k_sp_irr, dim3(fbg_blocks(a.n_irr, 256)), dim3(256), 0, st, a);
     // the odd groups of up to 1024 members: one kernel, everything; the larger ones (more than 1024 rows): pure interval and
     // lists (k_sp_odd), the chains (k_sp_chain), every pair where that does not do (k_sp_odd_slow)
-    if (n_small) hipLaunchKernelGGL(k_sp_odd_pairs, dim3(std::min<uint32_t>(n_small, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.odd, n_small);
+    // (workgroups that stay and take group after group: a workgroup per group spent more time being launched than working)
+    if (cnts[0]) hipLaunchKernelGGL((k_sp_odd_pairs<2, 0>), dim3(std::min<uint32_t>(cnts[0], 8192u)), dim3(SP_THREADS), 0, st, a, lists[0], cnts[0]);
+    if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 2048u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1]);
+    if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 2048u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2]);
     *launches += 3;
     ctx->sp_chain_n = 0; ctx->sp_slow_n = 0;
+    if (n_small) {
+        // its groups with more odd members than it takes: every pair the slow way
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (h[1] != 0) return FBG_OK;
+        const uint32_t n_slow = (uint32_t)h[5];
+        ctx->sp_slow_n = n_slow;
+        if (n_slow) {
+            hipLaunchKernelGGL((k_sp_odd_slow<1024>), dim3(std::min<uint32_t>(n_slow, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow);
+            *launches += 1;
+        }
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 7, 0, 8, st));
+    }
     if (n_big) {
-        hipLaunchKernelGGL((k_sp_odd<8192>), dim3(std::min<uint32_t>(n_big, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.odd_big, n_big);
+        hipLaunchKernelGGL((k_sp_odd<8192>), dim3(std::min<uint32_t>(n_big, 1u << 16)), dim3(SP_THREADS), 0, st, a, lists[3], n_big);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         if (h[1] != 0) return FBG_OK;
@@ -1239,13 +1313,18 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
     ctx->rk_keys = keys; ctx->sa_ptr = vals;
     ctx->rk_layout = FBG_SLOTS_PAIRS; ctx->rk_pb = 0; ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
     ctx->grs_ign_lo = (uint32_t)by_code; ctx->grs_ign_hi = (uint32_t)(by_code >> 32);
-    ctx->sp_G = 0; ctx->sp_R = 0; ctx->sp_n_irr = 0; ctx->sp_n_odd[0] = ctx->sp_n_odd[1] = 0; ctx->sp_odd_cap = 0;
+    ctx->sp_G = 0; ctx->sp_R = 0; ctx->sp_n_irr = 0; ctx->sp_n_odd[0] = ctx->sp_n_odd[1] = ctx->sp_n_odd[2] = ctx->sp_n_odd[3] = 0; ctx->sp_odd_cap = 0;
     SpArgs a;
     if (good && ctx->opt.span_scan == 2) {
         // debugging aid: the sorted values are a permutation of the cells (sum and xor agree), the keys ascend
         sp_args(ctx, a, 0);
         FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 16, 0, 8 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_sp_check, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keys, (const uint32_t *)vals, ctx->sp_cells.as<uint32_t>(), N, a.counters + 16);
+        unsigned long long c[5];
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(c, a.counters + 16, sizeof(c), hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (c[0] != c[1] || c[2] != c[3] || c[4] != 0)
+            return fbg_fail(ctx, FBG_ERR_HIP, "span scan: the sorted slots are not the cells in key order (%llu keys out of order)", c[4]);
     }
     if (good) {
         // groups
@@ -1293,17 +1372,16 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
         // the odd groups, listed
         const uint32_t cap = (uint32_t)std::min<uint64_t>(G, 1u << 24);
         ctx->sp_odd_cap = cap;
-        FBG_TRY(fbg_reserve(ctx, ctx->sp_odd, (size_t)cap * 8));
+        FBG_TRY(fbg_reserve(ctx, ctx->sp_odd, (size_t)cap * 16));
         sp_args(ctx, a, 0);
         FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 16 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sp_oddlist, dim3(fbg_blocks(G, 256)), dim3(256), 0, st, a, cap);
-        unsigned long long h[4];
+        hipLaunchKernelGGL(k_sp_oddlist, dim3(fbg_blocks(G, 256)), dim3(256), 0, st, a);
+        unsigned long long h[12];
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         launches += 2;
         if (h[3] != 0) good = false;
-        ctx->sp_n_odd[0] = (uint32_t)std::min<unsigned long long>(h[0], cap);
-        ctx->sp_n_odd[1] = (uint32_t)std::min<unsigned long long>(h[1], cap);
+        for (int c = 0; c < 4; c++) ctx->sp_n_odd[c] = (uint32_t)std::min<unsigned long long>(h[8 + c], cap);
     }
     int ok = 0;
     if (good) FBG_TRY(sp_scan(ctx, 0, &ok, &launches));

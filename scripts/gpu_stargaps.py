@@ -43,6 +43,6 @@ with F.Engine(0) as eng:
         eng.sync()
         dt = time.perf_counter() - t0
         print(json.dumps({"ms": round(1e3 * dt, 2), "blocks": blocks, "index_kind": eng.get_option("index_kind"),
-                          "span": eng.get_option("span_scan_used"), "work": eng.get_option("span_scan_work"), "G": eng.get_option("span_groups"), "odd": eng.get_option("span_odd_groups"), "irr": eng.get_option("span_irregular"), "chain": eng.get_option("span_chain"), "slow": eng.get_option("span_slow_groups"), "dbg": [eng.get_option("span_dbg%d" % i) for i in range(8)], "dp_kind": eng.get_option("dp_kind"),
+                          "span": eng.get_option("span_scan_used"), "work": eng.get_option("span_scan_work"), "G": eng.get_option("span_groups"), "odd": eng.get_option("span_odd_groups"), "irr": eng.get_option("span_irregular"), "chain": eng.get_option("span_chain"), "slow": eng.get_option("span_slow_groups"), "dp_kind": eng.get_option("dp_kind"),
                           "stages": {k: round(v[0], 2) for k, v in eng.stage_ms().items()},
                           "f_sum": int(d_f.sum())}), flush=True)

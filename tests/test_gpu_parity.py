@@ -1276,6 +1276,8 @@ SPAN_CASES = [
     dict(m=16, n=1200, gap_cells=0.03, gap_run=7, alphabet="AC", sub=0.002, lead=9),   # long repeats by chance: strays in the groups
     dict(m=1, n=700, gap_cells=0.05, gap_run=3),
     dict(m=3, n=64, gap_cells=0.2, gap_run=2, lead=5),
+    dict(m=1100, n=1500, gap_cells=0.02, gap_run=6, shared=0.1),         # groups of more than 1024 members: the chains, the slow list
+    dict(m=900, n=2500, gap_cells=0.02, gap_run=8, sub=0.003),           # groups of 897 .. 1024 members
 ]
 
 
