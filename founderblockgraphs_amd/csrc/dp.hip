@@ -610,12 +610,12 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
     if (lane == 0) { result[0] = err ? 0 : cnt; result[1] = err ? 1 : 0; }
 }
 
-// ---- wide windows: the matrix chain for block lengths of up to four thousand columns -------------------------------
+// ---- wide windows: the matrix chain for block lengths of up to sixteen thousand columns ----------------------------
 //
 // Rows that resemble each other, with gaps: behind a deletion a row's string occurs in the other rows some columns on, the
 // minimal extensions reach hundreds of columns and so do the blocks -- beyond the byte entries and LDS-sized square
 // matrices above, and the statement-by-statement sweep walks such an input at 0.5 us per column.  The same product with
-// 16-bit entries and RECTANGULAR matrices: a block of DPW_B = 128 steps acts on the WS (1024, 2048, 4096) values before it
+// 16-bit entries and RECTANGULAR matrices: a block of DPW_B = 128 steps acts on the WS (1024, 2048, ... 16384) values before it
 // through M_b[t][k] -- the recurrence of a source k along the block's steps only involves the block's own 128 columns
 // as intermediate candidates, so a thread owns a source and keeps 128 values in LDS, 256 sources per workgroup.
 //   k_dpw_blockM   all M_b, independently: (n / 128) * (WS / 256) workgroups; two candidates per 32-bit LDS word go
@@ -987,14 +987,16 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
     bool literal = R == 0;
     bool tiled = false;
     // extensions of hundreds of columns: the matrix chain with 16-bit entries (k_dpw_*), smallest window first
-    const bool wide_ok = f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 4096 && n >= 2 * DPW_B;
+    const bool wide_ok = f0 < n && !ctx->opt.dp_literal && !ctx->opt.dp_wave && max_ext + 2 > 256 && max_ext + 2 <= 16384 && n >= 2 * DPW_B;
     auto try_wide = [&](bool &done) -> int {
         const uint32_t nblocks = (uint32_t)((n + DPW_B - 1) / DPW_B);
         uint16_t *ext16 = ctx->dp_e.as<uint16_t>();
         hipLaunchKernelGGL(k_dpw_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext16);
-        for (uint32_t WS = max_ext + 2 <= 1024 ? 1024u : max_ext + 2 <= 2048 ? 2048u : 4096u; WS <= 4096 && !done; WS *= 2) {
+        uint32_t WS = 1024;
+        while (WS < max_ext + 2) WS *= 2;
+        for (; WS <= 16384 && !done; WS *= 2) {
             const size_t mbytes = (size_t)nblocks * DPW_B * WS * 2;
-            if (mbytes > (16ull << 30)) break;
+            if (mbytes > (64ull << 30)) break;
             if (ctx->tmp.cap < mbytes) {         // the matrices are an option, not a need: without room for them the literal sweep runs
                 size_t free_b = 0, total_b = 0;
                 FBG_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -1003,21 +1005,24 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             FBG_TRY(fbg_reserve(ctx, ctx->tmp, mbytes));
             uint16_t *Mw = ctx->tmp.as<uint16_t>();
             FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
-            if (WS == 1024) {
-                hipLaunchKernelGGL((k_dpw_blockM<1024>), dim3(nblocks, 1024 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
-                hipLaunchKernelGGL((k_dpw_chain<1024>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
-            } else if (WS == 2048) {
-                hipLaunchKernelGGL((k_dpw_blockM<2048>), dim3(nblocks, 2048 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
-                hipLaunchKernelGGL((k_dpw_chain<2048>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
-            } else {
-                hipLaunchKernelGGL((k_dpw_blockM<4096>), dim3(nblocks, 4096 / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);
-                hipLaunchKernelGGL((k_dpw_chain<4096>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);
+#define FBG_DPW(W)                                                                                                                    \
+    do {                                                                                                                              \
+        hipLaunchKernelGGL((k_dpw_blockM<W>), dim3(nblocks, W / 256), dim3(256), 0, st, ext16, (uint32_t)n, Mw);                       \
+        hipLaunchKernelGGL((k_dpw_chain<W>), dim3(1), dim3(1024), 0, st, Mw, (uint32_t)n, nblocks, mml, sc, first_valid);              \
+    } while (0)
+            switch (WS) {
+            case 1024: FBG_DPW(1024); break;
+            case 2048: FBG_DPW(2048); break;
+            case 4096: FBG_DPW(4096); break;
+            case 8192: FBG_DPW(8192); break;
+            default: FBG_DPW(16384); break;
             }
+#undef FBG_DPW
             hipLaunchKernelGGL(k_dpw_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext16, (uint32_t)n, WS, bt, sc, first_valid);
             FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
             done = hk[4] == 0;
-            if (done) ctx->dp_kind = WS == 1024 ? 3 : WS == 2048 ? 4 : 5;
+            if (done) { int k = 3; for (uint32_t w2 = 1024; w2 < WS; w2 *= 2) k++; ctx->dp_kind = k; }     // 3: 1024, 4: 2048, ... 7: 16384
         }
         if (!done) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
         return FBG_OK;

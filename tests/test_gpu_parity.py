@@ -161,11 +161,12 @@ def test_dp_sweep_random_f(engine, max_ext, style):
         assert np.array_equal(gb, b)
 
 
-@pytest.mark.parametrize("max_ext", [254, 255, 300, 700, 1021, 1022, 1023, 1500, 2045, 2046, 2047, 3000, 4093, 4094, 5000])
+@pytest.mark.parametrize("max_ext", [254, 255, 300, 700, 1021, 1022, 1023, 1500, 2045, 2046, 2047, 3000, 4093, 4094, 5000, 6000, 8189, 8190, 8191,
+                                     12000, 16381, 16382, 16383, 20000])
 @pytest.mark.parametrize("style", ["uniform", "plateau", "spiky"])
 def test_dp_sweep_wide_windows(engine, max_ext, style):
-    """Extensions of hundreds of columns: the 16-bit matrix chain (k_dpw_*), its two window sizes, and the hand-over to
-    the literal sweep when a value reaches the window."""
+    """Extensions of hundreds to thousands of columns: the 16-bit matrix chain (k_dpw_*), its window sizes 1024 .. 16384,
+    and the hand-over to the literal sweep when a value reaches the largest window."""
     rng = np.random.default_rng(max_ext * 11 + len(style))
     kinds = set()
     for n in (255, 256, 257, 1500, 40_000, 40_001):
@@ -178,10 +179,11 @@ def test_dp_sweep_wide_windows(engine, max_ext, style):
         assert np.array_equal(gbt, bt), (n, np.flatnonzero(gbt != bt)[:5])
         assert np.array_equal(gb, b)
         kinds.add(engine.get_option("dp_kind"))
-        if n >= 40_000 and style == "uniform" and 512 <= max_ext <= 4093:
-            # extensions of every size up to max_ext: beyond the byte matrices, within the 16-bit ones (f[0] > 0 included)
-            assert engine.get_option("dp_kind") in (3, 4, 5), (n, max_ext, engine.get_option("dp_kind"))
-    assert kinds <= {0, 1, 2, 3, 4, 5}
+        if n >= 40_000 and style == "uniform" and 512 <= max_ext <= 16381:
+            # extensions of every size up to max_ext: beyond the byte matrices, within the 16-bit ones (f[0] > 0 included);
+            # the one-lane literal sweep (dp_kind 0) only beyond the 16384 window
+            assert engine.get_option("dp_kind") in (3, 4, 5, 6, 7), (n, max_ext, engine.get_option("dp_kind"))
+    assert kinds <= {0, 1, 2, 3, 4, 5, 6, 7}
 
 
 def test_dp_sweep_wide_windows_full_size(engine):
@@ -209,6 +211,28 @@ def test_dp_sweep_wide_windows_full_size(engine):
     ends = torch.cat([b[:-1], torch.tensor([n - 1], device="cuda")])
     assert bool((d_f[starts] <= ends).all())
     assert int((ends - starts + 1).max()) == int(out[0][2][n]) > 256
+
+
+def test_dp_sweep_window_8192_at_scale(engine):
+    """Extensions of up to 6000 columns over 2 * 10^5 columns: the 8192 window of the 16-bit matrix chain (no one-lane sweep
+    on the product path: k_dp_minmax only runs under dp_literal, or beyond the 16384 window) against the statement-by-
+    statement sweep."""
+    import torch
+    n = 200_000
+    rng = np.random.default_rng(123)
+    f = _random_f(rng, n, 6000, "plateau").astype(np.int64)
+    d_f = torch.from_numpy(f).cuda()
+    out = []
+    for literal in (0, 1):
+        with fbg_options(engine, {"FBG_DP_LITERAL": str(literal)}):
+            d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            d_mml = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            d_bt = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            cnt = engine.minmax_dp_device(d_f.data_ptr(), n, d_b.data_ptr(), d_mml.data_ptr(), d_bt.data_ptr())
+            assert engine.get_option("dp_kind") == (0 if literal else 6)
+            out.append((cnt, d_b[:cnt].clone(), d_mml, d_bt))
+    assert out[0][0] == out[1][0] and all(torch.equal(out[0][k], out[1][k]) for k in (1, 2, 3))
 
 
 def test_dp_sweep_f0_nonzero_uses_literal_semantics(engine):
