@@ -16,6 +16,7 @@
 // The host writer then only formats: B counts, S lines from the representative rows, L lines, P lines.
 #include "fbg_internal.h"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 
 #define BG_NONE 0xffffffffu
 #define BG_THREADS 256
@@ -79,15 +80,19 @@ __device__ __forceinline__ bool bg_same_label(const BgArgs &a, uint64_t p, uint6
     }
 }
 
-// dynamic LDS: table[ts] (owner row of a slot), minrow[ts], slot_of[m], flags/scan scratch
-__global__ __launch_bounds__(BG_THREADS) void k_block_group(BgArgs a, uint32_t ts)
+// dynamic LDS: table[ts] (owner row of a slot), minrow[ts], slot_of[m], flags/scan scratch -- up to 4096 rows; beyond, the
+// same arrays live in global memory (scratch: one stretch per workgroup, L2-resident), and the workgroups stay and take
+// block after block
+__global__ __launch_bounds__(BG_THREADS) void k_block_group(BgArgs a, uint32_t ts, uint32_t *__restrict__ scratch)
 {
     extern __shared__ uint32_t bg_lds[];
-    uint32_t *table = bg_lds, *minrow = bg_lds + ts, *slot_of = bg_lds + 2 * ts, *rank = slot_of + a.m;
+    uint32_t *base = scratch ? scratch + (size_t)blockIdx.x * (2 * (size_t)ts + 2 * a.m) : bg_lds;
+    uint32_t *table = base, *minrow = base + ts, *slot_of = base + 2 * ts, *rank = slot_of + a.m;
     __shared__ uint32_t wsum[BG_THREADS / 64];
     __shared__ uint32_t carry;
-    const uint64_t j = blockIdx.x;
     const uint32_t m = (uint32_t)a.m, mask = ts - 1;
+  for (uint64_t j = blockIdx.x; j < a.nb; j += gridDim.x) {
+    __syncthreads();
     const uint64_t *h1 = a.h1 + j * a.m, *h2 = a.h2 + j * a.m;
     for (uint32_t s = threadIdx.x; s < ts; s += BG_THREADS) { table[s] = BG_NONE; minrow[s] = BG_NONE; }
     if (threadIdx.x == 0) carry = 0;
@@ -135,16 +140,19 @@ __global__ __launch_bounds__(BG_THREADS) void k_block_group(BgArgs a, uint32_t t
     for (uint32_t i = threadIdx.x; i < m; i += BG_THREADS)
         a.node_of[j * a.m + i] = slot_of[i] == BG_NONE ? BG_NONE : rank[minrow[slot_of[i]]];
     if (threadIdx.x == 0) a.count[j] = carry;
+  }
 }
 
 // local node numbers -> global ones; edges into block j: sorted distinct (node of block j-1, node of block j)
-__global__ __launch_bounds__(BG_THREADS) void k_block_edges(BgArgs a, uint32_t cap)
+__global__ __launch_bounds__(BG_THREADS) void k_block_edges(BgArgs a, uint32_t cap, unsigned long long *__restrict__ scratch)
 {
-    extern __shared__ unsigned long long bg_pairs[];       // cap >= m, a power of two
+    extern __shared__ unsigned long long bg_pairs_lds[];   // cap >= m, a power of two (more than 4096 rows: global scratch)
+    unsigned long long *bg_pairs = scratch ? scratch + (size_t)blockIdx.x * cap : bg_pairs_lds;
     __shared__ uint32_t wsum[BG_THREADS / 64];
     __shared__ uint32_t carry;
-    const uint64_t j = blockIdx.x;
     const uint32_t m = (uint32_t)a.m;
+  for (uint64_t j = blockIdx.x; j < a.nb; j += gridDim.x) {
+    __syncthreads();
     const unsigned long long f1 = a.first[j], f0 = j ? a.first[j - 1] : 0;
     for (uint32_t i = threadIdx.x; i < cap; i += BG_THREADS) {
         unsigned long long pr = ~0ull;
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(BG_THREADS) void k_block_edges(BgArgs a, uint32_t c
         __syncthreads();
     }
     if (threadIdx.x == 0) a.edge_count[j] = carry;
+  }
 }
 
 // second launch, after all edges are out: node_of local -> global (k_block_edges reads the local numbers of the block before)
@@ -210,7 +219,7 @@ int fbg_block_graph(fbg_ctx *ctx, const uint64_t *boundaries, uint64_t nb, uint3
         return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_block_graph: bad arguments");
     const uint64_t m = ctx->m, n = ctx->n;
     if (m * nb >= (1ull << 32)) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_block_graph: more than 2^32 (row, block) cells");
-    if (m > FBG_MAX_ROWS) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_block_graph: more than %d rows (the labels of a block are grouped in LDS)", FBG_MAX_ROWS);
+    if (m > FBG_MAX_ROWS) return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "fbg_block_graph: more than %d rows", FBG_MAX_ROWS);
     for (uint64_t j = 0; j < nb; j++)
         if (boundaries[j] > n || (j && boundaries[j] <= boundaries[j - 1]))
             return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_block_graph: boundaries must increase and end at most at n");
@@ -242,9 +251,19 @@ int fbg_block_graph(fbg_ctx *ctx, const uint64_t *boundaries, uint64_t nb, uint3
     uint32_t ts = 64;
     while (ts < 2 * m) ts <<= 1;
     const size_t lds1 = ((size_t)2 * ts + 2 * m) * 4;
-    if (lds1 > 64 * 1024)
-        FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_block_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    hipLaunchKernelGGL(k_block_group, dim3((unsigned)nb), dim3(BG_THREADS), lds1, st, a, ts);
+    const bool in_lds = m <= 4096;
+    const unsigned wgs = in_lds ? (unsigned)nb : (unsigned)std::min<uint64_t>(nb, 512);   // beyond LDS: workgroups that stay, a stretch of scratch each
+    uint32_t *scratch1 = nullptr;
+    if (in_lds) {
+        if (lds1 > 64 * 1024)
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_block_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    } else {
+        uint32_t cap2 = 64;
+        while (cap2 < m) cap2 <<= 1;
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_h, std::max((size_t)wgs * lds1, (size_t)wgs * cap2 * 8)));   // (k_block_edges' stretches too)
+        scratch1 = ctx->dp_h.as<uint32_t>();
+    }
+    hipLaunchKernelGGL(k_block_group, dim3(wgs), dim3(BG_THREADS), in_lds ? lds1 : 0, st, a, ts, scratch1);
     // first node of every block: exclusive scan of the counts
     hipLaunchKernelGGL(k_bg_widen, dim3(fbg_blocks(nb, 256)), dim3(256), 0, st, a.count, wide, nb);
     FBG_HIP_TRY(ctx, hipMemsetAsync(wide + nb, 0, 8, st));
@@ -260,7 +279,11 @@ int fbg_block_graph(fbg_ctx *ctx, const uint64_t *boundaries, uint64_t nb, uint3
     a.edges = ctx->dp_b.as<unsigned long long>();          // the hashes are not needed any more
     uint32_t cap = 64;
     while (cap < m) cap <<= 1;
-    hipLaunchKernelGGL(k_block_edges, dim3((unsigned)nb), dim3(BG_THREADS), (size_t)cap * 8, st, a, cap);
+    unsigned long long *scratch2 = nullptr;
+    if (!in_lds) {
+        scratch2 = ctx->dp_h.as<unsigned long long>();                      // (k_block_group is done with its stretches)
+    }
+    hipLaunchKernelGGL(k_block_edges, dim3(wgs), dim3(BG_THREADS), in_lds ? (size_t)cap * 8 : 0, st, a, cap, scratch2);
     hipLaunchKernelGGL(k_block_globalize, dim3(fbg_blocks(cells, 256)), dim3(256), 0, st, a);
     unsigned long long h_flag = 0;
     FBG_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, a.flag, 8, hipMemcpyDeviceToHost, st));

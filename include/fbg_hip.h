@@ -44,8 +44,9 @@ enum {
     FBG_ERR_HASH_COLLISION = 7   /* fbg_block_graph only: use the caller's own label numbering instead */
 };
 
-#define FBG_MAX_ROWS 4096   /* fbg_block_graph only: one workgroup groups the labels of a block in LDS (more rows:
-                               FBG_ERR_TOO_LARGE, number the labels on the host).  The segmentation itself has no row limit. */
+#define FBG_MAX_ROWS 262144 /* fbg_block_graph only: a workgroup groups the labels of a block -- in LDS up to 4096 rows, in a
+                               stretch of device memory of its own beyond (more rows than this: FBG_ERR_TOO_LARGE, number the
+                               labels on the host).  The segmentation itself has no row limit. */
 
 /* stage ids for fbg_stage_ms() */
 enum {

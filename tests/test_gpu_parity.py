@@ -890,13 +890,15 @@ def _block_graph_reference(msa, boundaries):
     return node_of, first, reps, edges
 
 
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(8))
 def test_block_graph_matches_reference_numbering(engine, case):
     """fbg_block_graph (nodes / edges of the xGFA) against the reference's hashing restated with dicts."""
     rng = np.random.default_rng(900 + case)
     m, n, kw = [(5, 60, {}), (40, 500, dict(similar=0.97)), (64, 300, dict(similar=0.9, gap_p=0.05, gap_run=6)),
                 (257, 200, dict(similar=0.99, gap_p=0.02, gap_run=30)), (1000, 150, dict(similar=0.98)),
-                (3, 40, dict(gap_p=0.3, gap_run=10))][case]
+                (3, 40, dict(gap_p=0.3, gap_run=10)),
+                (5000, 90, dict(similar=0.97, gap_p=0.01, gap_run=4)),      # more than 4096 rows: the labels grouped in device memory
+                (4097, 60, dict(similar=0.5))][case]
     msa = random_msa(rng, m, n, **kw)
     cuts = np.sort(rng.choice(np.arange(0, n - 1), size=min(n // 4, 40), replace=False)).astype(np.uint64)
     boundaries = np.concatenate([cuts, [n]]).astype(np.uint64)           # last entry is n (fbg.cpp:2026-2039)
