@@ -392,11 +392,15 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_runs(SpA
     }
 }
 
-// the odd groups, listed by size class (one reservation per wave: 5 * 10^5 single additions to one address took 5 ms)
-__global__ void k_sp_oddlist(SpArgs a)
+// the odd groups, listed by size class (one reservation per workgroup and class: 5 * 10^5 single additions to one address
+// took 5 ms, one per wave still 3.7)
+__global__ __launch_bounds__(1024) void k_sp_oddlist(SpArgs a)
 {
+    __shared__ uint32_t cnt[4];
+    __shared__ unsigned long long base[4];
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
     int cls = -1;
     if (g < a.G) {
         const uint32_t fl = a.gflags[g];
@@ -405,55 +409,55 @@ __global__ void k_sp_oddlist(SpArgs a)
             cls = s <= 64 ? 0 : s <= 896 ? 1 : s <= 1024 ? 2 : 3;
         }
     }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const unsigned long long mask = __ballot(cls == c);
-        if (!mask) continue;
-        unsigned long long base = 0;
-        if (lane == (uint32_t)__ffsll(mask) - 1) base = atomicAdd(&a.counters[8 + c], (unsigned long long)__popcll(mask));
-        base = __shfl(base, __ffsll(mask) - 1, 64);
-        if (cls == c) {
-            const unsigned long long e = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1));
-            if (e < a.odd_cap) a.odd[(size_t)c * a.odd_cap + e] = (uint32_t)g; else a.counters[3] = 1;
-        }
+    uint32_t mine = 0;
+    if (cls >= 0) mine = atomicAdd(&cnt[cls], 1u);
+    __syncthreads();
+    if (threadIdx.x < 4 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&a.counters[8 + threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    __syncthreads();
+    if (cls >= 0) {
+        const unsigned long long e = base[cls] + mine;
+        if (e < a.odd_cap) a.odd[(size_t)cls * a.odd_cap + e] = (uint32_t)g; else a.counters[3] = 1;
     }
 }
 
 // the pure interval of an odd group (one wave per group): the columns at which every member is coloured
 __global__ __launch_bounds__(256) void k_sp_odd_spans(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t max_group)
 {
-    const uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const bool have = e < count;
-    const uint32_t g = have ? list[e] : 0u;
-    const uint32_t s0 = a.gstart[g], s = have ? a.gstart[g + 1] - s0 : 0u, c0 = a.gcol[g];
-    uint32_t lo_max = 0, hi_min = SP_NONE, nodd = 0;
-    for (uint32_t i = lane; i < s; i += 64) {
-        const uint32_t v = a.vals[s0 + i];
-        uint32_t row, col, lo, hi;
-        sp_decode(a, v, row, col);
-        lo = hi = col;
-        if (v & SP_W) sp_wide_span(a, row, col, sp_pos(a, row, col), lo, hi);
-        if ((v & SP_W) || col != c0) nodd++;
-        if (lo > hi) { lo_max = SP_NONE; hi_min = 0; }       // a member that is never coloured
-        lo_max = max(lo_max, lo); hi_min = min(hi_min, hi);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        lo_max = max(lo_max, (uint32_t)__shfl_xor(lo_max, d, 64));
-        hi_min = min(hi_min, (uint32_t)__shfl_xor(hi_min, d, 64));
-        nodd += (uint32_t)__shfl_xor(nodd, d, 64);
-    }
     __shared__ unsigned long long work, members;
+    const uint32_t lane = threadIdx.x & 63;
     if (threadIdx.x == 0) { work = 0; members = 0; }
     __syncthreads();
-    if (lane == 0 && have) {
-        const bool none = lo_max > hi_min;
-        a.gplo[g] = none ? 1u : lo_max;
-        a.gphi[g] = none ? 0u : hi_min;
-        atomicAdd(&work, (unsigned long long)nodd * s);
-        atomicAdd(&members, (unsigned long long)nodd);
-        if (s > max_group || (!none && hi_min - lo_max >= SP_MAX_PURE)) a.counters[3] = 1;
+    unsigned long long my_work = 0, my_members = 0;            // (lane 0 of every wave)
+    for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < count; e += gridDim.x * 4) {
+        const uint32_t g = list[e];
+        const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0, c0 = a.gcol[g];
+        uint32_t lo_max = 0, hi_min = SP_NONE, nodd = 0;
+        for (uint32_t i = lane; i < s; i += 64) {
+            const uint32_t v = a.vals[s0 + i];
+            uint32_t row, col, lo, hi;
+            sp_decode(a, v, row, col);
+            lo = hi = col;
+            if (v & SP_W) sp_wide_span(a, row, col, sp_pos(a, row, col), lo, hi);
+            if ((v & SP_W) || col != c0) nodd++;
+            if (lo > hi) { lo_max = SP_NONE; hi_min = 0; }       // a member that is never coloured
+            lo_max = max(lo_max, lo); hi_min = min(hi_min, hi);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo_max = max(lo_max, (uint32_t)__shfl_xor(lo_max, d, 64));
+            hi_min = min(hi_min, (uint32_t)__shfl_xor(hi_min, d, 64));
+            nodd += (uint32_t)__shfl_xor(nodd, d, 64);
+        }
+        if (lane == 0) {
+            const bool none = lo_max > hi_min;
+            a.gplo[g] = none ? 1u : lo_max;
+            a.gphi[g] = none ? 0u : hi_min;
+            my_work += (unsigned long long)nodd * s;
+            my_members += nodd;
+            if (s > max_group || (!none && hi_min - lo_max >= SP_MAX_PURE)) a.counters[3] = 1;
+        }
     }
+    if (lane == 0 && my_work) { atomicAdd(&work, my_work); atomicAdd(&members, my_members); }
     __syncthreads();
     if (threadIdx.x == 0 && work) { atomicAdd(&a.counters[2], work); atomicAdd(&a.counters[5], members); }
 }
@@ -912,7 +916,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
     __shared__ uint32_t olo[SPP_MAXO], ohi[SPP_MAXO], omn[SPP_MAXO], oany[SPP_MAXO], ogmax[SPP_MAXO], oign[SPP_MAXO];
     __shared__ uint32_t LQ[SPP_MAXO][SPP_MAXO];
     __shared__ uint64_t qwin[SPP_MAXO][16];
-    __shared__ uint32_t tl[SPP_TAILS];
+    __shared__ uint32_t tl[SPP_TAILS], tmin[SPP_TAILS];
     __shared__ uint32_t n_odd, ntl, s_gv, s_need, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;       // B: 16 lanes per pair, 8 bytes each
@@ -954,12 +958,18 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
             __syncthreads();
             const uint32_t gv = s_gv;
             const uint32_t kign = sp_key_first_ignore(a, key, gv);
+            const uint32_t step = kign < gv ? kign : gv - 1;
+            // the regular members of the majority column all reach the same column: one update for them (hundreds of atomic
+            // maxima on one address cost more than everything else the group needs)
+            bool reg_major = false;
             for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
                 uint32_t row, col;
                 sp_decode(a, sv[i], row, col);
-                const uint32_t fi = (sv[i] & SP_I) ? sp_extent(a, sp[i], row, gv, kign) : col + (kign < gv ? kign : gv - 1);
+                if (!(sv[i] & SP_I) && col == major) { reg_major = true; continue; }
+                const uint32_t fi = (sv[i] & SP_I) ? sp_extent(a, sp[i], row, gv, kign) : col + step;
                 sp_update(a, x, fi);
             }
+            if (__ballot(reg_major) && (threadIdx.x & 63) == 0) sp_update(a, x, major + step);
         }
         if (no > SPP_MAXO) {                                   // many odd members (a deletion common to many rows): k_sp_odd_slow
             if (threadIdx.x == 0) {
@@ -1003,10 +1013,12 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
         // -- A: every odd member against the registers
         for (uint32_t o = 0; o < no; o++) {
             const bool own = own_of(o);
-            if (!own && (at_major_of(o) || !has_narrow)) continue;   // (uniform over the workgroup)
+            const bool atm = at_major_of(o);
+            if (!own && (atm || !has_narrow)) continue;        // (uniform over the workgroup)
             const uint32_t q = oidx[o];
             const uint64_t qlo = qwin[o][2 * sl8], qhi = qwin[o][2 * sl8 + 1];
             const uint32_t rows_live = own ? valid : (valid & narrow);
+            uint32_t mymax = 0;                                // the lane's longest match with a member of the majority
 #pragma unroll
             for (int r = 0; r < SPP_ROWS; r++) {
                 if ((uint32_t)r * 32 >= s) break;              // (uniform)
@@ -1014,50 +1026,47 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
                 const bool live = ((rows_live >> r) & 1u) && u != q;
                 const uint64_t dlo = mlo[r] ^ qlo, dhi = mhi[r] ^ qhi;
                 const uint32_t seg = (uint32_t)(__ballot(!live || (dlo | dhi) != 0) >> (8 * sub8)) & 0xffu;
-                if (live && seg && sl8 == (uint32_t)__ffs(seg) - 1)       // the lane that holds the first difference
-                    note(o, u, 16 * sl8 + (dlo ? ((uint32_t)__ffsll((unsigned long long)dlo) - 1) / 8 : 8 + ((uint32_t)__ffsll((unsigned long long)dhi) - 1) / 8));
+                if (live && seg && sl8 == (uint32_t)__ffs(seg) - 1) {     // the lane that holds the first difference
+                    const uint32_t L = (uint32_t)a.K + 16 * sl8 + (dlo ? ((uint32_t)__ffsll((unsigned long long)dlo) - 1) / 8 : 8 + ((uint32_t)__ffsll((unsigned long long)dhi) - 1) / 8);
+                    if ((narrow >> r) & 1u) { mymax = max(mymax, L); if (!atm) atomicMax(&nbest[u], L); }
+                    else LQ[o][omap[u]] = L;
+                }
                 if (live && !seg && sl8 == 0) {
                     const uint32_t at = atomicAdd(&ntl, 1u);
                     if (at < SPP_TAILS) tl[at] = o << 16 | u;
                     else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[q] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
                 }
             }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor(mymax, d, 64));
+            if (lane == 0 && mymax) { atomicMax(&omn[o], mymax); oany[o] = 1; }
         }
         __syncthreads();
-        // -- B: the pairs that match beyond the first window, 64 at a time, window after window
+        // -- B: the pairs that match beyond the first window: window after window, ALL of them at once -- a thread takes 8
+        // bytes of a pair, the pair's first differing byte is the minimum over its 16 threads (32 pairs at a time, each waiting
+        // for its own round trip, took a quarter of the kernel)
         const uint32_t nt = min(ntl, (uint32_t)SPP_TAILS);
-        for (uint32_t t0 = 0; t0 < nt; t0 += 32) {
-            uint32_t po[2], pu[2], Lb[2];
-            bool live4[2], pend[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const uint32_t idx = t0 + (uint32_t)rr * 16 + wv * 4 + sub;
-                live4[rr] = idx < nt;
-                const uint32_t ent = live4[rr] ? tl[idx] : 0u;
-                po[rr] = ent >> 16; pu[rr] = ent & 0xffffu; Lb[rr] = 0; pend[rr] = live4[rr];
+        for (uint32_t off = SP_WIN; nt > 0; off += SP_WIN) {
+            for (uint32_t t = threadIdx.x; t < nt; t += SP_THREADS) tmin[t] = SP_NONE;
+            if (threadIdx.x == 0) s_gv = 0;                    // (pairs still open after this window)
+            __syncthreads();
+            for (uint32_t idx = threadIdx.x; idx < nt * 16; idx += SP_THREADS) {
+                const uint32_t t = idx >> 4, piece = idx & 15, ent = tl[t];
+                if (ent == SP_NONE) continue;                  // settled in an earlier window
+                const uint64_t qx = sp_load8(a, (uint64_t)sp[oidx[ent >> 16]] + a.K + off + 8 * piece);
+                const uint64_t x = sp_load8(a, (uint64_t)sp[ent & 0xffffu] + a.K + off + 8 * piece);
+                const uint64_t diff = x ^ qx;
+                if (diff) atomicMin(&tmin[t], 8 * piece + ((uint32_t)__ffsll((unsigned long long)diff) - 1) / 8);
             }
-            for (uint32_t off = SP_WIN;; off += SP_WIN) {
-                uint64_t qx[2], x[2];
-#pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
-                    qx[rr] = pend[rr] ? sp_load8(a, (uint64_t)sp[oidx[po[rr]]] + a.K + off + 8 * sl) : 0ull;
-                    x[rr] = pend[rr] ? sp_load8(a, (uint64_t)sp[pu[rr]] + a.K + off + 8 * sl) : 0ull;
-                }
-                bool more = false;
-#pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
-                    const uint64_t diff = x[rr] ^ qx[rr];
-                    const uint32_t seg = (uint32_t)(__ballot(diff != 0) >> (16 * sub)) & 0xffffu;
-                    const uint32_t f = seg ? (uint32_t)__ffs(seg) - 1 : 0u;
-                    const uint64_t dfirst = __shfl(diff, (int)(16 * sub + f), 64);
-                    if (pend[rr] && seg) { Lb[rr] = off + 8 * f + ((uint32_t)__ffsll((unsigned long long)dfirst) - 1) / 8; pend[rr] = false; }
-                    more = more || pend[rr];
-                }
-                if (!__ballot(more)) break;                    // (two suffixes differ at the sentinel at the latest)
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < nt; t += SP_THREADS) {
+                const uint32_t ent = tl[t];
+                if (ent == SP_NONE) continue;
+                if (tmin[t] != SP_NONE) { note(ent >> 16, ent & 0xffffu, off + tmin[t]); tl[t] = SP_NONE; }
+                else s_gv = 1;                                 // (two suffixes differ at the sentinel at the latest)
             }
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++)
-                if (live4[rr] && sl == 0) note(po[rr], pu[rr], Lb[rr]);
+            __syncthreads();
+            if (!s_gv) break;
         }
         __syncthreads();
         // -- C: the columns of the odd members' spans outside the pure interval, a thread per (odd member, column)
@@ -1212,7 +1221,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     for (int c = 0; c < 4; c++) { lists[c] = a.odd + (size_t)c * a.odd_cap; cnts[c] = ctx->sp_n_odd[c]; }
     const uint32_t n_small = cnts[0] + cnts[1] + cnts[2], n_big = cnts[3];
     for (int c = 0; c < 4; c++)
-        if (cnts[c]) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(cnts[c], 4)), dim3(256), 0, st, a, lists[c], cnts[c], c == 3 ? 8192u : 1024u);
+        if (cnts[c]) hipLaunchKernelGGL(k_sp_odd_spans, dim3(fbg_blocks(cnts[c], 4, 4096)), dim3(256), 0, st, a, lists[c], cnts[c], c == 3 ? 8192u : 1024u);
     unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1375,7 +1384,7 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
         FBG_TRY(fbg_reserve(ctx, ctx->sp_odd, (size_t)cap * 16));
         sp_args(ctx, a, 0);
         FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 16 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sp_oddlist, dim3(fbg_blocks(G, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_sp_oddlist, dim3(fbg_blocks(G, 1024)), dim3(1024), 0, st, a);
         unsigned long long h[12];
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));

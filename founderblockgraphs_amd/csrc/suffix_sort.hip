@@ -207,8 +207,13 @@ __global__ void k_count_equal_neighbours(const uint64_t *__restrict__ keys, uint
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool eq = i + 1 < S && keys[i] == keys[i + 1];
+    __shared__ uint32_t blk;
+    if (threadIdx.x == 0) blk = 0;
+    __syncthreads();
     const unsigned long long m = __ballot(eq);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&blk, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && blk) atomicAdd(out, (unsigned long long)blk);
 }
 
 // grp[r] = r if key[r] starts a group, else 0  (max-scan turns it into the group head index)
