@@ -257,7 +257,7 @@ def measured_traffic(m, n, kernel):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected as
     MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled on gfx950); None when no pass
     exists for this workload / kernel."""
-    for name in ("r02_pmc_kernels.json", "r01_pmc_scan_kernels.json"):
+    for name in ("r03_pmc_kernels.json", "r02_pmc_kernels.json", "r01_pmc_scan_kernels.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 d = json.load(fh)
