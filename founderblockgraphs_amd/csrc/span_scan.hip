@@ -420,6 +420,13 @@ __global__ __launch_bounds__(1024) void k_sp_oddlist(SpArgs a)
     }
 }
 
+// the column of the first member of each listed group (sort key: the lists are worked off in column order)
+__global__ void k_sp_list_cols(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t *__restrict__ cols)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) cols[e] = a.gcol[list[e]];
+}
+
 // the pure interval of an odd group (one wave per group): the columns at which every member is coloured
 __global__ __launch_bounds__(256) void k_sp_odd_spans(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t max_group)
 {
@@ -905,8 +912,10 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
 #define SPP_TAILS 1024
 // SPP_ROWS: rows of 32 members (4 waves x 8 mates per wave and row, 16 bytes of a mate per lane) the registers hold: 2 (the
 // small groups, more than half of the odd ones: few registers, many workgroups per compute unit), 28 (896 members) or 32
-// (up to 1024); an instance takes the groups of more than MINS members that it has room for
-template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
+// (up to 1024); an instance takes the groups of more than MINS members that it has room for.  What the kernel waits for is
+// memory -- a dozen dependent round trips per group -- so the waves per SIMD count: at 2 (256 registers) it took 31 ms for
+// 1000 x 200 000, at 3 (168 registers, a few spills) 21 ms, at 4 (128, 42 spills) 23 ms
+template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
 {
     constexpr int CAP = SPP_ROWS * 32;
@@ -1066,7 +1075,9 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
                 else s_gv = 1;                                 // (two suffixes differ at the sentinel at the latest)
             }
             __syncthreads();
-            if (!s_gv) break;
+            const bool more = s_gv != 0;
+            __syncthreads();                                   // (everyone has read the flag before the next round resets it)
+            if (!more) break;
         }
         __syncthreads();
         // -- C: the columns of the odd members' spans outside the pure interval, a thread per (odd member, column)
@@ -1240,8 +1251,8 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     // lists (k_sp_odd), the chains (k_sp_chain), every pair where that does not do (k_sp_odd_slow)
     // (workgroups that stay and take group after group: a workgroup per group spent more time being launched than working)
     if (cnts[0]) hipLaunchKernelGGL((k_sp_odd_pairs<2, 0>), dim3(std::min<uint32_t>(cnts[0], 8192u)), dim3(SP_THREADS), 0, st, a, lists[0], cnts[0]);
-    if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 2048u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1]);
-    if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 2048u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2]);
+    if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 3072u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1]);
+    if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 3072u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2]);
     *launches += 3;
     ctx->sp_chain_n = 0; ctx->sp_slow_n = 0;
     if (n_small) {
@@ -1391,6 +1402,25 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
         launches += 2;
         if (h[3] != 0) good = false;
         for (int c = 0; c < 4; c++) ctx->sp_n_odd[c] = (uint32_t)std::min<unsigned long long>(h[8 + c], cap);
+        // The lists in COLUMN order: the workgroups of an odd group read the texts of all its members -- hundreds of rows at
+        // one column, two memory lines each -- and so do the groups of the columns next to it.  In key order those meet at
+        // random times; in column order the groups in flight at one time sit in neighbouring columns and share the lines
+        // through the L2 (35 -> 24 GB fetched for 1000 x 200 000).
+        for (int c = 0; c < 4 && good; c++) {
+            const uint32_t cnt = ctx->sp_n_odd[c];
+            if (cnt < 2) continue;
+            FBG_TRY(fbg_reserve(ctx, ctx->ps_f, (size_t)cnt * 4 * 3));
+            uint32_t *cols = ctx->ps_f.as<uint32_t>(), *cols_s = cols + cnt, *list_s = cols + 2 * (size_t)cnt;
+            uint32_t *lst = a.odd + (size_t)c * a.odd_cap;
+            hipLaunchKernelGGL(k_sp_list_cols, dim3(fbg_blocks(cnt, 256)), dim3(256), 0, st, a, (const uint32_t *)lst, cnt, cols);
+            int nb = 1;
+            while ((1ull << nb) < n + 1) nb++;
+            FBG_TRY(sp_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+                return rocprim::radix_sort_pairs(tmp, bytes, cols, cols_s, lst, list_s, (size_t)cnt, 0u, (unsigned)nb, st);
+            }));
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(lst, list_s, (size_t)cnt * 4, hipMemcpyDeviceToDevice, st));
+            launches += 3;
+        }
     }
     int ok = 0;
     if (good) FBG_TRY(sp_scan(ctx, 0, &ok, &launches));
