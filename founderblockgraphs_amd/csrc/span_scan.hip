@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void k_sp_cells(const uint32_t *__restrict__ c
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pos[mid] <= p0) lo = mid; else hi = mid; }
         const unsigned long long seps = __ballot(col >= n);
         row = lo + (uint32_t)__popcll(seps & ((1ull << lane) - 1));
+        if (p == N - 1) { row = m; col = n; }                  // the sentinel (as lane 0 of its wave it would pass for the last row's '#')
     } else {
         row = (uint32_t)(p / (n + 1));
         col = (uint32_t)(p - (uint64_t)row * (n + 1));

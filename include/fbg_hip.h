@@ -86,11 +86,16 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   msd_min_force      1: the sample sort of (key, position) pairs also for rows that resemble each other (tests)
  *   msd_sample_bins    1: the finish of the sample sort bins by sampled keys instead of symbol ranks (the earlier method, kept for tests)
  *   gapped_rank also takes 2 (no flag bits in the sort's values), 3 (flag bits, no threshold), 4 (threshold forced: tests)
+ *   span_scan          MSAs with gaps / ignore characters whose rows resemble each other take the group-level scan on
+ *                      column spans (span_scan.hip); 1: every such MSA takes it, -1: none, 2: as 0, and the sorted slots
+ *                      are checked to be the cells in key order (debugging)
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
- * gap-free MSA, 2 rank-order scan of an MSA with gaps / ignore characters, 3 one partition of a partitioned index.
+ * gap-free MSA, 2 scan in suffix order of an MSA with gaps / ignore characters (slot by slot, or -- "span_scan_used" = 1 --
+ * group by group), 3 one partition of a partitioned index.  "span_groups", "span_odd_groups", "span_irregular",
+ * "span_scan_work" (read-only): the group-level scan's table sizes and the text comparisons it expected.
  * "dp_kind" (read-only): the sweep that produced the last fbg_minmax_dp result: -1 none yet, 0 statement by statement,
- * 1 matrix chain with byte entries (windows up to 256 columns), 2 wave-parallel sweep, 3 / 4 / 5 matrix chain with 16-bit
- * entries over windows of 1024 / 2048 / 4096 columns.
+ * 1 matrix chain with byte entries (windows up to 256 columns), 2 wave-parallel sweep, 3 .. 7 matrix chain with 16-bit
+ * entries over windows of 1024 / 2048 / 4096 / 8192 / 16384 columns.
  * Unknown key: FBG_ERR_INVALID.
  */
 int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value);

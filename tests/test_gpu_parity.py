@@ -1358,3 +1358,21 @@ def test_span_scan_through_a_group_and_at_scale():
             b = e.elastic_f(big)
             assert e.get_option("span_scan_used") == 0
         assert np.array_equal(a, b)
+
+
+def test_span_scan_decline_hands_the_record_path_a_suffix_array(engine):
+    """The group-level scan declines (here: a gap of 5000 columns common to all rows makes a group whose members are coloured
+    together over more columns than it walks) AFTER the sort: the cells go back to text positions and the record path goes
+    on.  The text has 64 k + 1 symbols, so the sentinel is the first position of its wave in k_sp_cells -- where it took the
+    last row's '#' for itself, the suffix array had a position twice, and the text comparison of the record path read beyond
+    the text (a memory fault, found by scripts/gpu_fuzz_span.py)."""
+    rng = np.random.default_rng(5)
+    row = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 63)]
+    msa = np.full((3, 5063), ord("-"), dtype=np.uint8)
+    msa[:, :10] = row[:10]
+    msa[:, 5010:] = row[10:]
+    assert (3 * (63 + 1) + 1) % 64 == 1
+    with fbg_options(engine, {"span_scan": 1}):
+        for tricks_off in (False, True):
+            assert np.array_equal(engine.elastic_f(msa, disable_efg_tricks=tricks_off), O.compute_f(msa, disable_tricks=tricks_off))
+        assert engine.get_option("span_scan_used") == 0
