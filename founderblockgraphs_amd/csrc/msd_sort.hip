@@ -54,7 +54,15 @@ struct MsdArgs {
     unsigned long long *arena_count;
     uint32_t arena_cap;
     unsigned long long *flag;                  // != 0: a capacity was exceeded
+    int probe;                                 // timing probes (option msd_probe): bit 0 no global stores, bit 1 made-up slots instead of loads
 };
+
+__device__ __forceinline__ uint64_t msd_probe_word(uint32_t j)
+{
+    uint64_t x = ((uint64_t)blockIdx.x * 16384ull + j + 1) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    return (x & ~0x3fffull) | j;
+}
 
 // ranks -> exclusive offsets of the MSD_NB digit counts of a tile; thread d < MSD_NB also reserves the run of digit d
 // behind *cursor (one global atomic per non-empty digit) and leaves its start, relative to the bucket, in gbase[d]
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
             const uint64_t x = buf[j];
             const uint32_t d = (uint32_t)(x >> wshift);
             const uint64_t at = gbase[d] + (j - loff[d]);
+            if (a.probe & 1) continue;
             if (at < a.cap1) a.buf1[(uint64_t)d * a.cap1 + at] = x;
             else *a.flag = 1;
         }
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        w[r] = j < have ? in[j] : 0ull;
+        w[r] = j < have ? ((a.probe & 2) ? msd_probe_word(j) : in[j]) : 0ull;
     }
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
             const uint64_t x = buf[j];
             const uint32_t d = (uint32_t)(x >> wshift) & (MSD_NB - 1);
             const uint64_t at = gbase[d] + (j - loff[d]);
+            if (a.probe & 1) continue;
             if (at < MSD_FN_CAP) a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at] = x;
             else {
                 const unsigned long long e = atomicAdd(a.arena_count, 1ull);
@@ -212,7 +222,8 @@ __global__ void k_msd_widen(const uint32_t *__restrict__ count2, unsigned long l
 template <int CAP, int THREADS>
 __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, const uint64_t *in_a,
                                                 uint32_t n_a, const uint64_t *in_b, uint32_t have, uint64_t *out, int fshift,
-                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds)
+                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds,
+                                                int probe = 0)
 {
     constexpr int ITEMS = CAP / THREADS;
     for (int i = threadIdx.x; i < MSD_FN_BINS; i += THREADS) cnt[i] = 0;
@@ -222,7 +233,7 @@ __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
-        w[r] = j < have ? (j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
+        w[r] = j < have ? ((probe & 2) ? msd_probe_word(j) : j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -330,7 +341,7 @@ __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
-        if (j < have) out[j] = buf[j];
+        if (j < have && !(probe & 1)) out[j] = buf[j];
     }
 }
 
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
     if (have == 0 || have > MSD_FN_CAP) return;                // the larger ones: k_msd_finish_big
     const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
     msd_finish_body<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, in, have, in, have, a.out + a.off[blockIdx.x], fshift, fmask,
-                                                fshift - a.pb, sub, biglist, &nbig_lds);
+                                                fshift - a.pb, sub, biglist, &nbig_lds, a.probe);
 }
 
 // sub-buckets whose stretch overflowed: the arena (sorted by sub-bucket) holds the slots beyond MSD_FN_CAP.  One
@@ -412,6 +423,14 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 16, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
+    a.probe = 0;
+    const bool probing = ctx->opt.msd_probe != 0;              // every kernel runs its probe variants first (a profiler reads their times)
+    if (probing) {
+        a.probe = 1;
+        hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
+        a.probe = 0;
+    }
     hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag);
     uint32_t tiles2 = 0;
@@ -421,6 +440,13 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 2;
     if (h_flag != 0 || tiles2 == 0) return FBG_OK;
+    if (probing)
+        for (int v : {1, 3}) {
+            a.probe = v;
+            hipLaunchKernelGGL(k_msd_split, dim3(tiles2), dim3(MSD_THREADS), 0, st, a);
+            FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
+            a.probe = 0;
+        }
     hipLaunchKernelGGL(k_msd_split, dim3(tiles2), dim3(MSD_THREADS), 0, st, a);
     // offsets of the sub-buckets in the sorted array: exclusive scan of their sizes
     unsigned long long *wide = reinterpret_cast<unsigned long long *>(ctx->keysA.p);   // scratch: pass 1's slots are dead
@@ -436,6 +462,12 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     }
     const int fshift = g.pb + rest - fbits;
     const uint32_t fmask = (uint32_t)((1u << fbits) - 1);
+    if (probing)
+        for (int v : {1, 3}) {
+            a.probe = v;
+            hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
+            a.probe = 0;
+        }
     hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
     unsigned long long h2[2] = {0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));

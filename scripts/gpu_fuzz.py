@@ -24,7 +24,8 @@ ENVS = [{}, {"FBG_NO_PACKED": "1"}, {"FBG_FORCE_WIDE": "1"}, {"FBG_MSD_MIN": "1"
         {"FBG_GAPPED_RANK": "-1"}, {"FBG_GAPPED_RANK": "-1", "FBG_BP_MIN": "1"}, {"FBG_GAPPED_RANK": "-1", "FBG_MSD_MIN": "1"},
         {"FBG_GAPPED_RANK": "4"}, {"FBG_GAPPED_RANK": "4", "FBG_MSD_MIN": "1"}, {"FBG_GAPPED_RANK": "2"}, {"FBG_GAPPED_RANK": "3"},
         {"FBG_MSD_MIN": "1", "FBG_MSD_SAMPLE_BINS": "1"}, {"FBG_MSD_MIN": "1", "FBG_GAPPED_RANK": "-1", "FBG_MSD_SAMPLE_BINS": "1"},
-        {"FBG_MSD_MIN": "1", "FBG_GAPPED_RANK": "-1"}, {"FBG_MSD_MIN": "1"}]
+        {"FBG_MSD_MIN": "1", "FBG_GAPPED_RANK": "-1"}, {"FBG_MSD_MIN": "1"},
+        {"FBG_SPAN_SCAN": "1"}, {"FBG_SPAN_SCAN": "1"}, {"FBG_SPAN_SCAN": "1", "FBG_MSD_MIN": "1"}, {"FBG_SPAN_SCAN": "-1"}]
 ALL_KEYS = sorted({k for e in ENVS for k in e})
 eng = F.Engine(0)
 parts = [F.Engine(0) for _ in range(3)]

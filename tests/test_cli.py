@@ -18,8 +18,8 @@ REF = os.path.join(ROOT, "oracle", "_ref", "refcmdline")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def run(exe, *args):
-    p = subprocess.run([exe, *args], capture_output=True)
+def run(exe, *args, env=None):
+    p = subprocess.run([exe, *args], capture_output=True, env=None if env is None else {**os.environ, **env})
     return p.returncode, p.stdout, p.stderr.replace(exe.encode(), b"PROG")
 
 
@@ -121,12 +121,16 @@ def test_cli_fixtures_xgfa_bytes(name, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("case", range(7))
 def test_cli_random_xgfa_bytes(case, tmp_path):
     rng = np.random.default_rng(300 + case)
     m, n, kw, ign, notricks = [(6, 200, {}, "", False), (40, 900, dict(similar=0.97, gap_p=0.02, gap_run=6), "", False),
                                (25, 500, dict(similar=0.95, n_p=0.02), "N", False),
-                               (8, 300, dict(gap_p=0.05, gap_run=3), "", True), (300, 400, dict(similar=0.99), "", False)][case]
+                               (8, 300, dict(gap_p=0.05, gap_run=3), "", True), (300, 400, dict(similar=0.99), "", False),
+                               # similar rows WITH gaps: the group-level scan on column spans (span_scan.hip), by the
+                               # library's own choice and forced
+                               (200, 3000, dict(similar=0.99, gap_p=0.003, gap_run=8), "", False),
+                               (120, 2500, dict(similar=0.98, gap_p=0.004, gap_run=5, n_p=0.001), "N", True)][case]
     msa = random_msa(rng, m, n, **kw)
     # every row needs a non-gap character for -p (reference: undefined otherwise, fbg.cpp:1295)
     msa[:, 0] = np.where(msa[:, 0] == ord("-"), ord("A"), msa[:, 0])
@@ -139,7 +143,7 @@ def test_cli_random_xgfa_bytes(case, tmp_path):
         args.append(f"--ignore-chars={ign}")
     if notricks:
         args.append("--disable-elastic-tricks")
-    rc, _, se = run(BIN, *args)
+    rc, _, se = run(BIN, *args, env={"FBG_DEBUG_ENV": "1", "FBG_SPAN_SCAN": "1"} if case == 6 else None)
     f = O.compute_f(msa, ignore=ign, disable_tricks=notricks)
     if notricks and f[0] == n:
         assert rc == 1 and "No valid segmentation found!" in se.decode()
