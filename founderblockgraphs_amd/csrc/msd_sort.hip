@@ -54,7 +54,7 @@ struct MsdArgs {
     unsigned long long *arena_count;
     uint32_t arena_cap;
     unsigned long long *flag;                  // != 0: a capacity was exceeded
-    int probe;                                 // timing probes (option msd_probe): bit 0 no global stores, bit 1 made-up slots instead of loads
+    int probe;                                 // timing probes (option msd_probe): 1 no global stores, 2 made-up slots instead of loads, 16 / 32 non-temporal stores / loads
 };
 
 __device__ __forceinline__ uint64_t msd_probe_word(uint32_t j)
@@ -65,8 +65,10 @@ __device__ __forceinline__ uint64_t msd_probe_word(uint32_t j)
 }
 
 // ranks -> exclusive offsets of the MSD_NB digit counts of a tile; thread d < MSD_NB also reserves the run of digit d
-// behind *cursor (one global atomic per non-empty digit) and leaves its start, relative to the bucket, in gbase[d]
-__device__ __forceinline__ void msd_scan_and_reserve(uint32_t *cnt, uint32_t *loff, unsigned long long *gbase, uint32_t *wsum,
+// behind *cursor (one global atomic per non-empty digit) and leaves its start, relative to the bucket, minus the run's
+// start in the tile, in gdelta[d] (32-bit wrap-around arithmetic: the write-out adds the slot's place in the tile -- one
+// LDS lookup per slot, and these kernels are bound by their LDS operations)
+__device__ __forceinline__ void msd_scan_and_reserve(uint32_t *cnt, uint32_t *loff, uint32_t *gdelta, uint32_t *wsum,
                                                      unsigned long long *cursor_d, bool wide_cursor, uint32_t *cursor32_d)
 {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -82,7 +84,7 @@ __device__ __forceinline__ void msd_scan_and_reserve(uint32_t *cnt, uint32_t *lo
         loff[threadIdx.x] = pre + inc - c;
         unsigned long long g = 0;
         if (c) g = wide_cursor ? atomicAdd(cursor_d, (unsigned long long)c) : (unsigned long long)atomicAdd(cursor32_d, c);
-        gbase[threadIdx.x] = g;
+        gdelta[threadIdx.x] = (uint32_t)g - (pre + inc - c);
     }
     __syncthreads();
 }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
     __shared__ uint64_t buf[MSD_TILE];         // first the symbol codes of the tile (bytes), then the regrouped slots
     __shared__ uint8_t cd[256];
     __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
-    __shared__ unsigned long long gbase[MSD_NB];
+    __shared__ uint32_t gdelta[MSD_NB];
     __shared__ uint32_t wsum[MSD_THREADS / 64];
     uint8_t *tile = reinterpret_cast<uint8_t *>(buf);          // MSD_TILE + 64 bytes
     const int b = a.b, K = a.K;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
         w[i] = (w[i] << a.pb) | p;
     }
     __syncthreads();
-    msd_scan_and_reserve(cnt, loff, gbase, wsum, a.count1 + (threadIdx.x < MSD_NB ? threadIdx.x : 0), true, nullptr);
+    msd_scan_and_reserve(cnt, loff, gdelta, wsum, a.count1 + (threadIdx.x < MSD_NB ? threadIdx.x : 0), true, nullptr);
     const int wshift = a.pb + dshift;
 #pragma unroll
     for (int i = 0; i < MSD_ITEMS; i++)
@@ -130,10 +132,12 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
         if (j < have) {
             const uint64_t x = buf[j];
             const uint32_t d = (uint32_t)(x >> wshift);
-            const uint64_t at = gbase[d] + (j - loff[d]);
+            const uint32_t at = j + gdelta[d];                  // below 2^32: the host checks cap1 + N
             if (a.probe & 1) continue;
-            if (at < a.cap1) a.buf1[(uint64_t)d * a.cap1 + at] = x;
-            else *a.flag = 1;
+            if (at < a.cap1) {
+                if (a.probe & 16) __builtin_nontemporal_store(x, &a.buf1[(uint64_t)d * a.cap1 + at]);
+                else a.buf1[(uint64_t)d * a.cap1 + at] = x;
+            } else if (!a.probe) *a.flag = 1;
         }
     }
 }
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
 {
     __shared__ uint64_t buf[MSD_TILE];
     __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
-    __shared__ unsigned long long gbase[MSD_NB];
+    __shared__ uint32_t gdelta[MSD_NB];
     __shared__ uint32_t wsum[MSD_THREADS / 64];
     // the bucket this tile belongs to: largest s with tile_start[s] <= blockIdx.x
     uint32_t lo = 0, hi = MSD_NB;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        w[r] = j < have ? ((a.probe & 2) ? msd_probe_word(j) : in[j]) : 0ull;
+        w[r] = j < have ? ((a.probe & 2) ? msd_probe_word(j) : (a.probe & 32) ? __builtin_nontemporal_load(in + j) : in[j]) : 0ull;
     }
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
         rk[r] = j < have ? atomicAdd(&cnt[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)], 1u) : 0u;
     }
     __syncthreads();
-    msd_scan_and_reserve(cnt, loff, gbase, wsum, nullptr, false,
+    msd_scan_and_reserve(cnt, loff, gdelta, wsum, nullptr, false,
                          a.count2 + (size_t)seg * MSD_NB + (threadIdx.x < MSD_NB ? threadIdx.x : 0));
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
@@ -197,9 +201,12 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
         if (j < have) {
             const uint64_t x = buf[j];
             const uint32_t d = (uint32_t)(x >> wshift) & (MSD_NB - 1);
-            const uint64_t at = gbase[d] + (j - loff[d]);
+            const uint32_t at = j + gdelta[d];
             if (a.probe & 1) continue;
-            if (at < MSD_FN_CAP) a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at] = x;
+            if (at < MSD_FN_CAP) {
+                if (a.probe & 16) __builtin_nontemporal_store(x, &a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at]);
+                else a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at] = x;
+            } else if (a.probe) continue;
             else {
                 const unsigned long long e = atomicAdd(a.arena_count, 1ull);
                 if (e < a.arena_cap) { a.arena_sb[e] = seg * MSD_NB + d; a.arena_w[e] = x; }
@@ -233,7 +240,7 @@ __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
-        w[r] = j < have ? ((probe & 2) ? msd_probe_word(j) : j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
+        w[r] = j < have ? ((probe & 2) ? msd_probe_word(j) : (probe & 32) ? __builtin_nontemporal_load(in_a + j) : j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -341,7 +348,7 @@ __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, ui
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
-        if (j < have && !(probe & 1)) out[j] = buf[j];
+        if (j < have && !(probe & 1)) { if (probe & 16) __builtin_nontemporal_store(buf[j], out + j); else out[j] = buf[j]; }
     }
 }
 
@@ -392,11 +399,12 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
     const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);   // tests lower it
     if (!g.packed || !g.compact || N < min_n || rest < 1 || ctx->opt.no_msd_sort) return FBG_OK;
+    if (N >= (1ull << 31)) return FBG_OK;                      // places inside a bucket are 32-bit (k_msd_pack_split)
     const int fbits = rest < MSD_FN_BITS ? rest : MSD_FN_BITS;
     // without enough bits for the bins the counting in the finish turns quadratic: leave those to rocPRIM
     if (fbits < 6) return FBG_OK;
     hipStream_t st = ctx->stream;
-    const uint64_t cap1 = N / MSD_NB + N / (4 * MSD_NB) + 65536;
+    const uint64_t cap1 = (N / MSD_NB + N / (4 * MSD_NB) + 65536) & ~15ull;
     const uint64_t nsub = (uint64_t)MSD_NB * MSD_NB;
     if (N / nsub + N / (32 * nsub) + 64 > MSD_FN_CAP) return FBG_OK;        // sub-buckets would not fit their stretches
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)MSD_NB * cap1 * 8));
@@ -425,12 +433,13 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
     a.probe = 0;
     const bool probing = ctx->opt.msd_probe != 0;              // every kernel runs its probe variants first (a profiler reads their times)
-    if (probing) {
-        a.probe = 1;
-        hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
-        FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
-        a.probe = 0;
-    }
+    if (probing)
+        for (int v : {1, 16}) {
+            a.probe = v;
+            hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
+            FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
+            a.probe = 0;
+        }
     hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag);
     uint32_t tiles2 = 0;
@@ -441,7 +450,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     *launches += 2;
     if (h_flag != 0 || tiles2 == 0) return FBG_OK;
     if (probing)
-        for (int v : {1, 3}) {
+        for (int v : {1, 16, 32, 48}) {
             a.probe = v;
             hipLaunchKernelGGL(k_msd_split, dim3(tiles2), dim3(MSD_THREADS), 0, st, a);
             FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
@@ -463,7 +472,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     const int fshift = g.pb + rest - fbits;
     const uint32_t fmask = (uint32_t)((1u << fbits) - 1);
     if (probing)
-        for (int v : {1, 3}) {
+        for (int v : {1, 3, 16, 32, 48}) {
             a.probe = v;
             hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
             a.probe = 0;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *lof
     loff[threadIdx.x] = pre + inc - c;
     unsigned long long g = 0;
     if (c) g = cursor64 ? atomicAdd(cursor64 + threadIdx.x, (unsigned long long)c) : (unsigned long long)atomicAdd(cursor32 + threadIdx.x, c);
-    gbase[threadIdx.x] = g;
+    gbase[threadIdx.x] = g - (pre + inc - c);                  // minus the run's start in the tile: the write-out adds the slot's place (wraps)
     __syncthreads();
 }
 
@@ -232,7 +232,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
         if (j < have) {
             const uint64_t x = sw[j];
             const uint32_t d = MODE == 1 ? sd[j] : pp_t28(a, x) >> 19;       // (MODE 1: the digit travels with the slot; finding it again in loff was nine LDS reads)
-            const uint64_t at = gbase[d] + (j - loff[d]);
+            const uint64_t at = gbase[d] + j;
             if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; if (!a.packed) a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
             else *a.flag = 1;
         }
@@ -304,7 +304,7 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpA
         if (j < have) {
             const uint64_t x = sw[j];
             const uint32_t d = MODE == 1 ? sd[j] : (pp_t28(a, x) >> 10) & (PP_NB - 1);
-            const uint64_t at = gbase[d] + (j - loff[d]);
+            const uint64_t at = gbase[d] + j;
             const uint64_t sb = (uint64_t)seg * PP_NB + d;
             if (at < PP_FN_CAP) { a.w2[sb * PP_FN_CAP + at] = x; if (!a.packed) a.v2[sb * PP_FN_CAP + at] = sv[j]; }
             else {
@@ -463,19 +463,32 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
 #pragma unroll
             for (int r = 0; r < ITEMS; r++) {
                 const uint32_t j = threadIdx.x + r * PP_THREADS;
-                which[r] = -2; turn[r] = 0;
-                if (j < have && bn[r] == bbin) {
-                    which[r] = -1;
+                // (one atomic per wave and counter: hundreds of lanes adding 1 to the same LDS word take a cycle each)
+                const bool inbin = j < have && bn[r] == bbin;
+                which[r] = inbin ? -1 : -2; turn[r] = 0;
+                if (!__ballot(inbin)) continue;                         // (uniform over the wave)
+                const uint32_t wlane = threadIdx.x & 63;
+                const unsigned long long below_me = (1ull << wlane) - 1;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (!act[k]) continue;
-                        if (w[r] < pk[k]) atomicAdd(&pless[k], 1u);
-                        else if (w[r] == pk[k]) { which[r] = k; turn[r] = atomicAdd(&peq[k], 1u); }
+                for (int k = 0; k < 4; k++) {
+                    if (!act[k]) continue;
+                    const bool eq = inbin && w[r] == pk[k];
+                    const unsigned long long mless = __ballot(inbin && w[r] < pk[k]), meq = __ballot(eq);
+                    uint32_t tb = 0;
+                    if (wlane == 0) {
+                        if (mless) atomicAdd(&pless[k], (uint32_t)__popcll(mless));
+                        if (meq) tb = atomicAdd(&peq[k], (uint32_t)__popcll(meq));
                     }
-                    if (which[r] < 0) {                                 // no pivot's copy: into the compact list at the head of the bin's stretch
-                        const uint32_t oi = atomicAdd(&nother, 1u);
-                        sw[b0 + oi] = w[r]; sv[b0 + oi] = v[r];
-                    }
+                    tb = __shfl(tb, 0, 64);
+                    if (eq) { which[r] = k; turn[r] = tb + (uint32_t)__popcll(meq & below_me); }
+                }
+                {   // no pivot's copy: into the compact list at the head of the bin's stretch
+                    const bool other = inbin && which[r] < 0;
+                    const unsigned long long mo = __ballot(other);
+                    uint32_t ob = 0;
+                    if (wlane == 0 && mo) ob = atomicAdd(&nother, (uint32_t)__popcll(mo));
+                    ob = __shfl(ob, 0, 64);
+                    if (other) { const uint32_t oi = ob + (uint32_t)__popcll(mo & below_me); sw[b0 + oi] = w[r]; sv[b0 + oi] = v[r]; }
                 }
             }
             __syncthreads();

@@ -230,38 +230,52 @@ __global__ __launch_bounds__(64) void k_sp_cwin_scan(uint32_t wpr, CWin *__restr
 
 // cell | flags of every text position; a wave takes 64 consecutive positions: the row of the first by binary search,
 // the others count the separators in between
+// A wave walks SPC_CHUNKS stretches of 64 positions: the row of its first position by binary search in the rows' first
+// positions (ten dependent loads -- per stretch of 64 they were most of the kernel's time), from there on by counting the
+// separators passed.
+#define SPC_CHUNKS 8
 __global__ __launch_bounds__(256) void k_sp_cells(const uint32_t *__restrict__ colT, const uint32_t *__restrict__ pos, uint64_t N, uint32_t n, uint32_t m,
                                                   int K, const unsigned long long *__restrict__ ebits, uint32_t *__restrict__ cellT)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t p0 = p - lane;
-    if (p0 >= N) return;
-    const bool in = p < N;
-    uint32_t row, col;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t pw = wave * (64ull * SPC_CHUNKS);           // the wave's first position
+    if (pw >= N) return;
+    uint32_t lo = 0;
     if (colT) {
-        col = in ? colT[p] : n;
-        if (col > n) col = n;
-        uint32_t lo = 0, hi = m;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pos[mid] <= p0) lo = mid; else hi = mid; }
-        const unsigned long long seps = __ballot(col >= n);
-        row = lo + (uint32_t)__popcll(seps & ((1ull << lane) - 1));
-        if (p == N - 1) { row = m; col = n; }                  // the sentinel (as lane 0 of its wave it would pass for the last row's '#')
-    } else {
-        row = (uint32_t)(p / (n + 1));
-        col = (uint32_t)(p - (uint64_t)row * (n + 1));
-        if (p == N - 1) { row = m; col = n; }
+        uint32_t hi = m;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)pos[mid] <= pw) lo = mid; else hi = mid; }
     }
-    if (!in) return;
-    // irregular positions: bit p -> W, bits (p, p + K) -> I
-    const unsigned long long *e = ebits + (p >> 6);
-    const unsigned sh = (unsigned)(p & 63);
-    unsigned long long bits = e[0] >> sh;
-    if (sh) bits |= e[1] << (64 - sh);
-    uint32_t w = (bits & 1ull) ? SP_W : 0u;
-    uint32_t i = ((bits >> 1) & ((1ull << (K - 1)) - 1)) ? SP_I : 0u;
-    if (col >= n) w = i = 0;                                   // '#' / sentinel: no flags (the column says what they are)
-    cellT[p] = (row * (n + 1) + col) | w | i;
+#pragma unroll 2
+    for (int c = 0; c < SPC_CHUNKS; c++) {
+        const uint64_t p0 = pw + 64ull * c;
+        if (p0 >= N) return;
+        const uint64_t p = p0 + lane;
+        const bool in = p < N;
+        uint32_t row, col;
+        if (colT) {
+            col = in ? colT[p] : n;
+            if (col > n) col = n;
+            const unsigned long long seps = __ballot(in && col >= n);
+            row = lo + (uint32_t)__popcll(seps & ((1ull << lane) - 1));
+            lo += (uint32_t)__popcll(seps);
+            if (p == N - 1) { row = m; col = n; }              // the sentinel (it would pass for a row's '#')
+        } else {
+            row = (uint32_t)(p / (n + 1));
+            col = (uint32_t)(p - (uint64_t)row * (n + 1));
+            if (p == N - 1) { row = m; col = n; }
+        }
+        if (!in) return;
+        // irregular positions: bit p -> W, bits (p, p + K) -> I
+        const unsigned long long *e = ebits + (p >> 6);
+        const unsigned sh = (unsigned)(p & 63);
+        unsigned long long bits = e[0] >> sh;
+        if (sh) bits |= e[1] << (64 - sh);
+        uint32_t w = (bits & 1ull) ? SP_W : 0u;
+        uint32_t i = ((bits >> 1) & ((1ull << (K - 1)) - 1)) ? SP_I : 0u;
+        if (col >= n) w = i = 0;                               // '#' / sentinel: no flags (the column says what they are)
+        cellT[p] = (row * (n + 1) + col) | w | i;
+    }
 }
 
 // the values back to text positions (the record path reads them as the suffix array)
@@ -335,7 +349,13 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_groups(S
     const unsigned long long base = a.tile_cnt[blockIdx.x] + before;
     uint32_t gid = (uint32_t)base - 1;                        // group of the slot before the thread's first (wraps for slot 0: unused)
     uint32_t iat = (uint32_t)(base >> 32);
-    uint32_t acc = 0, prow, pcol;
+    // The flags of a group are the OR over its members.  A group of hundreds of members runs over dozens of threads, and
+    // every one of them adding its bits with an atomic of its own made a chain of same-address atomics per group: the part
+    // a thread holds of the group it starts in (lead) and of the group it ends in (acc, group gid) meet inside the wave --
+    // the groups' numbers rise from lane to lane -- and the last lane of a group's stretch adds them once.
+    const uint32_t gid_first = gid;
+    uint32_t acc = 0, lead = 0, prow, pcol;
+    bool led = false;
     sp_decode(a, v[0], prow, pcol);
 #pragma unroll
     for (int j = 0; j < SP_ITEMS; j++) {
@@ -345,7 +365,8 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_groups(S
         sp_decode(a, v[j + 1], row, col);
         const bool sep = col >= a.n;
         if ((heads >> j) & 1u) {
-            if (acc) atomicOr(&a.gflags[gid], acc);
+            if (!led) { lead = acc; led = true; }
+            else if (acc) atomicOr(&a.gflags[gid], acc);          // a group that starts and ends inside the thread's slots
             acc = 0;
             gid++;
             a.gstart[gid] = (uint32_t)k;
@@ -359,7 +380,18 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_groups(S
         }
         pcol = col;
     }
-    if (acc) atomicOr(&a.gflags[gid], acc);
+    const uint32_t lane = threadIdx.x & 63;
+    if (lane == 0 && lead) atomicOr(&a.gflags[gid_first], lead);  // (the group goes on from the wave before)
+    uint32_t nlead = __shfl_down(lead, 1, 64);                    // the next lane's part of the group this one ends in
+    if (lane == 63) nlead = 0;
+    uint32_t x = acc | nlead;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ox = __shfl_up(x, d, 64), og = __shfl_up(gid, d, 64);
+        if ((int)lane >= d && og == gid) x |= ox;
+    }
+    const uint32_t ng = __shfl_down(gid, 1, 64);
+    if ((lane == 63 || ng != gid) && x) atomicOr(&a.gflags[gid], x);
 }
 
 // ---- runs: maximal stretches of groups whose members all have the same one-column span ---------------------------
@@ -917,7 +949,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
 // memory -- a dozen dependent round trips per group -- so the waves per SIMD count: at 2 (256 registers) it took 31 ms for
 // 1000 x 200 000, at 3 (168 registers, a few spills) 21 ms, at 4 (128, 42 spills) 23 ms
 template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
-void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
+void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
 {
     constexpr int CAP = SPP_ROWS * 32;
     __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
@@ -931,7 +963,16 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;       // B: 16 lanes per pair, 8 bytes each
     const uint32_t sub8 = lane >> 3, sl8 = lane & 7;      // A: 8 lanes per mate, 16 bytes each
-    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+    // The list is in column order and the groups are handed out one by one (a ticket), so that the groups in flight are
+    // neighbours: a text line holds 128 columns of a row, and what a group reads its neighbours read again -- out of the
+    // XCD's L2 when they run at the same time, out of memory when the workgroups each walk a stride of the whole list
+    __shared__ uint32_t s_e;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_e = (uint32_t)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const uint32_t e = s_e;
+        if (e >= count) break;
         const uint32_t g = list[e];
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
         __syncthreads();
@@ -1211,7 +1252,7 @@ int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches)
         hipLaunchKernelGGL(k_sp_cwin_scan, dim3((unsigned)m), dim3(64), 0, st, wpr, ctx->sp_cwin.as<CWin>());
         *launches += 2;
     }
-    hipLaunchKernelGGL(k_sp_cells, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, ctx->gapfree ? (const uint32_t *)nullptr : ctx->colT.as<uint32_t>(),
+    hipLaunchKernelGGL(k_sp_cells, dim3(fbg_blocks(N, 256 * SPC_CHUNKS)), dim3(256), 0, st, ctx->gapfree ? (const uint32_t *)nullptr : ctx->colT.as<uint32_t>(),
                        ctx->pos.as<uint32_t>(), N, (uint32_t)n, (uint32_t)m, g.K, ctx->gbits.as<unsigned long long>(), ctx->sp_cells.as<uint32_t>());
     *launches += 1;
     FBG_HIP_TRY(ctx, hipGetLastError());
@@ -1251,9 +1292,10 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     // the odd groups of up to 1024 members: one kernel, everything; the larger ones (more than 1024 rows): pure interval and
     // lists (k_sp_odd), the chains (k_sp_chain), every pair where that does not do (k_sp_odd_slow)
     // (workgroups that stay and take group after group: a workgroup per group spent more time being launched than working)
-    if (cnts[0]) hipLaunchKernelGGL((k_sp_odd_pairs<2, 0>), dim3(std::min<uint32_t>(cnts[0], 8192u)), dim3(SP_THREADS), 0, st, a, lists[0], cnts[0]);
-    if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 3072u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1]);
-    if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 3072u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2]);
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 12, 0, 4 * sizeof(unsigned long long), st));        // the tickets
+    if (cnts[0]) hipLaunchKernelGGL((k_sp_odd_pairs<2, 0>), dim3(std::min<uint32_t>(cnts[0], 8192u)), dim3(SP_THREADS), 0, st, a, lists[0], cnts[0], a.counters + 12);
+    if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 3072u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1], a.counters + 13);
+    if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 3072u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2], a.counters + 14);
     *launches += 3;
     ctx->sp_chain_n = 0; ctx->sp_slow_n = 0;
     if (n_small) {
