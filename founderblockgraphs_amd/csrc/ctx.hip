@@ -218,6 +218,13 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (strcmp(key, "span_irregular") == 0) { *value = (int64_t)ctx->sp_n_irr; return FBG_OK; }
     if (strcmp(key, "span_chain") == 0) { *value = (int64_t)ctx->sp_chain_n; return FBG_OK; }
     if (strcmp(key, "span_slow_groups") == 0) { *value = (int64_t)ctx->sp_slow_n; return FBG_OK; }
+    if (strncmp(key, "span_dbg", 8) == 0 && key[8] >= '0' && key[8] <= '7' && !key[9]) {   // debug builds (SP_PHASE_TIMERS): cycles per phase of k_sp_odd_pairs
+        unsigned long long v = 0;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || ctx->scalars.cap < 256 * 8 ||
+            hipMemcpy(&v, (const unsigned long long *)ctx->scalars.p + 208 + 24 + (key[8] - '0'), 8, hipMemcpyDeviceToHost) != hipSuccess) return FBG_ERR_HIP;
+        *value = (int64_t)v;
+        return FBG_OK;
+    }
     if (strcmp(key, "index_kind") == 0) {      // read-only: which form the current index has
         *value = !ctx->index_valid ? -1 : ctx->part_active ? 3 : ctx->granked ? 2 : ctx->ranked ? 1 : 0;
         return FBG_OK;

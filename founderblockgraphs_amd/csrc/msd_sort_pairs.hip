@@ -54,6 +54,7 @@ struct PpArgs {
     const uint64_t *ebits;                     // pairs: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
     const uint32_t *payload;                   // pairs, MODE 1: the value of position p is payload[p] (span_scan.hip: cell | flags), not p
     int any_order;                             // MODE 1: slots with equal keys may come out in any order (the consumer works on groups of equal keys)
+    int probe;                                 // timing probes of k_pp_finish (option msd_probe): 1 copy only, 2 no pass over the crowded bins, 4 no counting
     // MODE 1 finish: bins from the symbols behind the prefix a sub-bucket's keys share, every symbol code replaced by its
     // rank among the FREQUENT symbols (rb bits; 0: bins from sampled keys instead).  rtab: ew bits per code = the rank;
     // mtab: 2 bits per code = 0 a frequent symbol, 1 / 2 a rare one below / above the frequent symbol whose rank it shares
@@ -377,6 +378,14 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         w[r] = j < have ? (j < n_a ? wa[j] : wb[j - n_a]) : ~0ull;
         v[r] = (j < have && !a.packed) ? (j < n_a ? va[j] : vb[j - n_a]) : 0u;
     }
+    if (a.probe & 1) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * PP_THREADS;
+            if (j < have) { wout[j] = w[r]; if (!a.packed) vout[j] = v[r]; }
+        }
+        return;
+    }
     if (MODE == 1 && a.rb == 0) {
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
@@ -448,7 +457,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         for (uint32_t i = threadIdx.x; i < PP_FBINS; i += PP_THREADS)
             if (cnt[i] > PP_CROWD) biglist2[atomicAdd(&nbig2, 1u)] = i;
         __syncthreads();
-        const uint32_t nb2 = nbig2;
+        const uint32_t nb2 = (a.probe & 2) ? 0u : nbig2;
         for (uint32_t e = 0; e < nb2; e++) {                            // uniform over the workgroup
             const uint32_t bbin = biglist2[e], b0 = loff[bbin], c = cnt[bbin];
             if (threadIdx.x < 4) { pv[threadIdx.x] = sw[b0 + (threadIdx.x * c) / 4]; pless[threadIdx.x] = 0; peq[threadIdx.x] = 0; }
@@ -565,7 +574,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) {
-            const uint32_t b0 = rb0[r], c = rc[r];
+            const uint32_t b0 = rb0[r], c = (a.probe & 4) ? 0u : rc[r];
             uint32_t smaller = 0;
             // (four loads in flight: a bin of thousands -- keys with a rare symbol at the edge of a sub-bucket share one
             // number -- is a long loop, and one load at a time made such a workgroup the tail of the launch)
@@ -679,6 +688,7 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
     a.ebits = (MODE == 1 && !g.wide && !g.packed && g.K <= 32) ? ctx->grs_ebits : nullptr;
     a.payload = (MODE == 1 && !g.wide && !g.packed) ? ctx->sort_payload : nullptr;
     a.any_order = a.payload ? 1 : 0;
+    a.probe = 0;
     const bool any = MODE == 1 && a.any_order;
     a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
     a.count1 = ctx->dp_a.as<unsigned long long>();
@@ -725,6 +735,15 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
         FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)nsub * 4));
         unsigned long long *later_count = flag + 3;
         FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
+        if (any && ctx->opt.msd_probe) {
+            for (int v : {1, 2, 4, 6}) {
+                a.probe = v;
+                hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+                                   later_count);
+                FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
+            }
+            a.probe = 0;
+        }
         if (any) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
                                     later_count);
         else hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, false>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),

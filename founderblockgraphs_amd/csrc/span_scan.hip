@@ -966,16 +966,26 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
     // The list is in column order and the groups are handed out one by one (a ticket), so that the groups in flight are
     // neighbours: a text line holds 128 columns of a row, and what a group reads its neighbours read again -- out of the
     // XCD's L2 when they run at the same time, out of memory when the workgroups each walk a stride of the whole list
+    // (a ticket is good for a few groups: the small groups are done faster than same-address atomics follow each other)
+    constexpr uint32_t BATCH = SPP_ROWS <= 2 ? 16u : 1u;
     __shared__ uint32_t s_e;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_e = (uint32_t)atomicAdd(ticket, 1ull);
+        if (threadIdx.x == 0) s_e = (uint32_t)atomicAdd(ticket, (unsigned long long)BATCH);
         __syncthreads();
-        const uint32_t e = s_e;
-        if (e >= count) break;
+        const uint32_t e0 = s_e;
+        if (e0 >= count) break;
+      for (uint32_t e = e0; e < e0 + BATCH && e < count; e++) {
         const uint32_t g = list[e];
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
         __syncthreads();
+#ifdef SP_PHASE_TIMERS
+        long long tph[7];
+        tph[0] = clock64();
+#define SP_T(k) tph[k] = clock64()
+#else
+#define SP_T(k)
+#endif
         if (s > CAP || s <= MINS) continue;                    // (another instance's)
         if (threadIdx.x == 0) { n_odd = 0; s_need = 0; ntl = 0; }
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
@@ -998,6 +1008,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             }
         }
         __syncthreads();
+        SP_T(1);
         const uint32_t no = n_odd;
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
         const uint64_t key = a.keys[s0];
@@ -1022,6 +1033,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             }
             if (__ballot(reg_major) && (threadIdx.x & 63) == 0) sp_update(a, x, major + step);
         }
+        SP_T(2);
         if (no > SPP_MAXO) {                                   // many odd members (a deletion common to many rows): k_sp_odd_slow
             if (threadIdx.x == 0) {
                 const unsigned long long at = atomicAdd(&a.counters[7], 1ull);
@@ -1052,6 +1064,13 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
         }
         for (uint32_t o = wv * 4 + sub; o < no; o += SP_THREADS / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
         __syncthreads();
+#ifdef SP_PHASE_TIMERS
+        { uint64_t acc = 0;
+#pragma unroll
+          for (int r = 0; r < SPP_ROWS; r++) acc ^= mlo[r] ^ mhi[r];
+          if (acc == 0x123456789abcdefull) a.counters[31] = 1; }   // (the loads have landed)
+#endif
+        SP_T(3);
         auto note = [&](uint32_t o, uint32_t u, uint32_t Lbeyond) {   // the match of odd member o with member u beyond the key
             const uint32_t L = fbg_clamp_lcp(Lbeyond + (uint32_t)a.K);
             const uint32_t ou = omap[u];
@@ -1093,6 +1112,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             if (lane == 0 && mymax) { atomicMax(&omn[o], mymax); oany[o] = 1; }
         }
         __syncthreads();
+        SP_T(4);
         // -- B: the pairs that match beyond the first window: window after window, ALL of them at once -- a thread takes 8
         // bytes of a pair, the pair's first differing byte is the minimum over its 16 threads (32 pairs at a time, each waiting
         // for its own round trip, took a quarter of the kernel)
@@ -1122,6 +1142,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             if (!more) break;
         }
         __syncthreads();
+        SP_T(5);
         // -- C: the columns of the odd members' spans outside the pure interval, a thread per (odd member, column)
         // g at column x: the majority members count everywhere but at their own column
         auto g_at = [&](uint32_t o, uint32_t x) -> uint32_t {
@@ -1166,6 +1187,15 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
                 sp_update(a, major, sp_extent(a, sp[i], row, gv, sp_first_ignore(a, sp[i], sp_reach(a, sp[i], row, gv))));
             }
         }
+#ifdef SP_PHASE_TIMERS
+        __syncthreads();
+        SP_T(6);
+        if (threadIdx.x == 0 && SPP_ROWS == 28) {
+            for (int k = 0; k < 6; k++) atomicAdd(&a.counters[24 + k], (unsigned long long)(tph[k + 1] - tph[k]));
+            atomicAdd(&a.counters[30], 1ull);
+        }
+#endif
+      }
     }
 }
 
@@ -1293,6 +1323,9 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     // lists (k_sp_odd), the chains (k_sp_chain), every pair where that does not do (k_sp_odd_slow)
     // (workgroups that stay and take group after group: a workgroup per group spent more time being launched than working)
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 12, 0, 4 * sizeof(unsigned long long), st));        // the tickets
+#ifdef SP_PHASE_TIMERS
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 24, 0, 8 * sizeof(unsigned long long), st));
+#endif
     if (cnts[0]) hipLaunchKernelGGL((k_sp_odd_pairs<2, 0>), dim3(std::min<uint32_t>(cnts[0], 8192u)), dim3(SP_THREADS), 0, st, a, lists[0], cnts[0], a.counters + 12);
     if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 3072u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1], a.counters + 13);
     if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 3072u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2], a.counters + 14);

@@ -1,5 +1,5 @@
 """Star phylogeny 1000 x 200000 with 2 % gap cells in runs of 8 (bench.py's other_workloads[1]) alone: step time, stages,
-which scan ran.  usage: python scripts/gpu_stargaps.py [reps] [span_scan option]"""
+which scan ran.  usage: python scripts/gpu_stargaps.py [reps] [span_scan option] [key=value ...]"""
 import json
 import os
 import sys
@@ -30,6 +30,9 @@ for i0 in range(0, m, 50):
 d = d.reshape(-1)
 with F.Engine(0) as eng:
     eng.set_option("span_scan", opt)
+    for kv in sys.argv[3:]:                                   # further debug options: key=value
+        k, val = kv.split("=")
+        eng.set_option(k, int(val))
     d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
     d_b = torch.empty(n + 1, dtype=torch.int64, device="cuda")
     eng.msa_set_device(d.data_ptr(), m, n)
@@ -46,3 +49,5 @@ with F.Engine(0) as eng:
                           "span": eng.get_option("span_scan_used"), "work": eng.get_option("span_scan_work"), "G": eng.get_option("span_groups"), "odd": eng.get_option("span_odd_groups"), "irr": eng.get_option("span_irregular"), "chain": eng.get_option("span_chain"), "slow": eng.get_option("span_slow_groups"), "dp_kind": eng.get_option("dp_kind"),
                           "stages": {k: round(v[0], 2) for k, v in eng.stage_ms().items()},
                           "f_sum": int(d_f.sum())}), flush=True)
+        if os.environ.get("FBG_PHASES"):                      # a library built with -DSP_PHASE_TIMERS: cycles of k_sp_odd_pairs<28,64> per phase
+            print("phases", [eng.get_option(f"span_dbg{k}") for k in range(7)], flush=True)
