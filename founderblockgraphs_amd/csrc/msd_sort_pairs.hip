@@ -30,6 +30,7 @@
 #define PP_BIG_CAP 9216                        // largest sub-bucket (k_pp_finish_big)
 #define PP_ARENA (1u << 20)
 #define PP_FN_SMALL 3072                      // LDS capacity of the finish variant for sparsely filled stretches (k_pp_finish)
+#define PP_FN_TINY 2048                       // ... and of the one for stretches filled to a fifth (similar rows, texts of 2 * 10^8 symbols: four workgroups per CU)
 #define PP_CROWD 160                           // MODE 1 finish: a bin of more slots than this is split once more
 
 struct PpArgs {
@@ -515,7 +516,7 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
             __syncthreads();
         }
     }
-    if (MODE == 1 && CAP != PP_FN_SMALL && !ANY) {                        // (not in the variant most sub-buckets go through: it costs that one 2 ms)
+    if (MODE == 1 && CAP > PP_FN_SMALL && !ANY) {                        // (not in the variant most sub-buckets go through: it costs that one 2 ms)
         __shared__ uint32_t nbig, biglist[CAP / PP_CROWD + 1], sub[256];
         __shared__ unsigned long long kmin, kmax;
         if (threadIdx.x == 0) nbig = 0;
@@ -735,6 +736,8 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
         FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)nsub * 4));
         unsigned long long *later_count = flag + 3;
         FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
+        // (any order, stretches filled to a fifth: the variant with room for PP_FN_TINY slots)
+        const bool tiny = any && MODE == 1 && total / nsub + total / (4 * nsub) <= PP_FN_TINY / 2;
         if (any && ctx->opt.msd_probe) {
             for (int v : {1, 2, 4, 6}) {
                 a.probe = v;
@@ -743,8 +746,15 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
                 FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
             }
             a.probe = 0;
+            if (tiny) {                                        // the small variant's time beside the tiny one's
+                hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+                                   later_count);
+                FBG_HIP_TRY(ctx, hipMemsetAsync(later_count, 0, 8, st));
+            }
         }
-        if (any) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+        if (tiny) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_TINY, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
+                                     later_count);
+        else if (any) hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, MODE == 1>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
                                     later_count);
         else hipLaunchKernelGGL((k_pp_finish<MODE, PP_FN_SMALL, false>), dim3((unsigned)nsub), dim3(PP_THREADS), 0, st, a, (const uint32_t *)nullptr, ctx->ps_a.as<uint32_t>(),
                                 later_count);

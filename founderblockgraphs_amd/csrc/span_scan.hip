@@ -948,7 +948,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
 // (up to 1024); an instance takes the groups of more than MINS members that it has room for.  What the kernel waits for is
 // memory -- a dozen dependent round trips per group -- so the waves per SIMD count: at 2 (256 registers) it took 31 ms for
 // 1000 x 200 000, at 3 (168 registers, a few spills) 21 ms, at 4 (128, 42 spills) 23 ms
-template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
+template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS)
 void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
 {
     constexpr int CAP = SPP_ROWS * 32;
@@ -962,7 +962,6 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
     __shared__ uint32_t n_odd, ntl, s_gv, s_need, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;       // B: 16 lanes per pair, 8 bytes each
-    const uint32_t sub8 = lane >> 3, sl8 = lane & 7;      // A: 8 lanes per mate, 16 bytes each
     // The list is in column order and the groups are handed out one by one (a ticket), so that the groups in flight are
     // neighbours: a text line holds 128 columns of a row, and what a group reads its neighbours read again -- out of the
     // XCD's L2 when they run at the same time, out of memory when the workgroups each walk a stride of the whole list
@@ -1051,25 +1050,9 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
         for (uint32_t i = threadIdx.x; i < no * SPP_MAXO; i += SP_THREADS) LQ[i / SPP_MAXO][i % SPP_MAXO] = 0;
         __syncthreads();
         if (!s_need) continue;
-        // -- the 128 bytes behind the key of every member -> registers; of the odd members -> LDS
-        uint64_t mlo[SPP_ROWS], mhi[SPP_ROWS];
-        uint32_t valid = 0, narrow = 0;                        // per row: the lane's mate exists / is a member of the majority
-#pragma unroll
-        for (int r = 0; r < SPP_ROWS; r++) {
-            const uint32_t u = (uint32_t)r * 32 + wv * 8 + sub8;
-            const bool ex = (uint32_t)r * 32 < s && u < s;
-            mlo[r] = ex ? sp_load8(a, (uint64_t)sp[u] + a.K + 16 * sl8) : 0ull;
-            mhi[r] = ex ? sp_load8(a, (uint64_t)sp[u] + a.K + 16 * sl8 + 8) : 0ull;
-            if (ex) { valid |= 1u << r; if (omap[u] == 0xffffu) narrow |= 1u << r; }
-        }
+        // -- the 128 bytes behind the key of the odd members -> LDS
         for (uint32_t o = wv * 4 + sub; o < no; o += SP_THREADS / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
         __syncthreads();
-#ifdef SP_PHASE_TIMERS
-        { uint64_t acc = 0;
-#pragma unroll
-          for (int r = 0; r < SPP_ROWS; r++) acc ^= mlo[r] ^ mhi[r];
-          if (acc == 0x123456789abcdefull) a.counters[31] = 1; }   // (the loads have landed)
-#endif
         SP_T(3);
         auto note = [&](uint32_t o, uint32_t u, uint32_t Lbeyond) {   // the match of odd member o with member u beyond the key
             const uint32_t L = fbg_clamp_lcp(Lbeyond + (uint32_t)a.K);
@@ -1080,36 +1063,54 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
                 if (!at_major_of(o)) atomicMax(&nbest[u], L);
             } else LQ[o][ou] = L;
         };
-        // -- A: every odd member against the registers
-        for (uint32_t o = 0; o < no; o++) {
-            const bool own = own_of(o);
-            const bool atm = at_major_of(o);
-            if (!own && (atm || !has_narrow)) continue;        // (uniform over the workgroup)
-            const uint32_t q = oidx[o];
-            const uint64_t qlo = qwin[o][2 * sl8], qhi = qwin[o][2 * sl8 + 1];
-            const uint32_t rows_live = own ? valid : (valid & narrow);
-            uint32_t mymax = 0;                                // the lane's longest match with a member of the majority
+        // -- A: a lane takes a member: the 128 bytes behind its key into the lane's registers (17 aligned words, shifted
+        // into place), then every odd member's window (LDS, the same word for all lanes) against them.  (Sixteen bytes of a
+        // member in each of eight lanes, all members of the group in registers at once, was the round's first version: a
+        // third of the kernel's time went into finding the first difference across lanes, ~40 instructions per row of 32
+        // members for two XORs of payload, and 168 registers held the kernel to 3 waves per SIMD.)
+        for (uint32_t u = threadIdx.x; u < ((s + SP_THREADS - 1) / SP_THREADS) * SP_THREADS; u += SP_THREADS) {
+            const bool ex = u < s;
+            uint64_t m[16];
+            {
+                const uint64_t p = ex ? (uint64_t)sp[u] + a.K : 0ull;
+                const uint64_t *w = reinterpret_cast<const uint64_t *>(a.T) + (p >> 3);
+                const uint64_t words = (a.N + 64) >> 3;         // the text buffer: N + 64 bytes, zero padded
+                const unsigned sh = (unsigned)(p & 7) * 8;
+                uint64_t x[17];
 #pragma unroll
-            for (int r = 0; r < SPP_ROWS; r++) {
-                if ((uint32_t)r * 32 >= s) break;              // (uniform)
-                const uint32_t u = (uint32_t)r * 32 + wv * 8 + sub8;
-                const bool live = ((rows_live >> r) & 1u) && u != q;
-                const uint64_t dlo = mlo[r] ^ qlo, dhi = mhi[r] ^ qhi;
-                const uint32_t seg = (uint32_t)(__ballot(!live || (dlo | dhi) != 0) >> (8 * sub8)) & 0xffu;
-                if (live && seg && sl8 == (uint32_t)__ffs(seg) - 1) {     // the lane that holds the first difference
-                    const uint32_t L = (uint32_t)a.K + 16 * sl8 + (dlo ? ((uint32_t)__ffsll((unsigned long long)dlo) - 1) / 8 : 8 + ((uint32_t)__ffsll((unsigned long long)dhi) - 1) / 8);
-                    if ((narrow >> r) & 1u) { mymax = max(mymax, L); if (!atm) atomicMax(&nbest[u], L); }
-                    else LQ[o][omap[u]] = L;
+                for (int i = 0; i < 17; i++) x[i] = (ex && (p >> 3) + i < words) ? w[i] : 0ull;
+#pragma unroll
+                for (int i = 0; i < 16; i++) m[i] = sh ? (x[i] >> sh) | (x[i + 1] << (64 - sh)) : x[i];
+            }
+            const bool narrow_u = ex && omap[u] == 0xffffu;
+            uint32_t my_nbest = 0;
+            for (uint32_t o = 0; o < no; o++) {
+                const bool own = own_of(o);
+                const bool atm = at_major_of(o);
+                if (!own && (atm || !has_narrow)) continue;    // (uniform over the workgroup)
+                const bool live = ex && (own || narrow_u) && u != oidx[o];
+                uint32_t L = SP_WIN;                           // first differing byte (SP_WIN: none in the window)
+#pragma unroll
+                for (int i = 15; i >= 0; i--) {
+                    const uint64_t d = m[i] ^ qwin[o][i];
+                    if (d) L = 8 * (uint32_t)i + ((uint32_t)__ffsll((unsigned long long)d) - 1) / 8;
                 }
-                if (live && !seg && sl8 == 0) {
+                uint32_t mymax = 0;                            // the lane's match with a member of the majority
+                if (live && L < SP_WIN) {
+                    const uint32_t Lk = (uint32_t)a.K + L;
+                    if (narrow_u) { mymax = Lk; if (!atm) my_nbest = max(my_nbest, Lk); }
+                    else LQ[o][omap[u]] = Lk;
+                }
+                if (live && L >= SP_WIN) {
                     const uint32_t at = atomicAdd(&ntl, 1u);
                     if (at < SPP_TAILS) tl[at] = o << 16 | u;
-                    else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[q] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
+                    else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[oidx[o]] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
                 }
-            }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor(mymax, d, 64));
-            if (lane == 0 && mymax) { atomicMax(&omn[o], mymax); oany[o] = 1; }
+                for (int d = 32; d >= 1; d >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor(mymax, d, 64));
+                if (lane == 0 && mymax) { atomicMax(&omn[o], mymax); oany[o] = 1; }
+            }
+            if (my_nbest) atomicMax(&nbest[u], my_nbest);
         }
         __syncthreads();
         SP_T(4);
