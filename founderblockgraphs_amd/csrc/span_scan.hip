@@ -948,17 +948,20 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
 // (up to 1024); an instance takes the groups of more than MINS members that it has room for.  What the kernel waits for is
 // memory -- a dozen dependent round trips per group -- so the waves per SIMD count: at 2 (256 registers) it took 31 ms for
 // 1000 x 200 000, at 3 (168 registers, a few spills) 21 ms, at 4 (128, 42 spills) 23 ms
-template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS)
-void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
+template <int SPP_ROWS, int MINS> __device__ __forceinline__
+void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
 {
     constexpr int CAP = SPP_ROWS * 32;
+    // the small groups (up to 64 members): a wave per group -- four times the groups in flight for the same registers
+    constexpr uint32_t NT = SPP_ROWS <= 2 ? 64u : (uint32_t)SP_THREADS;
+    constexpr uint32_t NTAILS = SPP_ROWS <= 2 ? 256u : (uint32_t)SPP_TAILS;
     __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
     __shared__ uint16_t omap[CAP];
     __shared__ uint16_t oidx[SPP_MAXO];
     __shared__ uint32_t olo[SPP_MAXO], ohi[SPP_MAXO], omn[SPP_MAXO], oany[SPP_MAXO], ogmax[SPP_MAXO], oign[SPP_MAXO];
     __shared__ uint32_t LQ[SPP_MAXO][SPP_MAXO];
     __shared__ uint64_t qwin[SPP_MAXO][16];
-    __shared__ uint32_t tl[SPP_TAILS], tmin[SPP_TAILS];
+    __shared__ uint32_t tl[NTAILS], tmin[NTAILS];
     __shared__ uint32_t n_odd, ntl, s_gv, s_need, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;       // B: 16 lanes per pair, 8 bytes each
@@ -987,13 +990,41 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
 #endif
         if (s > CAP || s <= MINS) continue;                    // (another instance's)
         if (threadIdx.x == 0) { n_odd = 0; s_need = 0; ntl = 0; }
-        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
+        for (uint32_t i = threadIdx.x; i < s; i += NT) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
         __syncthreads();
+        // the members' text positions: the loads of a thread's (up to four) members go out together, before the votes on the
+        // majority column, instead of one dependent round trip per member after them
+        constexpr int PER = (CAP + NT - 1) / NT;
+        uint32_t mrow[PER], mcol[PER], mbase[PER];
+        CWin mwin[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t i = threadIdx.x + (uint32_t)j * NT;
+            mrow[j] = 0; mcol[j] = 0; mbase[j] = 0; mwin[j] = CWin{0, 0, 0, 0, 0};
+            if (i < s) {
+                sp_decode(a, sv[i], mrow[j], mcol[j]);
+                if (a.cwin && mrow[j] < a.m && mcol[j] < a.n) { mbase[j] = a.pos[mrow[j]]; mwin[j] = a.cwin[(size_t)mrow[j] * a.wpr + (mcol[j] >> 7)]; }
+            }
+        }
         const uint32_t major = sp_major(a, sv, s, votes);
-        for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
-            uint32_t row, col;
-            sp_decode(a, sv[i], row, col);
-            const uint32_t p = sp_pos(a, row, col);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint32_t i = threadIdx.x + (uint32_t)j * NT;
+            if (i >= s) continue;
+            const uint32_t row = mrow[j], col = mcol[j];
+            uint32_t p;
+            if (a.cwin && row < a.m && col < a.n) {                // (sp_pos with the window already here)
+                const uint32_t o = col & 127u;
+                const uint32_t bits[4] = {mwin[j].b0, mwin[j].b1, mwin[j].b2, mwin[j].b3};
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t lo = 32u * q;
+                    if (o >= lo + 32) cnt += (uint32_t)__popc(bits[q]);
+                    else if (o > lo) cnt += (uint32_t)__popc(bits[q] & ((1u << (o - lo)) - 1));
+                }
+                p = mbase[j] + mwin[j].rank0 + cnt;
+            } else p = sp_pos(a, row, col);
             sp[i] = p;
             if ((sv[i] & SP_W) || col != major) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
@@ -1023,7 +1054,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             // the regular members of the majority column all reach the same column: one update for them (hundreds of atomic
             // maxima on one address cost more than everything else the group needs)
             bool reg_major = false;
-            for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+            for (uint32_t i = threadIdx.x; i < s; i += NT) {
                 uint32_t row, col;
                 sp_decode(a, sv[i], row, col);
                 if (!(sv[i] & SP_I) && col == major) { reg_major = true; continue; }
@@ -1047,11 +1078,11 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             omn[o] = 0; oany[o] = 0; ogmax[o] = 0; oign[o] = SP_NONE;
             if (own_of(o) || (!at_major_of(o) && has_narrow)) s_need = 1;
         }
-        for (uint32_t i = threadIdx.x; i < no * SPP_MAXO; i += SP_THREADS) LQ[i / SPP_MAXO][i % SPP_MAXO] = 0;
+        for (uint32_t i = threadIdx.x; i < no * SPP_MAXO; i += NT) LQ[i / SPP_MAXO][i % SPP_MAXO] = 0;
         __syncthreads();
         if (!s_need) continue;
         // -- the 128 bytes behind the key of the odd members -> LDS
-        for (uint32_t o = wv * 4 + sub; o < no; o += SP_THREADS / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
+        for (uint32_t o = wv * 4 + sub; o < no; o += NT / 16) qwin[o][sl] = sp_load8(a, (uint64_t)sp[oidx[o]] + a.K + 8 * sl);
         __syncthreads();
         SP_T(3);
         auto note = [&](uint32_t o, uint32_t u, uint32_t Lbeyond) {   // the match of odd member o with member u beyond the key
@@ -1068,7 +1099,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
         // member in each of eight lanes, all members of the group in registers at once, was the round's first version: a
         // third of the kernel's time went into finding the first difference across lanes, ~40 instructions per row of 32
         // members for two XORs of payload, and 168 registers held the kernel to 3 waves per SIMD.)
-        for (uint32_t u = threadIdx.x; u < ((s + SP_THREADS - 1) / SP_THREADS) * SP_THREADS; u += SP_THREADS) {
+        for (uint32_t u = threadIdx.x; u < ((s + NT - 1) / NT) * NT; u += NT) {
             const bool ex = u < s;
             uint64_t m[16];
             {
@@ -1089,12 +1120,15 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
                 const bool atm = at_major_of(o);
                 if (!own && (atm || !has_narrow)) continue;    // (uniform over the workgroup)
                 const bool live = ex && (own || narrow_u) && u != oidx[o];
-                uint32_t L = SP_WIN;                           // first differing byte (SP_WIN: none in the window)
+                // the first differing word (descending: the lowest one wins), its first differing byte once at the end
+                uint64_t dd = 0;
+                uint32_t wi = 16;
 #pragma unroll
                 for (int i = 15; i >= 0; i--) {
                     const uint64_t d = m[i] ^ qwin[o][i];
-                    if (d) L = 8 * (uint32_t)i + ((uint32_t)__ffsll((unsigned long long)d) - 1) / 8;
+                    if (d) { dd = d; wi = (uint32_t)i; }
                 }
+                const uint32_t L = wi < 16 ? 8 * wi + ((uint32_t)__ffsll((unsigned long long)dd) - 1) / 8 : SP_WIN;   // SP_WIN: none in the window
                 uint32_t mymax = 0;                            // the lane's match with a member of the majority
                 if (live && L < SP_WIN) {
                     const uint32_t Lk = (uint32_t)a.K + L;
@@ -1103,7 +1137,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
                 }
                 if (live && L >= SP_WIN) {
                     const uint32_t at = atomicAdd(&ntl, 1u);
-                    if (at < SPP_TAILS) tl[at] = o << 16 | u;
+                    if (at < NTAILS) tl[at] = o << 16 | u;
                     else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[oidx[o]] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
                 }
 #pragma unroll
@@ -1117,21 +1151,34 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
         // -- B: the pairs that match beyond the first window: window after window, ALL of them at once -- a thread takes 8
         // bytes of a pair, the pair's first differing byte is the minimum over its 16 threads (32 pairs at a time, each waiting
         // for its own round trip, took a quarter of the kernel)
-        const uint32_t nt = min(ntl, (uint32_t)SPP_TAILS);
+        const uint32_t nt = min(ntl, (uint32_t)NTAILS);
         for (uint32_t off = SP_WIN; nt > 0; off += SP_WIN) {
-            for (uint32_t t = threadIdx.x; t < nt; t += SP_THREADS) tmin[t] = SP_NONE;
+            for (uint32_t t = threadIdx.x; t < nt; t += NT) tmin[t] = SP_NONE;
             if (threadIdx.x == 0) s_gv = 0;                    // (pairs still open after this window)
             __syncthreads();
-            for (uint32_t idx = threadIdx.x; idx < nt * 16; idx += SP_THREADS) {
-                const uint32_t t = idx >> 4, piece = idx & 15, ent = tl[t];
-                if (ent == SP_NONE) continue;                  // settled in an earlier window
-                const uint64_t qx = sp_load8(a, (uint64_t)sp[oidx[ent >> 16]] + a.K + off + 8 * piece);
-                const uint64_t x = sp_load8(a, (uint64_t)sp[ent & 0xffffu] + a.K + off + 8 * piece);
-                const uint64_t diff = x ^ qx;
-                if (diff) atomicMin(&tmin[t], 8 * piece + ((uint32_t)__ffsll((unsigned long long)diff) - 1) / 8);
+            // (four pieces per thread and turn, their loads out together: one piece per turn was one round trip per turn,
+            // a dozen turns per window for the ~200 pairs of a group)
+            for (uint32_t idx0 = threadIdx.x; idx0 < nt * 16; idx0 += 4 * NT) {
+                uint64_t diff[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t idx = idx0 + (uint32_t)j * NT;
+                    diff[j] = 0;
+                    if (idx < nt * 16) {
+                        const uint32_t ent = tl[idx >> 4], piece = idx & 15;
+                        if (ent != SP_NONE)                    // (else: settled in an earlier window)
+                            diff[j] = sp_load8(a, (uint64_t)sp[ent & 0xffffu] + a.K + off + 8 * piece) ^
+                                      sp_load8(a, (uint64_t)sp[oidx[ent >> 16]] + a.K + off + 8 * piece);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t idx = idx0 + (uint32_t)j * NT;
+                    if (diff[j]) atomicMin(&tmin[idx >> 4], 8 * (idx & 15) + ((uint32_t)__ffsll((unsigned long long)diff[j]) - 1) / 8);
+                }
             }
             __syncthreads();
-            for (uint32_t t = threadIdx.x; t < nt; t += SP_THREADS) {
+            for (uint32_t t = threadIdx.x; t < nt; t += NT) {
                 const uint32_t ent = tl[t];
                 if (ent == SP_NONE) continue;
                 if (tmin[t] != SP_NONE) { note(ent >> 16, ent & 0xffffu, off + tmin[t]); tl[t] = SP_NONE; }
@@ -1153,7 +1200,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
             return best + 1;                                                             // 1656 (a partner exists: x is outside the pure interval)
         };
         for (int pass = 0; pass < 2; pass++) {
-            for (uint32_t idx = threadIdx.x; idx < no * 64; idx += SP_THREADS) {
+            for (uint32_t idx = threadIdx.x; idx < no * 64; idx += NT) {
                 const uint32_t o = idx >> 6;
                 if (!own_of(o)) continue;
                 uint32_t qrow, qcol;
@@ -1180,7 +1227,7 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
         }
         // -- the members of the majority column where some odd member is not coloured there
         if (has_narrow && !(plo <= major && major <= phi)) {
-            for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
+            for (uint32_t i = threadIdx.x; i < s; i += NT) {
                 uint32_t row, col;
                 sp_decode(a, sv[i], row, col);
                 if (omap[i] != 0xffffu || nbest[i] == 0) continue;
@@ -1198,6 +1245,17 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
 #endif
       }
     }
+}
+
+template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
+void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
+{
+    sp_odd_pairs_body<SPP_ROWS, MINS>(a, list, count, ticket);
+}
+// the groups of up to 64 members: a wave per group
+__global__ __launch_bounds__(64) void k_sp_odd_pairs_small(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
+{
+    sp_odd_pairs_body<2, 0>(a, list, count, ticket);
 }
 
 // With the tricks off a row that has ended keeps its '#' as the pointer: gg > tot, fi = n (fbg.cpp:1659-1664) for every
@@ -1327,7 +1385,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
 #ifdef SP_PHASE_TIMERS
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 24, 0, 8 * sizeof(unsigned long long), st));
 #endif
-    if (cnts[0]) hipLaunchKernelGGL((k_sp_odd_pairs<2, 0>), dim3(std::min<uint32_t>(cnts[0], 8192u)), dim3(SP_THREADS), 0, st, a, lists[0], cnts[0], a.counters + 12);
+    if (cnts[0]) hipLaunchKernelGGL(k_sp_odd_pairs_small, dim3(std::min<uint32_t>(cnts[0], 16384u)), dim3(64), 0, st, a, lists[0], cnts[0], a.counters + 12);
     if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 3072u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1], a.counters + 13);
     if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 3072u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2], a.counters + 14);
     *launches += 3;
