@@ -802,6 +802,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
     const uint32_t sub = lane >> 4, sl = lane & 15;            // mate of the wave's four, place in its 128-byte window
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
         const uint32_t g = list[e];
+        if (e > 0 && list[e - 1] == g) continue;               // (the big groups' list is sorted: a group that several chains gave up on is in it once per chain)
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
         __syncthreads();
         if (s > CAP) continue;                                 // (flagged by k_sp_odd_spans)
@@ -933,21 +934,21 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
     }
 }
 
-// ---- the odd groups of up to 1024 members: everything in one workgroup, the mates' texts in registers ---------------
+// ---- the odd groups of up to 1024 members: everything in one workgroup, a lane per member ----------------------------
 // What made the kernel above slow is not the bytes but the waiting: every odd member walks its mates again, two or three
-// dependent rounds of scattered loads per 64 mates, one odd member after the other.  Here the 128 bytes behind the key of
-// EVERY member are loaded once, in one batch (a lane holds 16 bytes of each of up to 32 mates: 8 lanes per mate, eight
-// mates per wave and row), and the odd members -- up to SPP_MAXO of them; a group with more goes to the slow list -- are
-// compared with them from registers (A).  The pairs that match beyond those 128 bytes (7 % when the rows differ in 1 % of
-// their symbols) are listed and walked together, 32 pairs' loads in flight (B).  Then every (odd member, column) of the
-// spans gets a thread (C).
+// dependent rounds of scattered loads per 64 mates, one odd member after the other.  Here every member gets a lane: the
+// 128 bytes behind its key are loaded into the lane's registers, once, and the odd members -- up to SPP_MAXO of them; a
+// group with more goes to the slow list -- are compared with them, their windows read from LDS (A).  The pairs that match
+// beyond those 128 bytes (7 % when the rows differ in 1 % of their symbols) are listed and walked together, window after
+// window (B).  Then every (odd member, column) of the spans gets a thread (C).
 #define SPP_MAXO 32
 #define SPP_TAILS 1024
-// SPP_ROWS: rows of 32 members (4 waves x 8 mates per wave and row, 16 bytes of a mate per lane) the registers hold: 2 (the
-// small groups, more than half of the odd ones: few registers, many workgroups per compute unit), 28 (896 members) or 32
-// (up to 1024); an instance takes the groups of more than MINS members that it has room for.  What the kernel waits for is
-// memory -- a dozen dependent round trips per group -- so the waves per SIMD count: at 2 (256 registers) it took 31 ms for
-// 1000 x 200 000, at 3 (168 registers, a few spills) 21 ms, at 4 (128, 42 spills) 23 ms
+// SPP_ROWS * 32: the members an instance has room for in LDS (values, positions, best matches): 64 (the small groups, more
+// than half of the odd ones: one wave per group, k_sp_odd_pairs_small), 896 or 1024; an instance takes the groups of more
+// than MINS members that it has room for.  What the kernel waits for is memory -- some twenty dependent steps per group,
+// 75 us -- so the groups in flight count: 5 workgroups per CU at 95 registers and 30 KB of LDS.  (The round's first
+// version kept ALL members' windows in registers, 16 bytes of a member in each of eight lanes: 168 registers, 3 workgroups
+// per CU, and a third of its time in the instructions that find a first difference across lanes: 17 ms against 10.6.)
 template <int SPP_ROWS, int MINS> __device__ __forceinline__
 void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
 {
@@ -1274,6 +1275,14 @@ __global__ void k_sp_fill_ends(SpArgs a)
     if (x < a.n) a.fmax[x] = a.n;
 }
 
+__global__ void k_sp_count_heads(const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ out)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool head = e < count && (e == 0 || list[e - 1] != list[e]);
+    const unsigned long long mask = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(out, (unsigned long long)__popcll(mask));
+}
+
 template <class F> static int sp_with_tmp(fbg_ctx *ctx, F &&call)
 {
     size_t bytes = 0;
@@ -1310,7 +1319,7 @@ static void sp_args(fbg_ctx *ctx, SpArgs &a, int disable_tricks)
     a.counters = ctx->scalars.as<unsigned long long>() + 208;     // (gapped_rank.hip: 128 .. 202)
     a.code = ctx->small.as<uint8_t>() + 2048;                     // (fbg_key_setup's table)
     a.chain = ctx->sp_chain.as<SpChain>(); a.chain_cap = (uint32_t)(ctx->sp_chain.cap / sizeof(SpChain));
-    a.slow = ctx->sp_slow.as<uint32_t>(); a.slow_cap = (uint32_t)(ctx->sp_slow.cap / 4);
+    a.slow = ctx->sp_slow.as<uint32_t>(); a.slow_cap = (uint32_t)(ctx->sp_slow.cap / 8);    // (the other half: the big groups' list, sorted)
     a.mins32 = ctx->gapfree ? nullptr : ctx->sp_mins.as<uint32_t>();
 }
 
@@ -1374,7 +1383,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     // the larger groups' odd members: a list for those that are coloured alone, a list of the groups that need every pair compared
     const uint64_t members = h[3];
     FBG_TRY(fbg_reserve(ctx, ctx->sp_chain, (members + 1) * sizeof(SpChain)));
-    FBG_TRY(fbg_reserve(ctx, ctx->sp_slow, ((uint64_t)n_small + n_big + members + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->sp_slow, ((uint64_t)n_small + n_big + members + 1) * 4 * 2));     // (second half: the big groups' list, sorted)
     sp_args(ctx, a, disable_tricks);
     hipLaunchKernelGGL(k_sp_values, dim3(fbg_blocks(G, 256)), dim3(256), 0, st, a);
     if (a.n_irr) hipLaunchKernelGGL(k_sp_irr, dim3(fbg_blocks(a.n_irr, 256)), dim3(256), 0, st, a);
@@ -1418,7 +1427,25 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
         if (h[1] != 0) return FBG_OK;
         const uint32_t n_slow = (uint32_t)h[5];
         ctx->sp_chain_n = n_chain; ctx->sp_slow_n = n_slow;
-        if (n_slow) hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow);
+        if (n_slow) {
+            // A group is in the list once per chain that gave up on it: sorted, the kernel takes every group once.  And it
+            // compares every odd member of a group with every mate, window after window -- a millisecond and more per group
+            // of a thousand rows that go along for thousands of symbols: beyond a few such groups per 10^6 suffixes the
+            // record path is the cheaper one (the option span_scan = 1 insists)
+            uint32_t *sorted = a.slow + a.slow_cap;
+            FBG_TRY(sp_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+                return rocprim::radix_sort_keys(tmp, bytes, (const uint32_t *)a.slow, sorted, (size_t)n_slow, 0u, 32u, st);
+            }));
+            FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 15, 0, 8, st));
+            hipLaunchKernelGGL(k_sp_count_heads, dim3(fbg_blocks(n_slow, 256)), dim3(256), 0, st, (const uint32_t *)sorted, n_slow, a.counters + 15);
+            unsigned long long uniq = 0;
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(&uniq, a.counters + 15, 8, hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            ctx->sp_slow_n = (uint32_t)uniq;
+            if (ctx->opt.span_scan != 1 && uniq > ctx->N / (1ull << 20) + 4) return FBG_OK;
+            hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)sorted, n_slow);
+            *launches += 3;
+        }
         *launches += 4;
     }
     if (disable_tricks) {

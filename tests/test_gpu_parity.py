@@ -1337,6 +1337,37 @@ def test_span_scan_matches_oracle(engine, case):
                 assert bad.size == 0, (case, ignore, tricks_off, bad[:8].tolist(), got[bad[:8]].tolist(), ref[bad[:8]].tolist())
 
 
+def test_span_scan_leaves_many_large_slow_groups_to_the_record_path(engine):
+    """More than 1024 identical rows with a few gap runs: every group of the first columns has all its members odd (the
+    rows' first symbols) and its chains give up -- thousands of list entries for a few hundred groups, each a second of
+    all-pairs comparisons.  By its own choice the library hands such an input to the record path (span_scan_used 0);
+    with span_scan = 1 it insists, takes every listed group once, and is still exact (fbg.cpp:1579-1695)."""
+    import time
+    import founderblockgraphs_amd as F
+    rng = np.random.default_rng(424243)
+    m, n = 1030, 1200
+    anc = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+    msa = np.tile(anc, (m, 1))
+    for i, j in np.argwhere(rng.random((m, n)) < 0.002):
+        msa[i, j:j + 5] = ord("-")
+    msa[:, 0] = anc[0]
+    f_on, f_off = O.compute_f(msa), O.compute_f(msa, disable_tricks=True)
+    for forced in (0, 1):
+        with fbg_options(engine, {"span_scan": forced}):
+            t0 = time.time()
+            for tricks_off, ref in ((False, f_on), (True, f_off)):
+                try:
+                    got = engine.elastic_f(msa, disable_efg_tricks=tricks_off)
+                    assert (got == ref).all(), (forced, tricks_off, np.flatnonzero(got != ref)[:8].tolist())
+                except F.NoSegmentation:
+                    assert tricks_off and ref[0] == n
+            if forced:
+                assert engine.get_option("span_scan_used") == 1
+            else:
+                assert engine.get_option("span_slow_groups") <= engine.get_option("span_groups")
+                assert time.time() - t0 < 5.0, time.time() - t0
+
+
 def test_span_scan_through_a_group_and_at_scale():
     """(a) the host-buffer group API on a star phylogeny with gaps: two members on one device -- the key-range partitions
     decline such rows, the members scan column shards of the group-level index -- equals the oracle; (b) a text large
