@@ -1,5 +1,6 @@
 """Star phylogeny 1000 x 200000 with 2 % gap cells in runs of 8 (bench.py's other_workloads[1]) alone: step time, stages,
-which scan ran.  usage: python scripts/gpu_stargaps.py [reps] [span_scan option] [key=value ...]"""
+which scan ran.  usage: python scripts/gpu_stargaps.py [reps] [span_scan option] [key=value ...]
+FBG_STAR_ROWS / FBG_STAR_COLS in the environment: another shape (e.g. more than 1024 rows: the big-group kernels)."""
 import json
 import os
 import sys
@@ -12,7 +13,7 @@ import founderblockgraphs_amd as F
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 opt = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-m, n = 1000, 200_000
+m, n = int(os.environ.get("FBG_STAR_ROWS", 1000)), int(os.environ.get("FBG_STAR_COLS", 200_000))
 g = torch.Generator(device="cuda").manual_seed(7)
 anc = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.uint8)
 d = torch.empty((m, n), dtype=torch.uint8, device="cuda")
