@@ -791,13 +791,13 @@ __global__ void k_sp_chain(SpArgs a, uint32_t count, int pass)
 
 #define SP_WIN 128u
 
-template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(SpArgs a, const uint32_t *__restrict__ list, uint32_t count)
+template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t min_size)
 {
     __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
     __shared__ uint16_t omap[CAP];                             // member -> its place in the odd list (0xffff: a member of the majority)
     __shared__ uint16_t oidx[SP_MAX_ODD];
     __shared__ uint32_t olo[SP_MAX_ODD], ohi[SP_MAX_ODD], Lq[SP_MAX_ODD];
-    __shared__ uint32_t n_odd, s_mn, s_any, s_gmax, s_ign, votes[8];
+    __shared__ uint32_t n_odd, n_col, s_mn, s_any, s_gmax, s_ign, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;            // mate of the wave's four, place in its 128-byte window
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
@@ -805,8 +805,8 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
         if (e > 0 && list[e - 1] == g) continue;               // (the big groups' list is sorted: a group that several chains gave up on is in it once per chain)
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
         __syncthreads();
-        if (s > CAP) continue;                                 // (flagged by k_sp_odd_spans)
-        if (threadIdx.x == 0) n_odd = 0;
+        if (s > CAP || s <= min_size) continue;                // (flagged by k_sp_odd_spans / another instance's)
+        if (threadIdx.x == 0) { n_odd = 0; n_col = 0; }
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
         __syncthreads();
         const uint32_t major = sp_major(a, sv, s, votes);
@@ -815,19 +815,21 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
             sp_decode(a, sv[i], row, col);
             const uint32_t p = sp_pos(a, row, col);
             sp[i] = p;
-            if ((sv[i] & SP_W) || col != major) {
+            uint32_t lo = col, hi = col;                        // (odd: as in k_sp_odd_pairs)
+            if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+            if (col != major || lo != col || hi != col) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
+                if (lo <= hi) atomicAdd(&n_col, 1u);
                 if (o < SP_MAX_ODD) {
                     oidx[o] = (uint16_t)i;
                     omap[i] = (uint16_t)o;
-                    uint32_t lo = col, hi = col;
-                    if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
                     olo[o] = lo; ohi[o] = hi;
                 }
             }
         }
         __syncthreads();
         const uint32_t no = n_odd;
+        if (no == s && n_col == 0) continue;                   // nobody is ever coloured (the first symbols of rows, tricks on): nothing to say
         if (no > SP_MAX_ODD) { if (threadIdx.x == 0) a.counters[3] = 1; continue; }
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
         const bool has_narrow = no < s;
@@ -963,7 +965,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
     __shared__ uint32_t LQ[SPP_MAXO][SPP_MAXO];
     __shared__ uint64_t qwin[SPP_MAXO][16];
     __shared__ uint32_t tl[NTAILS], tmin[NTAILS];
-    __shared__ uint32_t n_odd, ntl, s_gv, s_need, votes[8];
+    __shared__ uint32_t n_odd, n_col, ntl, s_gv, s_need, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;       // B: 16 lanes per pair, 8 bytes each
     // The list is in column order and the groups are handed out one by one (a ticket), so that the groups in flight are
@@ -990,57 +992,85 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
 #define SP_T(k)
 #endif
         if (s > CAP || s <= MINS) continue;                    // (another instance's)
-        if (threadIdx.x == 0) { n_odd = 0; s_need = 0; ntl = 0; }
+        if (threadIdx.x == 0) { n_odd = 0; n_col = 0; s_need = 0; ntl = 0; }
         for (uint32_t i = threadIdx.x; i < s; i += NT) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
         __syncthreads();
-        // the members' text positions: the loads of a thread's (up to four) members go out together, before the votes on the
-        // majority column, instead of one dependent round trip per member after them
-        constexpr int PER = (CAP + NT - 1) / NT;
-        uint32_t mrow[PER], mcol[PER], mbase[PER];
-        CWin mwin[PER];
+        uint32_t major;
+        if constexpr (CAP <= 1024) {
+            // the members' text positions: the loads of a thread's (up to four) members go out together, before the votes on the
+            // majority column, instead of one dependent round trip per member after them
+            constexpr int PER = (CAP + NT - 1) / NT;
+            uint32_t mrow[PER], mcol[PER], mbase[PER];
+            CWin mwin[PER];
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t i = threadIdx.x + (uint32_t)j * NT;
-            mrow[j] = 0; mcol[j] = 0; mbase[j] = 0; mwin[j] = CWin{0, 0, 0, 0, 0};
-            if (i < s) {
-                sp_decode(a, sv[i], mrow[j], mcol[j]);
-                if (a.cwin && mrow[j] < a.m && mcol[j] < a.n) { mbase[j] = a.pos[mrow[j]]; mwin[j] = a.cwin[(size_t)mrow[j] * a.wpr + (mcol[j] >> 7)]; }
-            }
-        }
-        const uint32_t major = sp_major(a, sv, s, votes);
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint32_t i = threadIdx.x + (uint32_t)j * NT;
-            if (i >= s) continue;
-            const uint32_t row = mrow[j], col = mcol[j];
-            uint32_t p;
-            if (a.cwin && row < a.m && col < a.n) {                // (sp_pos with the window already here)
-                const uint32_t o = col & 127u;
-                const uint32_t bits[4] = {mwin[j].b0, mwin[j].b1, mwin[j].b2, mwin[j].b3};
-                uint32_t cnt = 0;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t lo = 32u * q;
-                    if (o >= lo + 32) cnt += (uint32_t)__popc(bits[q]);
-                    else if (o > lo) cnt += (uint32_t)__popc(bits[q] & ((1u << (o - lo)) - 1));
+            for (int j = 0; j < PER; j++) {
+                const uint32_t i = threadIdx.x + (uint32_t)j * NT;
+                mrow[j] = 0; mcol[j] = 0; mbase[j] = 0; mwin[j] = CWin{0, 0, 0, 0, 0};
+                if (i < s) {
+                    sp_decode(a, sv[i], mrow[j], mcol[j]);
+                    if (a.cwin && mrow[j] < a.m && mcol[j] < a.n) { mbase[j] = a.pos[mrow[j]]; mwin[j] = a.cwin[(size_t)mrow[j] * a.wpr + (mcol[j] >> 7)]; }
                 }
-                p = mbase[j] + mwin[j].rank0 + cnt;
-            } else p = sp_pos(a, row, col);
-            sp[i] = p;
-            if ((sv[i] & SP_W) || col != major) {
-                const uint32_t o = atomicAdd(&n_odd, 1u);
-                if (o < SPP_MAXO) {
-                    oidx[o] = (uint16_t)i;
-                    omap[i] = (uint16_t)o;
-                    uint32_t lo = col, hi = col;
-                    if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
-                    olo[o] = lo; ohi[o] = hi;
+            }
+            major = sp_major(a, sv, s, votes);
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const uint32_t i = threadIdx.x + (uint32_t)j * NT;
+                if (i >= s) continue;
+                const uint32_t row = mrow[j], col = mcol[j];
+                uint32_t p;
+                if (a.cwin && row < a.m && col < a.n) {                // (sp_pos with the window already here)
+                    const uint32_t o = col & 127u;
+                    const uint32_t bits[4] = {mwin[j].b0, mwin[j].b1, mwin[j].b2, mwin[j].b3};
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t lo = 32u * q;
+                        if (o >= lo + 32) cnt += (uint32_t)__popc(bits[q]);
+                        else if (o > lo) cnt += (uint32_t)__popc(bits[q] & ((1u << (o - lo)) - 1));
+                    }
+                    p = mbase[j] + mwin[j].rank0 + cnt;
+                } else p = sp_pos(a, row, col);
+                sp[i] = p;
+                // odd: another column than the majority's, or a span that is not just its column (a W member whose span
+                // IS its column -- a row's first symbol at column 0 with the tricks off -- is a member like any other)
+                uint32_t lo = col, hi = col;
+                if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+                if (col != major || lo != col || hi != col) {
+                    const uint32_t o = atomicAdd(&n_odd, 1u);
+                    if (lo <= hi) atomicAdd(&n_col, 1u);
+                    if (o < SPP_MAXO) {
+                        oidx[o] = (uint16_t)i;
+                        omap[i] = (uint16_t)o;
+                        olo[o] = lo; ohi[o] = hi;
+                    }
+                }
+            }
+        } else {                                               // (the instances for more than 1024 members: one member at a time)
+            major = sp_major(a, sv, s, votes);
+            for (uint32_t i = threadIdx.x; i < s; i += NT) {
+                uint32_t row, col;
+                sp_decode(a, sv[i], row, col);
+                const uint32_t p = sp_pos(a, row, col);
+                sp[i] = p;
+                // odd: another column than the majority's, or a span that is not just its column (a W member whose span
+                // IS its column -- a row's first symbol at column 0 with the tricks off -- is a member like any other)
+                uint32_t lo = col, hi = col;
+                if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+                if (col != major || lo != col || hi != col) {
+                    const uint32_t o = atomicAdd(&n_odd, 1u);
+                    if (lo <= hi) atomicAdd(&n_col, 1u);
+                    if (o < SPP_MAXO) {
+                        oidx[o] = (uint16_t)i;
+                        omap[i] = (uint16_t)o;
+                        olo[o] = lo; ohi[o] = hi;
+                    }
                 }
             }
         }
         __syncthreads();
         SP_T(1);
         const uint32_t no = n_odd;
+        if (no == s && n_col == 0) continue;                   // nobody is ever coloured (the first symbols of more than SPP_MAXO rows, tricks on): nothing to say
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
         const uint64_t key = a.keys[s0];
         const bool has_narrow = no < s;
@@ -1253,6 +1283,12 @@ void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count,
 {
     sp_odd_pairs_body<SPP_ROWS, MINS>(a, list, count, ticket);
 }
+// the groups of more than 1024 members (LDS, not registers, limits the workgroups per CU)
+template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS)
+void k_sp_odd_pairs_big(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
+{
+    sp_odd_pairs_body<SPP_ROWS, MINS>(a, list, count, ticket);
+}
 // the groups of up to 64 members: a wave per group
 __global__ __launch_bounds__(64) void k_sp_odd_pairs_small(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
 {
@@ -1394,25 +1430,42 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
 #ifdef SP_PHASE_TIMERS
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 24, 0, 8 * sizeof(unsigned long long), st));
 #endif
+    const bool big_chains = ctx->opt.span_scan == 3;           // (debug: the groups of more than 1024 members by chains along the later keys' groups)
     if (cnts[0]) hipLaunchKernelGGL(k_sp_odd_pairs_small, dim3(std::min<uint32_t>(cnts[0], 16384u)), dim3(64), 0, st, a, lists[0], cnts[0], a.counters + 12);
     if (cnts[1]) hipLaunchKernelGGL((k_sp_odd_pairs<28, 64>), dim3(std::min<uint32_t>(cnts[1], 3072u)), dim3(SP_THREADS), 0, st, a, lists[1], cnts[1], a.counters + 13);
     if (cnts[2]) hipLaunchKernelGGL((k_sp_odd_pairs<32, 896>), dim3(std::min<uint32_t>(cnts[2], 3072u)), dim3(SP_THREADS), 0, st, a, lists[2], cnts[2], a.counters + 14);
+    if (n_big && !big_chains) {
+        // more than 1024 rows: the same kernel with room for 2048 / 4096 / 8192 members (3 / 2 / 1 workgroups per CU); every
+        // instance walks the list of the large groups and takes those of its size
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, 2 * sizeof(unsigned long long), st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 15, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL((k_sp_odd_pairs_big<64, 1024>), dim3(std::min<uint32_t>(n_big, 1024u)), dim3(SP_THREADS), 0, st, a, lists[3], n_big, a.counters + 15);
+        hipLaunchKernelGGL((k_sp_odd_pairs_big<128, 2048>), dim3(std::min<uint32_t>(n_big, 512u)), dim3(SP_THREADS), 0, st, a, lists[3], n_big, a.counters + 0);
+        hipLaunchKernelGGL((k_sp_odd_pairs_big<256, 4096>), dim3(std::min<uint32_t>(n_big, 256u)), dim3(SP_THREADS), 0, st, a, lists[3], n_big, a.counters + 1);
+        *launches += 3;
+    }
     *launches += 3;
     ctx->sp_chain_n = 0; ctx->sp_slow_n = 0;
-    if (n_small) {
-        // its groups with more odd members than it takes: every pair the slow way
+    if (n_small || (n_big && !big_chains)) {
+        // the groups with more odd members than that kernel takes: every pair the slow way
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         if (h[1] != 0) return FBG_OK;
         const uint32_t n_slow = (uint32_t)h[5];
         ctx->sp_slow_n = n_slow;
+        // (a large group on the slow list -- more odd members than the kernel above takes: a deletion in dozens of a few
+        // thousand rows, the first symbols of more than a thousand identical rows -- is tens of milliseconds of all-pairs
+        // comparisons: beyond a few of them per 10^6 suffixes the record path is the cheaper one; span_scan = 1 insists)
+        if (n_big && !big_chains && ctx->opt.span_scan != 1 && n_slow > ctx->N / (1ull << 20) + 4) return FBG_OK;
         if (n_slow) {
-            hipLaunchKernelGGL((k_sp_odd_slow<1024>), dim3(std::min<uint32_t>(n_slow, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow);
-            *launches += 1;
+            hipLaunchKernelGGL((k_sp_odd_slow<1024>), dim3(std::min<uint32_t>(n_slow, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow, 0u);
+            if (n_big && !big_chains)
+                hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow, 1024u);
+            *launches += 2;
         }
         FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 7, 0, 8, st));
     }
-    if (n_big) {
+    if (n_big && big_chains) {
         hipLaunchKernelGGL((k_sp_odd<8192>), dim3(std::min<uint32_t>(n_big, 1u << 16)), dim3(SP_THREADS), 0, st, a, lists[3], n_big);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1442,8 +1495,8 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
             FBG_HIP_TRY(ctx, hipMemcpyAsync(&uniq, a.counters + 15, 8, hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
             ctx->sp_slow_n = (uint32_t)uniq;
-            if (ctx->opt.span_scan != 1 && uniq > ctx->N / (1ull << 20) + 4) return FBG_OK;
-            hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)sorted, n_slow);
+            if (ctx->opt.span_scan != 1 && ctx->opt.span_scan != 3 && uniq > ctx->N / (1ull << 20) + 4) return FBG_OK;
+            hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)sorted, n_slow, 0u);
             *launches += 3;
         }
         *launches += 4;

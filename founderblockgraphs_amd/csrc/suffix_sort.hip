@@ -904,7 +904,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     // rows that resemble each other (twins among the keys of a sample; option span_scan = 1: whatever the rows): the
     // group-level scan on column spans (span_scan.hip), whose sort carries cells instead of positions
     bool try_span = fbg_span_eligible(ctx, g);
-    if (try_span && ctx->opt.span_scan != 1) {
+    if (try_span && ctx->opt.span_scan != 1 && ctx->opt.span_scan != 3) {
         bool similar = false;
         FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
         try_span = similar;

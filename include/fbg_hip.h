@@ -88,7 +88,8 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   gapped_rank also takes 2 (no flag bits in the sort's values), 3 (flag bits, no threshold), 4 (threshold forced: tests)
  *   span_scan          MSAs with gaps / ignore characters whose rows resemble each other take the group-level scan on
  *                      column spans (span_scan.hip); 1: every such MSA takes it, -1: none, 2: as 0, and the sorted slots
- *                      are checked to be the cells in key order (debugging)
+ *                      are checked to be the cells in key order (debugging), 3: as 1, with the groups of more than 1024
+ *                      members worked off by chains along the later keys' groups (the earlier method, kept for tests)
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
  * gap-free MSA, 2 scan in suffix order of an MSA with gaps / ignore characters (slot by slot, or -- "span_scan_used" = 1 --
  * group by group), 3 one partition of a partitioned index.  "span_groups", "span_odd_groups", "span_irregular",

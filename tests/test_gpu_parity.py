@@ -1337,6 +1337,21 @@ def test_span_scan_matches_oracle(engine, case):
                 assert bad.size == 0, (case, ignore, tricks_off, bad[:8].tolist(), got[bad[:8]].tolist(), ref[bad[:8]].tolist())
 
 
+def test_span_scan_large_groups_by_chains(engine):
+    """Groups of more than 1024 members through the chains along the later keys' groups (option span_scan = 3: the path
+    the large instances of k_sp_odd_pairs replaced as the default) -- same f (fbg.cpp:1579-1695)."""
+    kw = dict(SPAN_CASES[10])
+    m, n = kw.pop("m"), kw.pop("n")
+    assert m > 1024
+    msa = star_msa(np.random.default_rng(9010), m, n, **kw)
+    f_on, f_off = O.compute_f(msa), O.compute_f(msa, disable_tricks=True)
+    with fbg_options(engine, {"span_scan": 3}):
+        for tricks_off, ref in ((False, f_on), (True, f_off)):
+            got = engine.elastic_f(msa, disable_efg_tricks=tricks_off)
+            assert (got == ref).all(), (tricks_off, np.flatnonzero(got != ref)[:8].tolist())
+        assert engine.get_option("span_scan_used") == 1
+
+
 def test_span_scan_leaves_many_large_slow_groups_to_the_record_path(engine):
     """More than 1024 identical rows with a few gap runs: every group of the first columns has all its members odd (the
     rows' first symbols) and its chains give up -- thousands of list entries for a few hundred groups, each a second of
