@@ -1304,6 +1304,9 @@ SPAN_CASES = [
     dict(m=3, n=64, gap_cells=0.2, gap_run=2, lead=5),
     dict(m=1100, n=1500, gap_cells=0.02, gap_run=6, shared=0.1),         # groups of more than 1024 members: the chains, the slow list
     dict(m=900, n=2500, gap_cells=0.02, gap_run=8, sub=0.003),           # groups of 897 .. 1024 members
+    dict(m=2100, n=800, gap_cells=0.01, gap_run=6),                      # groups of 1025 .. 2048 members (k_sp_odd_pairs_big<64, 1024>)
+    dict(m=3000, n=400, gap_cells=0.005, gap_run=5, sub=0.002),          # ... 2049 .. 4096 members
+    dict(m=4500, n=250, gap_cells=0.004, gap_run=4, sub=0.001),          # ... 4097 .. 8192 members (one workgroup per CU)
 ]
 
 
@@ -1387,7 +1390,7 @@ def test_span_scan_through_a_group_and_at_scale():
     """(a) the host-buffer group API on a star phylogeny with gaps: two members on one device -- the key-range partitions
     decline such rows, the members scan column shards of the group-level index -- equals the oracle; (b) a text large
     enough that the sample of the sort decides by itself (2^22 symbols and more) and the three-pass sample sort carries the
-    cells: equal to the record path's f."""
+    cells: equal to the record path's f; (c) the same for 2000 rows."""
     import founderblockgraphs_amd as F
     rng = np.random.default_rng(515)
     msa = star_msa(rng, 150, 9000, gap_cells=0.02, gap_run=8)
@@ -1404,6 +1407,16 @@ def test_span_scan_through_a_group_and_at_scale():
             b = e.elastic_f(big)
             assert e.get_option("span_scan_used") == 0
         assert np.array_equal(a, b)
+        # (c) more than 1024 rows: groups of 1025 .. 2048 members (k_sp_odd_pairs_big<64, 1024>), the first symbols of 2000
+        # rows in one group (nobody coloured with the tricks on, everybody a regular member with the tricks off)
+        tall = star_msa(rng, 2000, 12000, gap_cells=0.02, gap_run=8)        # 2.4e7 symbols
+        for tricks_off in (False, True):
+            a = e.elastic_f(tall, disable_efg_tricks=tricks_off)
+            assert e.get_option("span_scan_used") == 1
+            with e.options(span_scan=-1):
+                b = e.elastic_f(tall, disable_efg_tricks=tricks_off)
+                assert e.get_option("span_scan_used") == 0
+            assert np.array_equal(a, b), tricks_off
 
 
 def test_span_scan_decline_hands_the_record_path_a_suffix_array(engine):
