@@ -1,6 +1,7 @@
 """Randomised parity campaign for the group-level scan on column spans (span_scan.hip; option span_scan = 1 takes it whatever
 the input): star phylogenies and noisy copies with gap runs, deletions shared by many rows, rows that start late / end
-early, ignore characters, small alphabets (repeats: stray suffixes in the groups), 1 .. 1300 rows; f with the elastic
+early, ignore characters, small alphabets (repeats: stray suffixes in the groups), 1 .. 1300 rows (FBG_FUZZ_TALL=1: a
+quarter of the cases with 2100 .. 6000 rows); f with the elastic
 tricks on and off against the oracle.  Usage: gpu_fuzz_span.py SECONDS [SEED]; exits non-zero on the first mismatch."""
 import os
 import sys
@@ -28,6 +29,9 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     m = int(rng.choice([1, 2, 3, 7, 20, 64, 65, 130, 300, 900, 1030, 1300]))
     n = int(rng.choice([1, 2, 9, 40, 150, 600, 2500])) if m > 300 else int(rng.choice([1, 5, 33, 200, 1000, 4000, 12000]))
+    if os.environ.get("FBG_FUZZ_TALL") and rng.random() < 0.25:      # thousands of rows: the large instances of k_sp_odd_pairs
+        m = int(rng.choice([2100, 3000, 4200, 6000]))
+        n = int(rng.choice([1, 9, 40, 150, 400]))
     alphabet = str(rng.choice(["A", "AC", "ACGT", "ACGT", "ACGTN", "ACGTRYKM"]))
     alpha = np.frombuffer(alphabet.encode(), dtype=np.uint8)
     anc = alpha[rng.integers(0, len(alpha), n)]
