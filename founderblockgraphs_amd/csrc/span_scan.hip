@@ -1099,6 +1099,10 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
             if (threadIdx.x == 0) {
                 const unsigned long long at = atomicAdd(&a.counters[7], 1ull);
                 if (at < a.slow_cap) a.slow[at] = g; else a.counters[3] = 1;
+                if (CAP > 1024) {                              // what the slow kernel has ahead in the large groups (the host decides)
+                    atomicAdd(&a.counters[32], (unsigned long long)no * s);
+                    if (no > 256) a.counters[33] = 1;
+                }
             }
             continue;
         }
@@ -1403,6 +1407,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     sp_args(ctx, a, disable_tricks);
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 2, 0, 6 * sizeof(unsigned long long), st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 32, 0, 2 * sizeof(unsigned long long), st));
     const uint32_t *lists[4];
     uint32_t cnts[4];
     for (int c = 0; c < 4; c++) { lists[c] = a.odd + (size_t)c * a.odd_cap; cnts[c] = ctx->sp_n_odd[c]; }
@@ -1453,10 +1458,17 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
         if (h[1] != 0) return FBG_OK;
         const uint32_t n_slow = (uint32_t)h[5];
         ctx->sp_slow_n = n_slow;
-        // (a large group on the slow list -- more odd members than the kernel above takes: a deletion in dozens of a few
-        // thousand rows, the first symbols of more than a thousand identical rows -- is tens of milliseconds of all-pairs
-        // comparisons: beyond a few of them per 10^6 suffixes the record path is the cheaper one; span_scan = 1 insists)
-        if (n_big && !big_chains && ctx->opt.span_scan != 1 && n_slow > ctx->N / (1ull << 20) + 4) return FBG_OK;
+        // (a large group on the slow list has more odd members than the kernel above takes -- a deletion in dozens of a few
+        // thousand rows -- and every one of them is compared with every mate: fine for dozens, but where hundreds of a
+        // group's members are odd (a thousand identical rows that start late: every pair runs on for the rows' length) a
+        // group is tens of milliseconds: those inputs, and more than 64 comparisons per suffix, go to the record path;
+        // span_scan = 1 insists)
+        if (n_big && !big_chains && ctx->opt.span_scan != 1 && n_slow) {
+            unsigned long long ahead[2] = {0, 0};
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(ahead, a.counters + 32, sizeof(ahead), hipMemcpyDeviceToHost, st));
+            FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (ahead[1] != 0 || ahead[0] > 64 * ctx->N) return FBG_OK;
+        }
         if (n_slow) {
             hipLaunchKernelGGL((k_sp_odd_slow<1024>), dim3(std::min<uint32_t>(n_slow, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow, 0u);
             if (n_big && !big_chains)
