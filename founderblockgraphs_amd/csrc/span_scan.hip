@@ -944,11 +944,12 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
 // beyond those 128 bytes (7 % when the rows differ in 1 % of their symbols) are listed and walked together, window after
 // window (B).  Then every (odd member, column) of the spans gets a thread (C).
 #define SPP_MAXO 32
-#define SPP_TAILS 1024
+#define SPP_TAILS 448
 // SPP_ROWS * 32: the members an instance has room for in LDS (values, positions, best matches): 64 (the small groups, more
 // than half of the odd ones: one wave per group, k_sp_odd_pairs_small), 896 or 1024; an instance takes the groups of more
 // than MINS members that it has room for.  What the kernel waits for is memory -- some twenty dependent steps per group,
-// 75 us -- so the groups in flight count: 5 workgroups per CU at 95 registers and 30 KB of LDS.  (The round's first
+// 75 us -- so the groups in flight count: 6 workgroups per CU at 80 registers and 25-27 KB of LDS (the window in two halves
+// of 64 bytes, 448 listed pairs).  (The round's first
 // version kept ALL members' windows in registers, 16 bytes of a member in each of eight lanes: 168 registers, 3 workgroups
 // per CU, and a third of its time in the instructions that find a first difference across lanes: 17 ms against 10.6.)
 template <int SPP_ROWS, int MINS> __device__ __forceinline__
@@ -995,75 +996,23 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
         if (threadIdx.x == 0) { n_odd = 0; n_col = 0; s_need = 0; ntl = 0; }
         for (uint32_t i = threadIdx.x; i < s; i += NT) { sv[i] = a.vals[s0 + i]; nbest[i] = 0; omap[i] = 0xffffu; }
         __syncthreads();
-        uint32_t major;
-        if constexpr (CAP <= 1024) {
-            // the members' text positions: the loads of a thread's (up to four) members go out together, before the votes on the
-            // majority column, instead of one dependent round trip per member after them
-            constexpr int PER = (CAP + NT - 1) / NT;
-            uint32_t mrow[PER], mcol[PER], mbase[PER];
-            CWin mwin[PER];
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const uint32_t i = threadIdx.x + (uint32_t)j * NT;
-                mrow[j] = 0; mcol[j] = 0; mbase[j] = 0; mwin[j] = CWin{0, 0, 0, 0, 0};
-                if (i < s) {
-                    sp_decode(a, sv[i], mrow[j], mcol[j]);
-                    if (a.cwin && mrow[j] < a.m && mcol[j] < a.n) { mbase[j] = a.pos[mrow[j]]; mwin[j] = a.cwin[(size_t)mrow[j] * a.wpr + (mcol[j] >> 7)]; }
-                }
-            }
-            major = sp_major(a, sv, s, votes);
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const uint32_t i = threadIdx.x + (uint32_t)j * NT;
-                if (i >= s) continue;
-                const uint32_t row = mrow[j], col = mcol[j];
-                uint32_t p;
-                if (a.cwin && row < a.m && col < a.n) {                // (sp_pos with the window already here)
-                    const uint32_t o = col & 127u;
-                    const uint32_t bits[4] = {mwin[j].b0, mwin[j].b1, mwin[j].b2, mwin[j].b3};
-                    uint32_t cnt = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t lo = 32u * q;
-                        if (o >= lo + 32) cnt += (uint32_t)__popc(bits[q]);
-                        else if (o > lo) cnt += (uint32_t)__popc(bits[q] & ((1u << (o - lo)) - 1));
-                    }
-                    p = mbase[j] + mwin[j].rank0 + cnt;
-                } else p = sp_pos(a, row, col);
-                sp[i] = p;
-                // odd: another column than the majority's, or a span that is not just its column (a W member whose span
-                // IS its column -- a row's first symbol at column 0 with the tricks off -- is a member like any other)
-                uint32_t lo = col, hi = col;
-                if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
-                if (col != major || lo != col || hi != col) {
-                    const uint32_t o = atomicAdd(&n_odd, 1u);
-                    if (lo <= hi) atomicAdd(&n_col, 1u);
-                    if (o < SPP_MAXO) {
-                        oidx[o] = (uint16_t)i;
-                        omap[i] = (uint16_t)o;
-                        olo[o] = lo; ohi[o] = hi;
-                    }
-                }
-            }
-        } else {                                               // (the instances for more than 1024 members: one member at a time)
-            major = sp_major(a, sv, s, votes);
-            for (uint32_t i = threadIdx.x; i < s; i += NT) {
-                uint32_t row, col;
-                sp_decode(a, sv[i], row, col);
-                const uint32_t p = sp_pos(a, row, col);
-                sp[i] = p;
-                // odd: another column than the majority's, or a span that is not just its column (a W member whose span
-                // IS its column -- a row's first symbol at column 0 with the tricks off -- is a member like any other)
-                uint32_t lo = col, hi = col;
-                if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
-                if (col != major || lo != col || hi != col) {
-                    const uint32_t o = atomicAdd(&n_odd, 1u);
-                    if (lo <= hi) atomicAdd(&n_col, 1u);
-                    if (o < SPP_MAXO) {
-                        oidx[o] = (uint16_t)i;
-                        omap[i] = (uint16_t)o;
-                        olo[o] = lo; ohi[o] = hi;
-                    }
+        const uint32_t major = sp_major(a, sv, s, votes);
+        for (uint32_t i = threadIdx.x; i < s; i += NT) {
+            uint32_t row, col;
+            sp_decode(a, sv[i], row, col);
+            const uint32_t p = sp_pos(a, row, col);
+            sp[i] = p;
+            // odd: another column than the majority's, or a span that is not just its column (a W member whose span
+            // IS its column -- a row's first symbol at column 0 with the tricks off -- is a member like any other)
+            uint32_t lo = col, hi = col;
+            if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+            if (col != major || lo != col || hi != col) {
+                const uint32_t o = atomicAdd(&n_odd, 1u);
+                if (lo <= hi) atomicAdd(&n_col, 1u);
+                if (o < SPP_MAXO) {
+                    oidx[o] = (uint16_t)i;
+                    omap[i] = (uint16_t)o;
+                    olo[o] = lo; ohi[o] = hi;
                 }
             }
         }
@@ -1134,50 +1083,62 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
         // member in each of eight lanes, all members of the group in registers at once, was the round's first version: a
         // third of the kernel's time went into finding the first difference across lanes, ~40 instructions per row of 32
         // members for two XORs of payload, and 168 registers held the kernel to 3 waves per SIMD.)
+        // The window in two halves of 64 bytes: most pairs part in the first one (the rows differ in 2 % of their columns), and
+        // 8 instead of 16 words per lane are what lets a sixth workgroup onto the CU.
         for (uint32_t u = threadIdx.x; u < ((s + NT - 1) / NT) * NT; u += NT) {
             const bool ex = u < s;
-            uint64_t m[16];
-            {
-                const uint64_t p = ex ? (uint64_t)sp[u] + a.K : 0ull;
-                const uint64_t *w = reinterpret_cast<const uint64_t *>(a.T) + (p >> 3);
-                const uint64_t words = (a.N + 64) >> 3;         // the text buffer: N + 64 bytes, zero padded
-                const unsigned sh = (unsigned)(p & 7) * 8;
-                uint64_t x[17];
-#pragma unroll
-                for (int i = 0; i < 17; i++) x[i] = (ex && (p >> 3) + i < words) ? w[i] : 0ull;
-#pragma unroll
-                for (int i = 0; i < 16; i++) m[i] = sh ? (x[i] >> sh) | (x[i + 1] << (64 - sh)) : x[i];
-            }
+            const uint64_t p = ex ? (uint64_t)sp[u] + a.K : 0ull;
+            const uint64_t *w = reinterpret_cast<const uint64_t *>(a.T) + (p >> 3);
+            const uint64_t words = (a.N + 64) >> 3;             // the text buffer: N + 64 bytes, zero padded
+            const unsigned sh = (unsigned)(p & 7) * 8;
             const bool narrow_u = ex && omap[u] == 0xffffu;
             uint32_t my_nbest = 0;
-            for (uint32_t o = 0; o < no; o++) {
-                const bool own = own_of(o);
-                const bool atm = at_major_of(o);
-                if (!own && (atm || !has_narrow)) continue;    // (uniform over the workgroup)
-                const bool live = ex && (own || narrow_u) && u != oidx[o];
-                // the first differing word (descending: the lowest one wins), its first differing byte once at the end
-                uint64_t dd = 0;
-                uint32_t wi = 16;
+            uint32_t open = 0;                                  // bit o: this member and odd member o agree on the first half
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                if (half == 1 && !__ballot(open != 0)) break;  // (uniform over the wave)
+                uint64_t m[8];
+                {
+                    const bool want = ex && (half == 0 || open != 0);
+                    uint64_t x[9];
 #pragma unroll
-                for (int i = 15; i >= 0; i--) {
-                    const uint64_t d = m[i] ^ qwin[o][i];
-                    if (d) { dd = d; wi = (uint32_t)i; }
-                }
-                const uint32_t L = wi < 16 ? 8 * wi + ((uint32_t)__ffsll((unsigned long long)dd) - 1) / 8 : SP_WIN;   // SP_WIN: none in the window
-                uint32_t mymax = 0;                            // the lane's match with a member of the majority
-                if (live && L < SP_WIN) {
-                    const uint32_t Lk = (uint32_t)a.K + L;
-                    if (narrow_u) { mymax = Lk; if (!atm) my_nbest = max(my_nbest, Lk); }
-                    else LQ[o][omap[u]] = Lk;
-                }
-                if (live && L >= SP_WIN) {
-                    const uint32_t at = atomicAdd(&ntl, 1u);
-                    if (at < NTAILS) tl[at] = o << 16 | u;
-                    else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[oidx[o]] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
-                }
+                    for (int i = 0; i < 9; i++) x[i] = (want && (p >> 3) + 8 * half + i < words) ? w[8 * half + i] : 0ull;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor(mymax, d, 64));
-                if (lane == 0 && mymax) { atomicMax(&omn[o], mymax); oany[o] = 1; }
+                    for (int i = 0; i < 8; i++) m[i] = sh ? (x[i] >> sh) | (x[i + 1] << (64 - sh)) : x[i];
+                }
+                for (uint32_t o = 0; o < no; o++) {
+                    const bool own = own_of(o);
+                    const bool atm = at_major_of(o);
+                    if (!own && (atm || !has_narrow)) continue;    // (uniform over the workgroup)
+                    const bool live = half == 0 ? ex && (own || narrow_u) && u != oidx[o] : ((open >> o) & 1u) != 0;
+                    if (half == 1 && !__ballot(live)) continue;    // (uniform over the wave)
+                    // the first differing word (descending: the lowest one wins), its first differing byte once at the end
+                    uint64_t dd = 0;
+                    uint32_t wi = 8;
+#pragma unroll
+                    for (int i = 7; i >= 0; i--) {
+                        const uint64_t d = m[i] ^ qwin[o][8 * half + i];
+                        if (d) { dd = d; wi = (uint32_t)i; }
+                    }
+                    const bool found = wi < 8;
+                    uint32_t mymax = 0;                            // the lane's match with a member of the majority
+                    if (live && found) {
+                        const uint32_t Lk = (uint32_t)a.K + 64u * half + 8 * wi + ((uint32_t)__ffsll((unsigned long long)dd) - 1) / 8;
+                        if (narrow_u) { mymax = Lk; if (!atm) my_nbest = max(my_nbest, Lk); }
+                        else LQ[o][omap[u]] = Lk;
+                    }
+                    if (live && !found) {
+                        if (half == 0) open |= 1u << o;
+                        else {
+                            const uint32_t at = atomicAdd(&ntl, 1u);
+                            if (at < NTAILS) tl[at] = o << 16 | u;
+                            else note(o, u, fbg_extend_match(a.T, (uint64_t)sp[oidx[o]] + a.K + SP_WIN, (uint64_t)sp[u] + a.K + SP_WIN, 0) + SP_WIN);
+                        }
+                    }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor(mymax, d, 64));
+                    if (lane == 0 && mymax) { atomicMax(&omn[o], mymax); oany[o] = 1; }
+                }
             }
             if (my_nbest) atomicMax(&nbest[u], my_nbest);
         }
@@ -1282,7 +1243,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
     }
 }
 
-template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(5)))
+template <int SPP_ROWS, int MINS> __global__ __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(6)))
 void k_sp_odd_pairs(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, unsigned long long *__restrict__ ticket)
 {
     sp_odd_pairs_body<SPP_ROWS, MINS>(a, list, count, ticket);
