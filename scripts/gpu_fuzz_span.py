@@ -33,6 +33,8 @@ while time.time() - t0 < budget:
         m = int(rng.choice([2100, 3000, 4200, 6000]))
         n = int(rng.choice([1, 9, 40, 150, 400]))
     alphabet = str(rng.choice(["A", "AC", "ACGT", "ACGT", "ACGTN", "ACGTRYKM"]))
+    if m > 2000 and alphabet == "A":                          # (thousands of rows of one letter, forced through the all-pairs kernel: a minute per case)
+        alphabet = "AC"
     alpha = np.frombuffer(alphabet.encode(), dtype=np.uint8)
     anc = alpha[rng.integers(0, len(alpha), n)]
     if rng.random() < 0.3 and n >= 40:                        # a tandem repeat in the ancestor: strays in the groups
