@@ -959,12 +959,13 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
     // the small groups (up to 64 members): a wave per group -- four times the groups in flight for the same registers
     constexpr uint32_t NT = SPP_ROWS <= 2 ? 64u : (uint32_t)SP_THREADS;
     constexpr uint32_t NTAILS = SPP_ROWS <= 2 ? 256u : (uint32_t)SPP_TAILS;
+    constexpr int MAXO = SPP_ROWS <= 2 ? 16 : SPP_MAXO;           // odd members a group may have here (more: k_sp_odd_slow); 16 of up to 64 members: 7 KB of LDS
     __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
     __shared__ uint16_t omap[CAP];
-    __shared__ uint16_t oidx[SPP_MAXO];
-    __shared__ uint32_t olo[SPP_MAXO], ohi[SPP_MAXO], omn[SPP_MAXO], oany[SPP_MAXO], ogmax[SPP_MAXO], oign[SPP_MAXO];
-    __shared__ uint32_t LQ[SPP_MAXO][SPP_MAXO];
-    __shared__ uint64_t qwin[SPP_MAXO][16];
+    __shared__ uint16_t oidx[MAXO];
+    __shared__ uint32_t olo[MAXO], ohi[MAXO], omn[MAXO], oany[MAXO], ogmax[MAXO], oign[MAXO];
+    __shared__ uint32_t LQ[MAXO][MAXO];
+    __shared__ uint64_t qwin[MAXO][16];
     __shared__ uint32_t tl[NTAILS], tmin[NTAILS];
     __shared__ uint32_t n_odd, n_col, ntl, s_gv, s_need, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1009,7 +1010,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
             if (col != major || lo != col || hi != col) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
                 if (lo <= hi) atomicAdd(&n_col, 1u);
-                if (o < SPP_MAXO) {
+                if (o < MAXO) {
                     oidx[o] = (uint16_t)i;
                     omap[i] = (uint16_t)o;
                     olo[o] = lo; ohi[o] = hi;
@@ -1019,7 +1020,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
         __syncthreads();
         SP_T(1);
         const uint32_t no = n_odd;
-        if (no == s && n_col == 0) continue;                   // nobody is ever coloured (the first symbols of more than SPP_MAXO rows, tricks on): nothing to say
+        if (no == s && n_col == 0) continue;                   // nobody is ever coloured (the first symbols of more than MAXO rows, tricks on): nothing to say
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
         const uint64_t key = a.keys[s0];
         const bool has_narrow = no < s;
@@ -1044,7 +1045,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
             if (__ballot(reg_major) && (threadIdx.x & 63) == 0) sp_update(a, x, major + step);
         }
         SP_T(2);
-        if (no > SPP_MAXO) {                                   // many odd members (a deletion common to many rows): k_sp_odd_slow
+        if (no > MAXO) {                                   // many odd members (a deletion common to many rows): k_sp_odd_slow
             if (threadIdx.x == 0) {
                 const unsigned long long at = atomicAdd(&a.counters[7], 1ull);
                 if (at < a.slow_cap) a.slow[at] = g; else a.counters[3] = 1;
@@ -1062,7 +1063,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
             omn[o] = 0; oany[o] = 0; ogmax[o] = 0; oign[o] = SP_NONE;
             if (own_of(o) || (!at_major_of(o) && has_narrow)) s_need = 1;
         }
-        for (uint32_t i = threadIdx.x; i < no * SPP_MAXO; i += NT) LQ[i / SPP_MAXO][i % SPP_MAXO] = 0;
+        for (uint32_t i = threadIdx.x; i < no * MAXO; i += NT) LQ[i / MAXO][i % MAXO] = 0;
         __syncthreads();
         if (!s_need) continue;
         // -- the 128 bytes behind the key of the odd members -> LDS
