@@ -86,6 +86,9 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   msd_min_force      1: the sample sort of (key, position) pairs also for rows that resemble each other (tests)
  *   msd_sample_bins    1: the finish of the sample sort bins by sampled keys instead of symbol ranks (the earlier method, kept for tests)
  *   gapped_rank also takes 2 (no flag bits in the sort's values), 3 (flag bits, no threshold), 4 (threshold forced: tests)
+ *   msd_probe          1: the kernels of the MSD sort and the finish of the sample sort also run in timing variants (no stores,
+ *                      made-up slots, single phases) before the real launch -- for a kernel trace read in launch order
+ *                      (scripts/gpu_trace_order.sh); results unchanged
  *   span_scan          MSAs with gaps / ignore characters whose rows resemble each other take the group-level scan on
  *                      column spans (span_scan.hip); 1: every such MSA takes it, -1: none, 2: as 0, and the sorted slots
  *                      are checked to be the cells in key order (debugging), 3: as 1, with the groups of more than 1024

@@ -50,3 +50,17 @@ def test_product_does_not_import_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "pyoracle" not in text and "liboracle" not in text and "fbg_oracle" not in text, (dirpath, fn)
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """The behaviour switches of fbg_set_option (the table g_opt_keys in csrc/ctx.hip) are part of the seam: a key the
+    header does not explain is a key a maintainer of the reference cannot use."""
+    import re
+    src = open(os.path.join(ROOT, "founderblockgraphs_amd", "csrc", "ctx.hip")).read()
+    table = src[src.index("static const OptKey g_opt_keys[] = {"):]
+    table = table[:table.index("};")]
+    keys = re.findall(r'\{"([a-z_0-9]+)", &FbgOptions::', table)
+    assert len(keys) >= 20
+    header = open(os.path.join(ROOT, "include", "fbg_hip.h")).read()
+    missing = [k for k in keys if not re.search(r"\b%s\b" % re.escape(k), header)]
+    assert not missing, missing
