@@ -43,8 +43,11 @@ struct MsdArgs {
     int b, K, pb, kb;                          // bits per symbol, symbols per key, position bits, key bits
     uint64_t *buf1;                            // pass 1 output: MSD_NB stretches of cap1 slots
     uint64_t cap1;
-    unsigned long long *count1;                // [MSD_NB]
-    const uint32_t *tile_start;                // [MSD_NB + 1]: first tile of every bucket (pass 2)
+    int xs;                                    // stretches per bucket (1, or 8: one per XCD, see k_msd_pack_split), segcap = cap1 / xs slots each
+    uint64_t segcap;
+    unsigned long long *count1;                // [MSD_NB * xs]
+    const uint32_t *tile_start;                // [MSD_NB * xs + 1]: first tile of every stretch (pass 2)
+    uint32_t tiles2, tiles2_x;                 // pass 2: tiles in all; tiles per XCD when the tiles are dealt to the XCDs in ranges (0: in launch order)
     uint64_t *buf2;                            // pass 2 output: MSD_NB^2 stretches of MSD_FN_CAP slots
     uint32_t *count2;                          // [MSD_NB^2]
     const unsigned long long *off;             // [MSD_NB^2 + 1]: exclusive scan of count2
@@ -119,8 +122,13 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
         w[i] = (w[i] << a.pb) | p;
     }
     __syncthreads();
-    msd_scan_and_reserve(cnt, loff, gdelta, wsum, a.count1 + (threadIdx.x < MSD_NB ? threadIdx.x : 0), true, nullptr);
+    // Workgroups b and b + 8 run on the same XCD (dispatch deals them round-robin).  With one stretch per (bucket, XCD)
+    // the runs that neighbour each other in memory were written through the same L2, which merges their partial
+    // 128-byte lines before they leave for HBM; runs of different XCDs leave every line they share twice, in parts.
+    const uint32_t xq = a.xs > 1 ? (blockIdx.x & (uint32_t)(a.xs - 1)) : 0u;
+    msd_scan_and_reserve(cnt, loff, gdelta, wsum, a.count1 + (threadIdx.x < MSD_NB ? threadIdx.x * a.xs + xq : 0), true, nullptr);
     const int wshift = a.pb + dshift;
+    uint64_t *const obase = a.buf1 + xq * a.segcap;
 #pragma unroll
     for (int i = 0; i < MSD_ITEMS; i++)
         if (rk[i] != 0xffffffffu) buf[loff[(uint32_t)(w[i] >> wshift)] + rk[i]] = w[i];
@@ -134,27 +142,46 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
             const uint32_t d = (uint32_t)(x >> wshift);
             const uint32_t at = j + gdelta[d];                  // below 2^32: the host checks cap1 + N
             if (a.probe & 1) continue;
-            if (at < a.cap1) {
-                if (a.probe & 16) __builtin_nontemporal_store(x, &a.buf1[(uint64_t)d * a.cap1 + at]);
-                else a.buf1[(uint64_t)d * a.cap1 + at] = x;
+            if (at < a.segcap) {
+                if (a.probe & 16) __builtin_nontemporal_store(x, &obase[(uint64_t)d * a.cap1 + at]);
+                else obase[(uint64_t)d * a.cap1 + at] = x;
             } else if (!a.probe) *a.flag = 1;
         }
     }
 }
 
-// first tile of every bucket of pass 1 (one thread; MSD_NB buckets)
-__global__ void k_msd_tiles(const unsigned long long *__restrict__ count1, uint64_t cap1, uint32_t *__restrict__ tile_start,
-                            unsigned long long *__restrict__ flag)
+// first tile of every stretch of pass 1 (one workgroup of 1024 threads; nseg <= 4096 stretches, four per thread)
+__global__ __launch_bounds__(1024) void k_msd_tiles(const unsigned long long *__restrict__ count1, uint64_t segcap, uint32_t nseg,
+                                                    uint32_t *__restrict__ tile_start, unsigned long long *__restrict__ flag)
 {
-    if (blockIdx.x || threadIdx.x) return;
-    uint32_t t = 0;
-    for (int s = 0; s < MSD_NB; s++) {
-        tile_start[s] = t;
-        const unsigned long long c = count1[s] < cap1 ? count1[s] : cap1;
-        if (count1[s] > cap1) *flag = 1;
-        t += (uint32_t)((c + MSD_TILE - 1) / MSD_TILE);
+    __shared__ uint32_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t t[4], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t s = threadIdx.x * 4 + q;
+        t[q] = 0;
+        if (s < nseg) {
+            const unsigned long long c = count1[s] < segcap ? count1[s] : segcap;
+            if (count1[s] > segcap) *flag = 1;
+            t[q] = (uint32_t)((c + MSD_TILE - 1) / MSD_TILE);
+        }
+        tot += t[q];
     }
-    tile_start[MSD_NB] = t;
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = inc - tot;
+    for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t s = threadIdx.x * 4 + q;
+        if (s < nseg) tile_start[s] = pre;
+        pre += t[q];
+        if (s + 1 == nseg) tile_start[nseg] = pre;
+    }
 }
 
 __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
@@ -163,14 +190,19 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
     __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
     __shared__ uint32_t gdelta[MSD_NB];
     __shared__ uint32_t wsum[MSD_THREADS / 64];
-    // the bucket this tile belongs to: largest s with tile_start[s] <= blockIdx.x
-    uint32_t lo = 0, hi = MSD_NB;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (a.tile_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-    const uint32_t seg = lo;
-    const uint64_t segn = min((uint64_t)a.count1[seg], a.cap1);
-    const uint64_t first = (uint64_t)(blockIdx.x - a.tile_start[seg]) * MSD_TILE;
+    // The tile of this workgroup.  tiles2_x != 0: the workgroups of one XCD (b, b + 8, ...) take a contiguous range of the
+    // tiles, i.e. whole buckets: all the runs a sub-bucket receives come through one L2, which merges the partial lines
+    // where two runs meet (k_msd_pack_split has the other half of the story).
+    const uint32_t tile = a.tiles2_x ? (blockIdx.x & 7u) * a.tiles2_x + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= a.tiles2) return;
+    // the stretch this tile belongs to: largest s with tile_start[s] <= tile
+    uint32_t lo = 0, hi = MSD_NB * (uint32_t)a.xs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (a.tile_start[mid] <= tile) lo = mid; else hi = mid; }
+    const uint32_t seg = lo / (uint32_t)a.xs;                    // the bucket
+    const uint64_t segn = min((uint64_t)a.count1[lo], a.segcap);
+    const uint64_t first = (uint64_t)(tile - a.tile_start[lo]) * MSD_TILE;
     const uint32_t have = (uint32_t)min((uint64_t)MSD_TILE, segn - first);
-    const uint64_t *in = a.buf1 + (uint64_t)seg * a.cap1 + first;
+    const uint64_t *in = a.buf1 + (uint64_t)seg * a.cap1 + (uint64_t)(lo % (uint32_t)a.xs) * a.segcap + first;
     if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int wshift = a.pb + a.kb - 2 * MSD_DIG;
@@ -404,12 +436,15 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     // without enough bits for the bins the counting in the finish turns quadratic: leave those to rocPRIM
     if (fbits < 6) return FBG_OK;
     hipStream_t st = ctx->stream;
-    const uint64_t cap1 = (N / MSD_NB + N / (4 * MSD_NB) + 65536) & ~15ull;
+    const int xcd = ctx->opt.msd_xcd < 0 ? 3 : (int)ctx->opt.msd_xcd;
+    const int xs = (xcd & 2) ? 8 : 1;
+    const uint64_t cap1 = (N / MSD_NB + N / (4 * MSD_NB) + 65536) & ~127ull;   // a multiple of 8 stretches of 16 slots
     const uint64_t nsub = (uint64_t)MSD_NB * MSD_NB;
     if (N / nsub + N / (32 * nsub) + 64 > MSD_FN_CAP) return FBG_OK;        // sub-buckets would not fit their stretches
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)MSD_NB * cap1 * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, (size_t)nsub * MSD_FN_CAP * 8));
-    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, MSD_NB * 8 + (MSD_NB + 1) * 4 + 64));
+    const uint32_t nseg = MSD_NB * (uint32_t)xs;
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, (size_t)nseg * 8 + ((size_t)nseg + 1) * 4 + 64));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_b, nsub * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (nsub + 1) * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)MSD_ARENA * 4 * 2));
@@ -417,9 +452,10 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;
     MsdArgs a;
     a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = g.pb; a.kb = g.key_bits;
-    a.buf1 = ctx->keysA.as<uint64_t>(); a.cap1 = cap1;
+    a.buf1 = ctx->keysA.as<uint64_t>(); a.cap1 = cap1; a.xs = xs; a.segcap = cap1 / xs;
+    a.tiles2 = 0; a.tiles2_x = 0;
     a.count1 = ctx->dp_a.as<unsigned long long>();
-    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + MSD_NB * 8);
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + (size_t)nseg * 8);
     a.tile_start = tile_start;
     a.buf2 = ctx->keysB.as<uint64_t>();
     a.count2 = ctx->dp_b.as<uint32_t>();
@@ -429,7 +465,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     a.flag = flag;
     a.arena_sb = ctx->dp_d.as<uint32_t>(); a.arena_w = ctx->dp_e.as<uint64_t>(); a.arena_count = flag + 1; a.arena_cap = MSD_ARENA;
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 16, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
     a.probe = 0;
     const bool probing = ctx->opt.msd_probe != 0;              // every kernel runs its probe variants first (a profiler reads their times)
@@ -437,26 +473,29 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
         for (int v : {1, 16}) {
             a.probe = v;
             hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
-            FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, MSD_NB * 8, st));
+            FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
             a.probe = 0;
         }
     hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag);
+    hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, st, a.count1, a.segcap, nseg, tile_start, flag);
     uint32_t tiles2 = 0;
     unsigned long long h_flag = 0;
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tiles2, tile_start + MSD_NB, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tiles2, tile_start + nseg, 4, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, flag, 8, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 2;
     if (h_flag != 0 || tiles2 == 0) return FBG_OK;
+    a.tiles2 = tiles2;
+    a.tiles2_x = (xcd & 1) ? (tiles2 + 7) / 8 : 0;
+    const unsigned grid2 = a.tiles2_x ? 8 * a.tiles2_x : tiles2;
     if (probing)
         for (int v : {1, 16, 32, 48}) {
             a.probe = v;
-            hipLaunchKernelGGL(k_msd_split, dim3(tiles2), dim3(MSD_THREADS), 0, st, a);
+            hipLaunchKernelGGL(k_msd_split, dim3(grid2), dim3(MSD_THREADS), 0, st, a);
             FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
             a.probe = 0;
         }
-    hipLaunchKernelGGL(k_msd_split, dim3(tiles2), dim3(MSD_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_msd_split, dim3(grid2), dim3(MSD_THREADS), 0, st, a);
     // offsets of the sub-buckets in the sorted array: exclusive scan of their sizes
     unsigned long long *wide = reinterpret_cast<unsigned long long *>(ctx->keysA.p);   // scratch: pass 1's slots are dead
     hipLaunchKernelGGL(k_msd_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);

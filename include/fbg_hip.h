@@ -89,6 +89,9 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   msd_probe          1: the kernels of the MSD sort and the finish of the sample sort also run in timing variants (no stores,
  *                      made-up slots, single phases) before the real launch -- for a kernel trace read in launch order
  *                      (scripts/gpu_trace_order.sh); results unchanged
+ *   msd_xcd            which passes of the MSD sort place their writes by XCD (-1 = 3): bit 0 pass 2 (the tiles of a bucket
+ *                      go to the workgroups of one XCD), bit 1 pass 1 (a stretch per bucket and XCD); 0: neither (the
+ *                      layout of rounds 1-3); results unchanged
  *   span_scan          MSAs with gaps / ignore characters whose rows resemble each other take the group-level scan on
  *                      column spans (span_scan.hip); 1: every such MSA takes it, -1: none, 2: as 0, and the sorted slots
  *                      are checked to be the cells in key order (debugging), 3: as 1, with the groups of more than 1024
