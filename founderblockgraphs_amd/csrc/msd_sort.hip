@@ -21,7 +21,9 @@
 // rocPRIM instead (suffix_sort.hip).  Equal keys end up in position order.
 #include "fbg_internal.h"
 #include "msd_keys.h"
+#include "rank_common.h"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 
 #define MSD_DIG 9
 #define MSD_NB (1 << MSD_DIG)
@@ -254,26 +256,19 @@ __global__ void k_msd_widen(const uint32_t *__restrict__ count2, unsigned long l
     if (i < cnt) wide[i] = count2[i];
 }
 
-// `have` slots (the first n_a from in_a, the rest from in_b) -> out, sorted: bins on key bits inside LDS, then every slot
-// counts the smaller slots of its bin (the words are distinct)
+// the `have` slots in w[] (slot j = threadIdx.x + r * THREADS in w[r]) -> buf, sorted: bins on key bits inside LDS, then every
+// slot counts the smaller slots of its bin (the words are distinct)
 #define MSD_BIG_BIN 192                        // a bin with more slots is split on its low key bits instead of counted through
 #define MSD_LOW_BITS 10                        // ... when at most this many key bits lie below the bin bits
 template <int CAP, int THREADS>
-__device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, const uint64_t *in_a,
-                                                uint32_t n_a, const uint64_t *in_b, uint32_t have, uint64_t *out, int fshift,
-                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds,
-                                                int probe = 0)
+__device__ __forceinline__ void msd_finish_sort(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, uint64_t (&w)[CAP / THREADS],
+                                                uint32_t have, int fshift, uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist,
+                                                uint32_t *nbig_lds)
 {
     constexpr int ITEMS = CAP / THREADS;
     for (int i = threadIdx.x; i < MSD_FN_BINS; i += THREADS) cnt[i] = 0;
     __syncthreads();
-    uint64_t w[ITEMS];
     uint32_t rk[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * THREADS;
-        w[r] = j < have ? ((probe & 2) ? msd_probe_word(j) : (probe & 32) ? __builtin_nontemporal_load(in_a + j) : j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
-    }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
@@ -377,6 +372,23 @@ __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, ui
         if (j < have) buf[rk[r]] = w[r];
     }
     __syncthreads();
+}
+
+// `have` slots (the first n_a from in_a, the rest from in_b) -> out, sorted
+template <int CAP, int THREADS>
+__device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, const uint64_t *in_a,
+                                                uint32_t n_a, const uint64_t *in_b, uint32_t have, uint64_t *out, int fshift,
+                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds,
+                                                int probe = 0)
+{
+    constexpr int ITEMS = CAP / THREADS;
+    uint64_t w[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * THREADS;
+        w[r] = j < have ? ((probe & 2) ? msd_probe_word(j) : (probe & 32) ? __builtin_nontemporal_load(in_a + j) : j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
+    }
+    msd_finish_sort<CAP, THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, lowbits, sub, biglist, nbig_lds);
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
@@ -397,6 +409,162 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
     const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
     msd_finish_body<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, in, have, in, have, a.out + a.off[blockIdx.x], fshift, fmask,
                                                 fshift - a.pb, sub, biglist, &nbig_lds, a.probe);
+}
+
+// ---- pass 3 by workgroups that stay, with the classification of the extension scan fused in ---------------------------
+// k_msd_finish starts a workgroup per sub-bucket: its first loads leave when it starts and nothing else of it can run until
+// they are back (1.4 of 4.3 ms at 10^9 slots).  Here a workgroup takes sub-buckets b, b + G, ... and has the slots of the
+// next one on their way (in registers) while it sorts the current one.
+// FUSED: with the sub-bucket sorted in LDS the workgroup also does what k_rank_scan (rank_scan.hip) does in a pass of its
+// own over the sorted slots when the threshold lies above K (rs_pick_threshold: a.g_min = K + 1; the caller checks
+// afterwards that this was the regime): only slots that tie on the key, sit next to a tie group, share their column with
+// a neighbour or lie in the 64 columns nearest a row end can matter.  Those -- a seventh of the slots -- queue up in LDS
+// and go through rank_scan_slow, the scan's general code, reading the sorted sub-bucket; slots within 8 of the
+// sub-bucket's ends (their neighbourhood is another workgroup's) are written to a list that k_rank_scan_list works off
+// from global memory afterwards.  Same lists (ra.cand, ra.ties, per-workgroup regions) as k_rank_scan.
+struct FuseArgs {
+    RankArgs ra;
+    uint32_t *defer;                           // slots left to k_rank_scan_list
+    uint32_t defer_cap;
+    unsigned long long *fcnt;                  // [0] entries of defer, [1] slots that tie on the key, [2] != 0: a list overflowed
+};
+
+template <bool FUSED>
+__global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_msd_finish_p(MsdArgs a, int fshift, uint32_t fmask, FuseArgs f)
+{
+    __shared__ uint64_t buf[MSD_FN_CAP];
+    __shared__ uint32_t cl[2 * MSD_FN_BINS];                   // bin counts | bin offsets; afterwards the queue of the classification
+    __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
+    __shared__ uint32_t sub[1 << MSD_LOW_BITS];
+    __shared__ uint16_t biglist[MSD_FN_CAP / MSD_BIG_BIN + 1];
+    __shared__ uint32_t nbig_lds;
+    __shared__ uint32_t s_q, s_cand_n, s_tie_n, s_defer_n, s_defer_base, s_ties;
+    __shared__ uint32_t s_defer[32];
+    uint32_t *cnt = cl, *loff = cl + MSD_FN_BINS;
+    uint16_t *sq = reinterpret_cast<uint16_t *>(cl);           // MSD_FN_CAP entries
+    constexpr int ITEMS = MSD_FN_ITEMS;
+    const uint32_t nsub = MSD_NB * MSD_NB, G = gridDim.x;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; s_ties = 0; }
+    uint32_t sb = blockIdx.x;
+    uint32_t have_n = sb < nsub ? a.count2[sb] : 0u;
+    uint32_t have_nn = sb + G < nsub ? a.count2[sb + G] : 0u;
+    if (have_n > MSD_FN_CAP) have_n = 0;                        // the larger ones: k_msd_finish_big
+    uint64_t wn[ITEMS];
+    auto fetch = [&](uint32_t s, uint32_t have) {
+        const uint64_t *in = a.buf2 + (uint64_t)s * MSD_FN_CAP;
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
+            wn[r] = j < have ? in[j] : ~0ull;
+        }
+    };
+    fetch(sb, have_n);
+    uint32_t my_ties = 0;
+    for (; sb < nsub; sb += G) {
+        const uint32_t have = have_n;
+        uint64_t w[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) w[r] = wn[r];
+        have_n = have_nn > MSD_FN_CAP ? 0u : have_nn;
+        have_nn = (uint64_t)sb + 2ull * G < nsub ? a.count2[sb + 2 * G] : 0u;
+        if (sb + G < nsub) fetch(sb + G, have_n);
+        if (have == 0) continue;                                // uniform
+        const uint64_t o = a.off[sb];
+        if (FUSED && threadIdx.x == 0) { s_q = 0; s_defer_n = 0; }
+        msd_finish_sort<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
+        uint64_t *out = a.out + o;
+        if (!FUSED) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; r++) {
+                const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
+                if (j < have) out[j] = buf[j];
+            }
+            __syncthreads();                                    // buf is rewritten by the next round
+            continue;
+        }
+        // the sorted slots leave; every slot looks at its two neighbours either way
+        const RankArgs &ra = f.ra;
+#pragma unroll 2
+        for (int r = 0; r < ITEMS; r++) {
+            const int j = (int)(threadIdx.x + r * MSD_FN_THREADS);
+            bool want = false, defer = false;
+            if (j < (int)have) {
+                const uint64_t x = buf[j];
+                out[j] = x;
+                defer = j < 2 || j + 2 >= (int)have;            // a neighbour, or a neighbour's neighbour, lies in another sub-bucket
+                if (!defer) {
+                    const uint64_t xm2 = buf[j - 2], xm1 = buf[j - 1], xp1 = buf[j + 1], xp2 = buf[j + 2];
+                    const uint64_t key = x >> ra.pb, km1 = xm1 >> ra.pb, kp1 = xp1 >> ra.pb;
+                    const uint32_t rem = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
+                    const uint32_t remm = rs_rem<FBG_SLOTS_PACKED>(ra, xm1 & ra.pmask), remp = rs_rem<FBG_SLOTS_PACKED>(ra, xp1 & ra.pmask);
+                    const bool tie = km1 == key || kp1 == key;
+                    const bool adj = (xm2 >> ra.pb) == km1 || (xp2 >> ra.pb) == kp1;
+                    const bool run = rem != 0 && (remm == rem || remp == rem);
+                    const bool near_end = rem != 0 && rem <= 64;
+                    want = tie || adj || run || near_end;
+                    my_ties += tie ? 1u : 0u;
+                    if (want && (j < RS_HALO || j + RS_HALO >= (int)have)) { want = false; defer = true; }
+                }
+            }
+            {
+                const unsigned long long mask = __ballot(want);
+                if (mask) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if (lane == leader) base = atomicAdd(&s_q, (uint32_t)__popcll(mask));
+                    base = __shfl(base, leader, 64);
+                    if (want) sq[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)j;
+                }
+            }
+            if (__ballot(defer)) {                              // at most 2 * RS_HALO slots of a sub-bucket
+                if (defer) { const uint32_t e = atomicAdd(&s_defer_n, 1u); if (e < 32) s_defer[e] = (uint32_t)j; }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t qn = s_q;
+            const RsWordView view{buf, &ra, 0, (int)have};
+            for (uint32_t q0 = 0; q0 < qn; q0 += MSD_FN_THREADS) {
+                if (q0 + (threadIdx.x & ~63u) >= qn) break;    // wave-uniform
+                const uint32_t q = q0 + threadIdx.x;
+                bool want_cand = false, want_tie = false;
+                uint64_t k = 0;
+                if (q < qn) {
+                    const int i = sq[q];
+                    k = o + (uint64_t)i;
+                    rank_scan_slow(ra, view, i, 0, (int)have, k, want_cand, want_tie);
+                }
+                rs_append(want_cand, &s_cand_n, ra.cand, ra.region, (uint32_t)k);
+                rs_append(want_tie, &s_tie_n, ra.ties, ra.tie_region, (uint32_t)k);
+            }
+            const uint32_t nd = min(s_defer_n, 32u);
+            if (threadIdx.x == 0 && nd) s_defer_base = (uint32_t)atomicAdd(f.fcnt, (unsigned long long)nd);
+        }
+        __syncthreads();
+        {
+            const uint32_t nd = min(s_defer_n, 32u);
+            if (threadIdx.x < nd) {
+                const uint32_t e = s_defer_base + threadIdx.x;
+                if (e < f.defer_cap) f.defer[e] = (uint32_t)(o + s_defer[threadIdx.x]);
+                else f.fcnt[2] = 1;
+            }
+        }
+        __syncthreads();                                        // the queue and the lists are reset by the next round
+    }
+    if (FUSED) {
+        // the tie count: wave sums -> one LDS word -> one global add
+        uint32_t t = my_ties;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0 && t) atomicAdd(&s_ties, t);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            f.ra.blk_count[blockIdx.x] = s_cand_n;
+            f.ra.tie_count[blockIdx.x] = s_tie_n;
+            if (s_ties) atomicAdd(f.fcnt + 1, (unsigned long long)s_ties);
+        }
+    }
 }
 
 // sub-buckets whose stretch overflowed: the arena (sorted by sub-bucket) holds the slots beyond MSD_FN_CAP.  One
@@ -421,12 +589,32 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
                                                   a.out + a.off[sb], fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
 }
 
+// FUSED: the slots of the sub-buckets k_msd_finish_big sorted go to k_rank_scan_list, all of them (same grid)
+__global__ __launch_bounds__(256) void k_msd_defer_big(MsdArgs a, const uint32_t *__restrict__ sb_sorted, uint32_t entries, FuseArgs f)
+{
+    __shared__ unsigned long long s_base;
+    const uint32_t e = blockIdx.x;
+    if (e >= entries) return;
+    const uint32_t sb = sb_sorted[e];
+    if (e > 0 && sb_sorted[e - 1] == sb) return;
+    const uint32_t have = a.count2[sb];
+    if (threadIdx.x == 0) s_base = atomicAdd(f.fcnt, (unsigned long long)have);
+    __syncthreads();
+    const uint64_t o = a.off[sb];
+    for (uint32_t i = threadIdx.x; i < have; i += blockDim.x) {
+        const unsigned long long at = s_base + i;
+        if (at < f.defer_cap) f.defer[at] = (uint32_t)(o + i);
+        else f.fcnt[2] = 1;
+    }
+}
+
 // Sorts the packed slots of the current text by their key bits.  *ok = 0: a capacity was exceeded (keys spread
 // unevenly) or the geometry does not suit this sort -- nothing usable was produced.  On success *sorted points at
 // the N sorted words (inside ctx->keysA).
-int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches)
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches, bool want_fused)
 {
     *ok = 0;
+    ctx->fz_valid = false;
     const uint64_t N = ctx->N;
     const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
     const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);   // tests lower it
@@ -516,9 +704,35 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
             hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
             a.probe = 0;
         }
-    hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
+    // pass 3: workgroups that stay and prefetch (option msd_fuse bit 0), with the scan's classification fused in (bit 1)
+    const int fuse = ctx->opt.msd_fuse < 0 ? 0 : (int)ctx->opt.msd_fuse;
+    const bool persistent = (fuse & 1) && !probing;
+    const bool fused = persistent && (fuse & 2) && want_fused;
+    FuseArgs fz;
+    memset(&fz, 0, sizeof(fz));
+    unsigned fin_blocks = 0;
+    if (persistent) {
+        int dev_cus = 0, per_cu = 0;
+        FBG_HIP_TRY(ctx, hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        if (fused) FBG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msd_finish_p<true>, MSD_FN_THREADS, 0));
+        else FBG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msd_finish_p<false>, MSD_FN_THREADS, 0));
+        if (per_cu < 1) per_cu = 1;
+        fin_blocks = (unsigned)std::min<uint64_t>(nsub, (uint64_t)dev_cus * per_cu);
+        fin_blocks &= ~7u;                                      // a multiple of the XCDs: a workgroup's sub-buckets keep their residue
+        if (fin_blocks < 8) fin_blocks = 8;
+    }
+    if (fused) {
+        FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, fin_blocks, &fz.ra, &fz.defer, &fz.defer_cap, &fz.fcnt));
+        hipLaunchKernelGGL(k_msd_finish_p<true>, dim3(fin_blocks), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
+    } else if (persistent) {
+        hipLaunchKernelGGL(k_msd_finish_p<false>, dim3(fin_blocks), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
+    } else {
+        hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
+    }
     unsigned long long h2[2] = {0, 0};
+    unsigned long long hf[3] = {0, 0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
+    if (fused) FBG_HIP_TRY(ctx, hipMemcpyAsync(hf, fz.fcnt, 24, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 4;
     if (h2[0] != 0) return FBG_OK;
@@ -536,7 +750,9 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
         e = rocprim::radix_sort_pairs(ctx->tmp.p, have, a.arena_sb, sb_sorted, a.arena_w, w_sorted, (size_t)entries, 0u, 32u, st);
         if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_msd_finish_big, dim3(entries), dim3(MSD_BIG_THREADS), 0, st, a, sb_sorted, w_sorted, entries, fshift, fmask);
+        if (fused) hipLaunchKernelGGL(k_msd_defer_big, dim3(entries), dim3(256), 0, st, a, sb_sorted, entries, fz);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
+        if (fused) FBG_HIP_TRY(ctx, hipMemcpyAsync(hf, fz.fcnt, 24, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 2;
         if (h2[0] != 0) return FBG_OK;
@@ -544,5 +760,12 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipGetLastError());
     *sorted = ctx->keysA.as<uint64_t>();
     *ok = 1;
+    if (fused && hf[2] == 0 && hf[0] <= fz.defer_cap) {
+        // the scan's lists are made (rank_scan.hip takes it from here): the slots left to k_rank_scan_list, the slots that tie
+        ctx->fz_valid = true;
+        ctx->fz_blocks = fin_blocks;
+        ctx->fz_defer_n = hf[0];
+        ctx->fz_ties = hf[1];
+    }
     return FBG_OK;
 }

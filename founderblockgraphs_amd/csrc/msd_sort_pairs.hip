@@ -43,6 +43,9 @@ struct PpArgs {
     uint64_t lo, hi, mul;                      // key range (hi ignored when nohi), t = umul64hi(key - lo, mul) < 2^28
     int nohi;
     uint64_t *w1; uint32_t *v1; uint64_t cap1; unsigned long long *count1;      // pass 1 output: PP_NB stretches
+    int xs;                                    // ... each in xs parts of segcap = cap1 / xs slots (8: one per XCD, as in msd_sort.hip; count1[PP_NB * xs])
+    uint64_t segcap;
+    uint32_t tiles2, tiles2_x;                 // pass 2: tiles in all; tiles per XCD when the workgroups of an XCD take a range of tiles (0: launch order)
     const uint32_t *tile_start;
     uint64_t *w2; uint32_t *v2; uint32_t *count2;                               // pass 2 output: PP_NB^2 stretches of PP_FN_CAP
     const unsigned long long *off;
@@ -116,7 +119,7 @@ __device__ __forceinline__ uint32_t pp_digit_of_slot(const uint32_t *loff, uint3
 
 // scan of PP_NB counts (one per thread) + run reservation, as msd_scan_and_reserve
 __device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *loff, unsigned long long *gbase, uint32_t *wsum,
-                                                    unsigned long long *cursor64, uint32_t *cursor32)
+                                                    unsigned long long *cursor64, uint32_t *cursor32, int stride64 = 1)
 {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t c = cnt[threadIdx.x];                       // PP_THREADS == PP_NB
@@ -129,7 +132,7 @@ __device__ __forceinline__ void pp_scan_and_reserve(uint32_t *cnt, uint32_t *lof
     for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
     loff[threadIdx.x] = pre + inc - c;
     unsigned long long g = 0;
-    if (c) g = cursor64 ? atomicAdd(cursor64 + threadIdx.x, (unsigned long long)c) : (unsigned long long)atomicAdd(cursor32 + threadIdx.x, c);
+    if (c) g = cursor64 ? atomicAdd(cursor64 + (size_t)threadIdx.x * stride64, (unsigned long long)c) : (unsigned long long)atomicAdd(cursor32 + threadIdx.x, c);
     gbase[threadIdx.x] = g - (pre + inc - c);                  // minus the run's start in the tile: the write-out adds the slot's place (wraps)
     __syncthreads();
 }
@@ -221,13 +224,17 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
     uint32_t v[PP_STAGE / PP_THREADS], rk[PP_STAGE / PP_THREADS];
     uint32_t dg[PP_STAGE / PP_THREADS];
     pp_regroup<PP_STAGE>(sw, sv, cnt, have, [&](uint64_t x) { return MODE == 1 ? pp_rank511(sp, x >> a.pb) : pp_t28(a, x) >> 19; }, w, v, rk, dg);
-    pp_scan_and_reserve(cnt, loff, gbase, wsum, a.count1, nullptr);
+    // a stretch per (bucket, XCD): workgroups b and b + 8 share an XCD, whose L2 merges the partial lines where their runs
+    // meet (msd_sort.hip, k_msd_pack_split)
+    const uint32_t xq = a.xs > 1 ? (blockIdx.x & (uint32_t)(a.xs - 1)) : 0u;
+    pp_scan_and_reserve(cnt, loff, gbase, wsum, a.count1 + xq, nullptr, a.xs);
 #pragma unroll
     for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) { const uint32_t at = loff[dg[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; if (MODE == 1) sd[at] = (uint16_t)dg[r]; }
     }
     __syncthreads();
+    const uint64_t xoff = (uint64_t)xq * a.segcap;
 #pragma unroll
     for (int r = 0; r < PP_STAGE / PP_THREADS; r++) {
         const uint32_t j = threadIdx.x + r * PP_THREADS;
@@ -235,27 +242,48 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_pack_spli
             const uint64_t x = sw[j];
             const uint32_t d = MODE == 1 ? sd[j] : pp_t28(a, x) >> 19;       // (MODE 1: the digit travels with the slot; finding it again in loff was nine LDS reads)
             const uint64_t at = gbase[d] + j;
-            if (at < a.cap1) { a.w1[(uint64_t)d * a.cap1 + at] = x; if (!a.packed) a.v1[(uint64_t)d * a.cap1 + at] = sv[j]; }
+            if (at < a.segcap) { a.w1[(uint64_t)d * a.cap1 + xoff + at] = x; if (!a.packed) a.v1[(uint64_t)d * a.cap1 + xoff + at] = sv[j]; }
             else *a.flag = 1;
         }
     }
 }
 
-__global__ void k_pp_tiles(const unsigned long long *__restrict__ count1, uint64_t cap1, uint32_t *__restrict__ tile_start,
-                           unsigned long long *__restrict__ total, unsigned long long *__restrict__ flag)
+// first tile of every stretch of pass 1 and the number of slots in all (one workgroup of 1024 threads, nseg <= 4096)
+__global__ __launch_bounds__(1024) void k_pp_tiles(const unsigned long long *__restrict__ count1, uint64_t segcap, uint32_t nseg,
+                                                   uint32_t *__restrict__ tile_start, unsigned long long *__restrict__ total,
+                                                   unsigned long long *__restrict__ flag)
 {
-    if (blockIdx.x || threadIdx.x) return;
-    uint32_t t = 0;
+    __shared__ uint32_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t t[4], tot = 0;
     unsigned long long sum = 0;
-    for (int s = 0; s < PP_NB; s++) {
-        tile_start[s] = t;
-        if (count1[s] > cap1) *flag = 1;
-        const unsigned long long c = count1[s] < cap1 ? count1[s] : cap1;
-        sum += c;
-        t += (uint32_t)((c + PP_TILE - 1) / PP_TILE);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t s = threadIdx.x * 4 + q;
+        t[q] = 0;
+        if (s < nseg) {
+            if (count1[s] > segcap) *flag = 1;
+            const unsigned long long c = count1[s] < segcap ? count1[s] : segcap;
+            sum += c;
+            t[q] = (uint32_t)((c + PP_TILE - 1) / PP_TILE);
+        }
+        tot += t[q];
     }
-    tile_start[PP_NB] = t;
-    *total = sum;
+    if (sum) atomicAdd(total, sum);                            // zeroed by the caller
+    uint32_t inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t pre = inc - tot;
+    for (uint32_t q = 0; q < wv; q++) pre += wsum[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t s = threadIdx.x * 4 + q;
+        if (s < nseg) tile_start[s] = pre;
+        pre += t[q];
+        if (s + 1 == nseg) tile_start[nseg] = pre;
+    }
 }
 
 template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpArgs a)
@@ -267,14 +295,18 @@ template <int MODE> __global__ __launch_bounds__(PP_THREADS) void k_pp_split(PpA
     __shared__ uint32_t cnt[PP_NB], loff[PP_NB];
     __shared__ unsigned long long gbase[PP_NB];
     __shared__ uint32_t wsum[PP_THREADS / 64];
-    uint32_t lo = 0, hi = PP_NB;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (a.tile_start[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-    const uint32_t seg = lo;
-    const uint64_t segn = min((uint64_t)a.count1[seg], a.cap1);
-    const uint64_t first = (uint64_t)(blockIdx.x - a.tile_start[seg]) * PP_TILE;
+    // tiles2_x != 0: the workgroups of one XCD take a range of the tiles, whole buckets (msd_sort.hip, k_msd_split)
+    const uint32_t tile = a.tiles2_x ? (blockIdx.x & 7u) * a.tiles2_x + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= a.tiles2) return;
+    uint32_t lo = 0, hi = PP_NB * (uint32_t)a.xs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (a.tile_start[mid] <= tile) lo = mid; else hi = mid; }
+    const uint32_t seg = lo / (uint32_t)a.xs;
+    const uint64_t segn = min((uint64_t)a.count1[lo], a.segcap);
+    const uint64_t first = (uint64_t)(tile - a.tile_start[lo]) * PP_TILE;
     const uint32_t have = (uint32_t)min((uint64_t)PP_TILE, segn - first);
-    const uint64_t *inw = a.w1 + (uint64_t)seg * a.cap1 + first;
-    const uint32_t *inv = a.v1 + (uint64_t)seg * a.cap1 + first;
+    const uint64_t in0 = (uint64_t)seg * a.cap1 + (uint64_t)(lo % (uint32_t)a.xs) * a.segcap + first;
+    const uint64_t *inw = a.w1 + in0;
+    const uint32_t *inv = a.v1 + in0;
     cnt[threadIdx.x] = 0;
     if (MODE == 1) sp[threadIdx.x] = threadIdx.x ? a.grid[(size_t)PP_NB * seg + threadIdx.x] : 0ull;
     __syncthreads();
@@ -672,13 +704,16 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
 {
     const uint64_t N = ctx->N;
     hipStream_t st = ctx->stream;
-    const uint64_t cap1 = est / PP_NB + est / (4 * PP_NB) + 65536;
+    const int xcd = ctx->opt.msd_xcd < 0 ? 3 : (int)ctx->opt.msd_xcd;
+    const int xs = (xcd & 2) ? 8 : 1;
+    const uint32_t nseg = PP_NB * (uint32_t)xs;
+    const uint64_t cap1 = (est / PP_NB + est / (4 * PP_NB) + 65536 + 127) & ~127ull;     // 8 parts of whole 128-byte lines
     const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, (size_t)PP_NB * cap1 * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsA, (size_t)PP_NB * cap1 * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->msd_w, (size_t)nsub * PP_FN_CAP * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->msd_v, (size_t)nsub * PP_FN_CAP * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, PP_NB * 8 + (PP_NB + 1) * 4 + 64));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, (size_t)nseg * 8 + ((size_t)nseg + 1) * 4 + 64));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_b, nsub * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_c, (nsub + 1) * 8 * 2));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)PP_ARENA * 4 * 5));
@@ -691,9 +726,10 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
     a.any_order = a.payload ? 1 : 0;
     a.probe = 0;
     const bool any = MODE == 1 && a.any_order;
-    a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1;
+    a.w1 = ctx->keysA.as<uint64_t>(); a.v1 = ctx->valsA.as<uint32_t>(); a.cap1 = cap1; a.xs = xs; a.segcap = cap1 / xs;
+    a.tiles2 = 0; a.tiles2_x = 0;
     a.count1 = ctx->dp_a.as<unsigned long long>();
-    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + PP_NB * 8);
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + (size_t)nseg * 8);
     a.tile_start = tile_start;
     a.w2 = ctx->msd_w.as<uint64_t>(); a.v2 = ctx->msd_v.as<uint32_t>(); a.count2 = ctx->dp_b.as<uint32_t>();
     unsigned long long *wide = ctx->dp_c.as<unsigned long long>(), *off = wide + (nsub + 1);
@@ -705,13 +741,13 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
     a.flag = flag;
     a.wout = nullptr; a.vout = nullptr;
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 24, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, PP_NB * 8, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
     hipLaunchKernelGGL((k_pp_pack_split<MODE>), dim3(fbg_blocks(N, (uint64_t)PP_TILE * nparts)), dim3(PP_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_pp_tiles, dim3(1), dim3(1), 0, st, a.count1, cap1, tile_start, flag + 2, flag);
+    hipLaunchKernelGGL(k_pp_tiles, dim3(1), dim3(1024), 0, st, a.count1, a.segcap, nseg, tile_start, flag + 2, flag);
     uint32_t tiles2 = 0;
     unsigned long long h3[3] = {0, 0, 0};
-    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tiles2, tile_start + PP_NB, 4, hipMemcpyDeviceToHost, st));
+    FBG_HIP_TRY(ctx, hipMemcpyAsync(&tiles2, tile_start + nseg, 4, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h3, flag, 24, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 2;
@@ -720,7 +756,9 @@ static int pp_sort(fbg_ctx *ctx, const KeyGeom &g, PpArgs &a, uint64_t est, int 
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, (total + 2 * out_offset) * 8));
     if (!g.packed) FBG_TRY(fbg_reserve(ctx, ctx->valsB, (total + 2 * out_offset) * 4));
     a.wout = ctx->keysB.as<uint64_t>() + out_offset; a.vout = ctx->valsB.as<uint32_t>() + out_offset;
-    hipLaunchKernelGGL((k_pp_split<MODE>), dim3(tiles2), dim3(PP_THREADS), 0, st, a);
+    a.tiles2 = tiles2;
+    a.tiles2_x = (xcd & 1) ? (tiles2 + 7) / 8 : 0;
+    hipLaunchKernelGGL((k_pp_split<MODE>), dim3(a.tiles2_x ? 8 * a.tiles2_x : tiles2), dim3(PP_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_pp_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);
     {
         size_t bytes = 0;

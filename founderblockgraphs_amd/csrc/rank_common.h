@@ -112,6 +112,140 @@ __device__ __forceinline__ void rs_update(const RankArgs &a, uint32_t col, uint3
 }
 
 
+// one wave-aggregated append per list: a single update per wave of the workgroup's counter (LDS; it goes to
+// global memory once, when the workgroup is done)
+__device__ __forceinline__ void rs_append(bool want, uint32_t *counter, uint32_t *list, uint32_t region, uint32_t value)
+{
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) {
+        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+        if (slot < region) list[(size_t)blockIdx.x * region + slot] = value;
+    }
+}
+
+#define RS_HALO 8
+
+// Where rank_scan_slow finds the keys and symbols-left of the slots around the one it looks at: index i of a window.
+struct RsLdsView {                             // k_rank_scan: a chunk staged in LDS
+    const uint64_t *skey;
+    const uint32_t *srem;
+    __device__ __forceinline__ uint64_t key(int i) const { return skey[i]; }
+    __device__ __forceinline__ uint32_t rem(int i) const { return srem[i]; }
+};
+struct RsWordView {                            // packed words (key << pb | position) in LDS or global memory, words[lo .. hi) readable
+    const uint64_t *words;
+    const RankArgs *a;
+    int lo, hi;
+    __device__ __forceinline__ uint64_t word(int i) const { return i >= lo && i < hi ? words[i] : 0ull; }
+    __device__ __forceinline__ uint64_t key(int i) const { return word(i) >> a->pb; }
+    __device__ __forceinline__ uint32_t rem(int i) const { return rs_rem<FBG_SLOTS_PACKED>(*a, word(i) & a->pmask); }
+};
+
+// Slots that tie with a neighbour on the whole key, and slots next to such a group, need to look around.
+// i: LDS index of the slot (slot k = base + i - RS_HALO); valid LDS indices are [lo_i, hi_i).
+template <class V>
+__device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const V &v, const int i,
+                                               const int lo_i, const int hi_i, const uint64_t k, bool &want_cand, bool &want_tie)
+{
+    const uint64_t key = v.key(i);
+    const uint32_t rem = v.rem(i);
+    const bool has_prev = i > lo_i, has_next = i + 1 < hi_i;               // neighbours inside the owned range
+    const uint64_t kp = v.key(i - 1), kn = v.key(i + 1);
+    const bool tie = (has_prev && kp == key) || (has_next && kn == key);
+    if (tie) {
+        // bounds of the group, looking at most RS_TG slots either way
+        int h = i, t = i;
+        while (h > lo_i && i - h < RS_TG && v.key(h - 1) == key) h--;
+        bool big = h > lo_i && v.key(h - 1) == key;
+        while (t + 1 < hi_i && t - i < RS_TG && v.key(t + 1) == key) t++;
+        big = big || (t + 1 < hi_i && v.key(t + 1) == key) || t - h + 1 > RS_TG;
+        bool simple = !big;
+        if (simple && a.part_mode && (k - (uint64_t)(i - h) < a.own_lo + 2 || k + (uint64_t)(t - i) + 2 >= a.own_hi))
+            simple = false;                                                                    // partition edge
+        if (simple) {
+            // every member: K real symbols, columns all different, and different from the slots next to the group
+            uint32_t cols[RS_TG];
+            const int s = t - h + 1;
+#pragma unroll
+            for (int q = 0; q < RS_TG; q++) {
+                cols[q] = 0xffffffffu - (uint32_t)q;
+                if (q < s) {
+                    cols[q] = v.rem(h + q);
+                    if (cols[q] < (uint32_t)a.K) simple = false;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RS_TG; q++)
+#pragma unroll
+                for (int r = q + 1; r < RS_TG; r++)
+                    if (cols[q] == cols[r]) simple = false;
+            if (simple && h > lo_i) {
+                if (h - 1 > lo_i && v.key(h - 2) == v.key(h - 1)) simple = false;                // tie groups side by side
+                const uint32_t oc = v.rem(h - 1);
+#pragma unroll
+                for (int q = 0; q < RS_TG; q++)
+                    if (cols[q] == oc) simple = false;
+            }
+            if (simple && t + 1 < hi_i) {
+                if (t + 2 < hi_i && v.key(t + 2) == v.key(t + 1)) simple = false;
+                const uint32_t oc = v.rem(t + 1);
+#pragma unroll
+                for (int q = 0; q < RS_TG; q++)
+                    if (cols[q] == oc) simple = false;
+            }
+        }
+        if (simple) want_tie = i == h;
+        else want_cand = true;
+        return;
+    }
+    if (rem == 0) return;
+    // not a tie itself, but next to a tie group whose final order is not known here: any member may end up next to
+    // this slot.  Same column anywhere in it -> run treatment; LCP with it: the member with most symbols left
+    const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);           // neighbour not known yet
+    bool run = (has_prev && v.rem(i - 1) == rem) || (has_next && v.rem(i + 1) == rem);
+    uint32_t mrp = has_prev ? v.rem(i - 1) : 0u, mrn = has_next ? v.rem(i + 1) : 0u;
+    if (has_prev && i - 1 > lo_i && v.key(i - 2) == kp) {
+        int j = i - 1, cnt = 0;
+        uint32_t mr = 0;
+        for (;;) {
+            const uint32_t rj = v.rem(j);
+            mr = max(mr, rj);
+            run = run || rj == rem;
+            cnt++;
+            if (j == lo_i || v.key(j - 1) != kp) break;
+            if (cnt == RS_TG) { run = true; break; }
+            j--;
+        }
+        mrp = mr;
+    }
+    if (has_next && i + 2 < hi_i && v.key(i + 2) == kn) {
+        int j = i + 1, cnt = 0;
+        uint32_t mr = 0;
+        for (;;) {
+            const uint32_t rj = v.rem(j);
+            mr = max(mr, rj);
+            run = run || rj == rem;
+            cnt++;
+            if (j + 1 >= hi_i || v.key(j + 1) != kn) break;
+            if (cnt == RS_TG) { run = true; break; }
+            j++;
+        }
+        mrn = mr;
+    }
+    if (edge || run) { want_cand = true; return; }
+    const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), mrp) : 0u;
+    const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), mrn) : 0u;
+    const uint32_t g = max(lp, ln) + 1;
+    if (g >= a.g_min || rem <= 64) rs_update(a, rs_col_of_rem(a, rem), g);
+}
+
+
 // ---- host side ----------------------------------------------------------------------------------------------
 static inline int rs_layout(const KeyGeom &g) { return g.packed ? FBG_SLOTS_PACKED : g.wide ? FBG_SLOTS_WIDE : FBG_SLOTS_PAIRS; }
 

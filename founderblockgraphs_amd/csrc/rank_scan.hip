@@ -39,126 +39,11 @@
 
 #include "rank_common.h"
 
-// one wave-aggregated append per list: a single update per wave of the workgroup's counter (LDS; it goes to
-// global memory once, when the workgroup is done)
-__device__ __forceinline__ void rs_append(bool want, uint32_t *counter, uint32_t *list, uint32_t region, uint32_t value)
-{
-    const unsigned long long mask = __ballot(want);
-    if (!mask) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (want) {
-        const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-        if (slot < region) list[(size_t)blockIdx.x * region + slot] = value;
-    }
-}
-
 // k_rank_scan stages a chunk of 256 slots (+ RS_HALO either side) in LDS as (key, column): all the looking around
 // that tie groups need happens there.
-#define RS_HALO 8
 #define RS_ITEMS 4
 #define RS_THREADS 256
 #define RS_CHUNK (RS_THREADS * RS_ITEMS)
-
-// Slots that tie with a neighbour on the whole key, and slots next to such a group, need to look around.
-// i: LDS index of the slot (slot k = base + i - RS_HALO); valid LDS indices are [lo_i, hi_i).
-__device__ __forceinline__ void rank_scan_slow(const RankArgs &a, const uint64_t *skey, const uint32_t *srem, const int i,
-                                               const int lo_i, const int hi_i, const uint64_t k, bool &want_cand, bool &want_tie)
-{
-    const uint64_t key = skey[i];
-    const uint32_t rem = srem[i];
-    const bool has_prev = i > lo_i, has_next = i + 1 < hi_i;               // neighbours inside the owned range
-    const uint64_t kp = skey[i - 1], kn = skey[i + 1];
-    const bool tie = (has_prev && kp == key) || (has_next && kn == key);
-    if (tie) {
-        // bounds of the group, looking at most RS_TG slots either way
-        int h = i, t = i;
-        while (h > lo_i && i - h < RS_TG && skey[h - 1] == key) h--;
-        bool big = h > lo_i && skey[h - 1] == key;
-        while (t + 1 < hi_i && t - i < RS_TG && skey[t + 1] == key) t++;
-        big = big || (t + 1 < hi_i && skey[t + 1] == key) || t - h + 1 > RS_TG;
-        bool simple = !big;
-        if (simple && a.part_mode && (k - (uint64_t)(i - h) < a.own_lo + 2 || k + (uint64_t)(t - i) + 2 >= a.own_hi))
-            simple = false;                                                                    // partition edge
-        if (simple) {
-            // every member: K real symbols, columns all different, and different from the slots next to the group
-            uint32_t cols[RS_TG];
-            const int s = t - h + 1;
-#pragma unroll
-            for (int q = 0; q < RS_TG; q++) {
-                cols[q] = 0xffffffffu - (uint32_t)q;
-                if (q < s) {
-                    cols[q] = srem[h + q];
-                    if (cols[q] < (uint32_t)a.K) simple = false;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < RS_TG; q++)
-#pragma unroll
-                for (int r = q + 1; r < RS_TG; r++)
-                    if (cols[q] == cols[r]) simple = false;
-            if (simple && h > lo_i) {
-                if (h - 1 > lo_i && skey[h - 2] == skey[h - 1]) simple = false;                // tie groups side by side
-                const uint32_t oc = srem[h - 1];
-#pragma unroll
-                for (int q = 0; q < RS_TG; q++)
-                    if (cols[q] == oc) simple = false;
-            }
-            if (simple && t + 1 < hi_i) {
-                if (t + 2 < hi_i && skey[t + 2] == skey[t + 1]) simple = false;
-                const uint32_t oc = srem[t + 1];
-#pragma unroll
-                for (int q = 0; q < RS_TG; q++)
-                    if (cols[q] == oc) simple = false;
-            }
-        }
-        if (simple) want_tie = i == h;
-        else want_cand = true;
-        return;
-    }
-    if (rem == 0) return;
-    // not a tie itself, but next to a tie group whose final order is not known here: any member may end up next to
-    // this slot.  Same column anywhere in it -> run treatment; LCP with it: the member with most symbols left
-    const bool edge = a.part_mode && (k < a.own_lo + 2 || k + 2 >= a.own_hi);           // neighbour not known yet
-    bool run = (has_prev && srem[i - 1] == rem) || (has_next && srem[i + 1] == rem);
-    uint32_t mrp = has_prev ? srem[i - 1] : 0u, mrn = has_next ? srem[i + 1] : 0u;
-    if (has_prev && i - 1 > lo_i && skey[i - 2] == kp) {
-        int j = i - 1, cnt = 0;
-        uint32_t mr = 0;
-        for (;;) {
-            const uint32_t rj = srem[j];
-            mr = max(mr, rj);
-            run = run || rj == rem;
-            cnt++;
-            if (j == lo_i || skey[j - 1] != kp) break;
-            if (cnt == RS_TG) { run = true; break; }
-            j--;
-        }
-        mrp = mr;
-    }
-    if (has_next && i + 2 < hi_i && skey[i + 2] == kn) {
-        int j = i + 1, cnt = 0;
-        uint32_t mr = 0;
-        for (;;) {
-            const uint32_t rj = srem[j];
-            mr = max(mr, rj);
-            run = run || rj == rem;
-            cnt++;
-            if (j + 1 >= hi_i || skey[j + 1] != kn) break;
-            if (cnt == RS_TG) { run = true; break; }
-            j++;
-        }
-        mrn = mr;
-    }
-    if (edge || run) { want_cand = true; return; }
-    const uint32_t lp = has_prev ? min(min(rs_key_lcp(kp, key, a.b, a.key_bits), rem), mrp) : 0u;
-    const uint32_t ln = has_next ? min(min(rs_key_lcp(key, kn, a.b, a.key_bits), rem), mrn) : 0u;
-    const uint32_t g = max(lp, ln) + 1;
-    if (g >= a.g_min || rem <= 64) rs_update(a, rs_col_of_rem(a, rem), g);
-}
 
 // A few thousand workgroups, each walking chunks of RS_CHUNK slots of the SA; a thread owns RS_ITEMS consecutive
 // slots.  Per chunk: (1) keys and columns into LDS -- the global loads of the NEXT chunk are issued right away, so
@@ -351,7 +236,7 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
                     const int i = sq[q];
                     k = base + (uint64_t)(i - RS_HALO);
                     const bool is_tie = (i > lo_i && skey[i - 1] == skey[i]) || (i + 1 < hi_i && skey[i + 1] == skey[i]);
-                    if (!(a.values_only && is_tie)) rank_scan_slow(a, skey, srem, i, lo_i, hi_i, k, want_cand, want_tie);
+                    if (!(a.values_only && is_tie)) rank_scan_slow(a, RsLdsView{skey, srem}, i, lo_i, hi_i, k, want_cand, want_tie);
                 }
                 if (!a.values_only) {
                     rs_append(want_cand, &s_cand_n, a.cand, a.region, (uint32_t)k);
@@ -367,6 +252,36 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
         __syncthreads();
     }
     if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
+}
+
+// The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_p) could not classify from its sub-bucket alone:
+// rank_scan_slow on the RS_HALO slots either side of each, read from global memory.  Workgroup b appends to region
+// row_base + b of the lists.
+#define RS_LIST_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32_t *__restrict__ list, uint64_t count, uint32_t row_base)
+{
+    __shared__ uint32_t s_cand_n, s_tie_n;
+    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
+    __syncthreads();
+    const size_t row = (size_t)(row_base + blockIdx.x) - blockIdx.x;      // rs_append adds blockIdx.x itself
+    uint32_t *cand = a.cand + row * a.region, *ties = a.ties + row * a.tie_region;
+    for (uint64_t e0 = (uint64_t)blockIdx.x * 256; e0 < count; e0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t e = e0 + threadIdx.x;
+        bool want_cand = false, want_tie = false;
+        uint64_t k = 0;
+        if (e < count) {
+            k = list[e];
+            const int64_t base = (int64_t)k - RS_HALO;                     // slot of window index 0
+            const int lo_i = (int)max((int64_t)0, (int64_t)a.own_lo - base);
+            const int hi_i = (int)min((int64_t)(2 * RS_HALO + 1), (int64_t)a.own_hi - base);
+            const RsWordView view{a.keys + base, &a, lo_i, hi_i};
+            rank_scan_slow(a, view, RS_HALO, lo_i, hi_i, k, want_cand, want_tie);
+        }
+        rs_append(want_cand, &s_cand_n, cand, a.region, (uint32_t)k);
+        rs_append(want_tie, &s_tie_n, ties, a.tie_region, (uint32_t)k);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { a.blk_count[row_base + blockIdx.x] = s_cand_n; a.tie_count[row_base + blockIdx.x] = s_tie_n; }
 }
 
 // the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
@@ -742,13 +657,23 @@ static int rs_join(fbg_ctx *ctx)
 // k_rank_scan over the owned slots, the small tie groups, then the candidates: compacted, sorted, tie groups put
 // in final order.  On return a.cand / a.pm name the sorted list and its scratch; *T = ~0 when a workgroup's
 // candidate region overflowed (similar rows: the caller takes another path).
-static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches)
+static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches, bool premade = false)
 {
     hipStream_t st = ctx->stream;
     const uint64_t own = a.own_hi - a.own_lo;
-    const unsigned rs_blocks = fbg_blocks(own, RS_CHUNK, 256 * 16);
-    const uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
-    const uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
+    unsigned rs_blocks = fbg_blocks(own, RS_CHUNK, 256 * 16);
+    uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
+    uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
+    if (premade) {
+        // the lists were made by pass 3 of the MSD sort (fbg_rank_fuse_prepare set the regions up); what it left over is
+        // classified now, into RS_LIST_BLOCKS more regions
+        rs_blocks = ctx->fz_blocks + RS_LIST_BLOCKS;
+        region = a.region; tie_region = a.tie_region;
+        FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)(rs_blocks + 1) * 4));
+        FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
+        hipLaunchKernelGGL(k_rank_scan_list, dim3(RS_LIST_BLOCKS), dim3(256), 0, st, a, ctx->ps_c.as<uint32_t>(), ctx->fz_defer_n, ctx->fz_blocks);
+        FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
+    } else {
     FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rs_blocks * region * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)rs_blocks * tie_region * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
@@ -765,6 +690,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
+    }
     if (ctx->opt.no_aux_stream) {
         RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
     } else {
@@ -776,7 +702,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     // ever reuses or frees the buffers under it
     const int rc_rest = [&]() -> int {
         // candidate counts per workgroup -> offsets; total and the largest count come back to the host
-        uint32_t *d_counts = ctx->dp_c.as<uint32_t>(), *d_offs = ctx->dp_d.as<uint32_t>();
+        uint32_t *d_counts = a.blk_count, *d_offs = ctx->dp_d.as<uint32_t>();
         FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
             return rocprim::exclusive_scan(tmp, bytes, d_counts, d_offs, 0u, (size_t)(rs_blocks + 1), rocprim::plus<uint32_t>(), st);
         }));
@@ -851,6 +777,45 @@ static int rs_pick_threshold(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, ui
     return FBG_OK;
 }
 
+// Everything k_msd_finish_p<true> (msd_sort.hip) needs to make the lists of the scan while it sorts: the arguments of the
+// scan for the packed slots at `keys` with the threshold above K, column maxima and counters zeroed, list regions for
+// `blocks` workgroups plus those of k_rank_scan_list, and the list of the slots left to that kernel.
+int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, unsigned blocks, RankArgs *out, uint32_t **defer,
+                          uint32_t *defer_cap, unsigned long long **fcnt)
+{
+    const uint64_t N = ctx->N, n = ctx->n;
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
+    unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    RankArgs a;
+    rs_args_init(ctx, a, keys, nullptr, N, FBG_SLOTS_PACKED, g.pb, g.b, g.key_bits, g.K);
+    a.g_min = (uint32_t)g.K + 1;
+    const unsigned rows = blocks + RS_LIST_BLOCKS;
+    const uint32_t region = (uint32_t)((N / blocks) / 8 + 256), tie_region = (uint32_t)((N / blocks) / 6 + 256);
+    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rows * region * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)rows * tie_region * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
+    a.big = ctx->big_groups.as<uint32_t>();
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)(rows + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (size_t)(rows + 1) * 4));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_a.p, 0, (size_t)(rows + 1) * 4, st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_b.p, 0, (size_t)(rows + 1) * 4, st));
+    a.cand = ctx->list.as<uint32_t>(); a.blk_count = ctx->ps_a.as<uint32_t>(); a.region = region;
+    a.ties = ctx->tie_list.as<uint32_t>(); a.tie_count = ctx->ps_b.as<uint32_t>(); a.tie_region = tie_region;
+    // 2 * RS_HALO slots of every sub-bucket at most, and the sub-buckets that overflowed their stretch in full
+    const uint64_t cap = (uint64_t)2 * RS_HALO * 512 * 512 + (1u << 21);
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, cap * 4));
+    *defer = ctx->ps_c.as<uint32_t>();
+    *defer_cap = (uint32_t)cap;
+    *fcnt = ctx->scalars.as<unsigned long long>() + 116;
+    FBG_HIP_TRY(ctx, hipMemsetAsync(*fcnt, 0, 3 * sizeof(unsigned long long), st));
+    ctx->fz_region = region; ctx->fz_tie_region = tie_region;
+    *out = a;
+    return FBG_OK;
+}
+
 // Called by fbg_suffix_sort right after the round-0 sort of the compact keys.  *done = 1 when the rank-order scan
 // covered the whole input (ctx->ranked set); 0 = continue with the record path.
 int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &geom, int *done)
@@ -862,18 +827,34 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     const int layout = rs_layout(geom);
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
-    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
-    FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    int launches = 0;
+    // Pass 3 of the MSD sort has classified the slots already (msd_sort.hip, k_msd_finish_p<true>) and counted the slots that
+    // tie on the key -- all of them, where rs_pick_threshold looks at a sample.  Its lists stand if the regime is the one
+    // it assumed: so many ties in every column that nothing else can be a column maximum (g_min = K + 1).
+    bool premade = false;
+    if (ctx->fz_valid) {
+        ctx->fz_valid = false;
+        if (ctx->fz_ties * 4 > N) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);   // similar rows: not for this scan
+        premade = layout == FBG_SLOTS_PACKED && !ctx->opt.rank_no_threshold && N > (1u << 22) &&
+                  (double)ctx->fz_ties / (double)N * (double)ctx->m >= 32.0;
+    }
+    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));             // (before rs_args_init reads the pointer)
     RankArgs a;
     rs_args_init(ctx, a, keys, vals, N, layout, geom.pb, geom.b, geom.key_bits, geom.K);
-    int launches = 0;
-    int reject = 0;
-    FBG_TRY(rs_pick_threshold(ctx, a, keys, N, geom, &reject, &launches));
-    if (reject) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
     uint64_t T = 0;
-    FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
+    if (premade) {
+        a.g_min = (uint32_t)geom.K + 1;
+        a.cand = ctx->list.as<uint32_t>(); a.blk_count = ctx->ps_a.as<uint32_t>(); a.region = ctx->fz_region;
+        a.ties = ctx->tie_list.as<uint32_t>(); a.tie_count = ctx->ps_b.as<uint32_t>(); a.tie_region = ctx->fz_tie_region;
+    } else {
+        FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
+        FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+        int reject = 0;
+        FBG_TRY(rs_pick_threshold(ctx, a, keys, N, geom, &reject, &launches));
+        if (reject) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+    }
+    FBG_TRY(rs_classify(ctx, a, layout, &T, &launches, premade));
     if (T == ~0ull) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
     if (T > 0) {
         RS_LAUNCH(k_runs, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);

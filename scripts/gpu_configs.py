@@ -29,6 +29,9 @@ def star_msa(m, n, p=0.01, seed=7):
 
 def run(name, m, n, elastic=True, ignore="", gap_fraction=0.0, gap_run=0, n_fraction=0.0, star=False, reps=2, gapped=False, star_gaps=0.0):
     eng = F.Engine(0)
+    for kv in filter(None, os.environ.get("FBG_OPTS", "").split(",")):      # debug options for every run: FBG_OPTS=key=value,key=value
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     st = torch.cuda.Stream()
     torch.cuda.set_stream(st)
     eng.set_stream(st.cuda_stream)
