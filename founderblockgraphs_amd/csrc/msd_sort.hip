@@ -411,159 +411,284 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
                                                 fshift - a.pb, sub, biglist, &nbig_lds, a.probe);
 }
 
-// ---- pass 3 by workgroups that stay, with the classification of the extension scan fused in ---------------------------
-// k_msd_finish starts a workgroup per sub-bucket: its first loads leave when it starts and nothing else of it can run until
-// they are back (1.4 of 4.3 ms at 10^9 slots).  Here a workgroup takes sub-buckets b, b + G, ... and has the slots of the
-// next one on their way (in registers) while it sorts the current one.
-// FUSED: with the sub-bucket sorted in LDS the workgroup also does what k_rank_scan (rank_scan.hip) does in a pass of its
-// own over the sorted slots when the threshold lies above K (rs_pick_threshold: a.g_min = K + 1; the caller checks
-// afterwards that this was the regime): only slots that tie on the key, sit next to a tie group, share their column with
-// a neighbour or lie in the 64 columns nearest a row end can matter.  Those -- a seventh of the slots -- queue up in LDS
-// and go through rank_scan_slow, the scan's general code, reading the sorted sub-bucket; slots within 8 of the
-// sub-bucket's ends (their neighbourhood is another workgroup's) are written to a list that k_rank_scan_list works off
-// from global memory afterwards.  Same lists (ra.cand, ra.ties, per-workgroup regions) as k_rank_scan.
+// ---- pass 3 with the classification of the extension scan fused in ------------------------------------------------
+// With the sub-bucket sorted in LDS the workgroup also does what k_rank_scan (rank_scan.hip) does in a pass of its own
+// over the sorted slots when the threshold lies above K (rs_pick_threshold: g_min = K + 1; the caller checks afterwards
+// that this was the regime): only slots that tie on the key, share their column with a neighbour, sit next to a tie
+// group or lie in the 64 columns nearest a row end can matter.  Instructions are what this kernel is short of -- scalar
+// ones more than vector ones (one scalar unit per CU) -- so the pass over all slots does the least it can: a wave looks
+// at 64 consecutive slots, a lane each, the neighbours' key and symbols-left by DPP shifts (lanes 1..62 are settled,
+// consecutive waves overlap by two slots); the first members of tie groups (3 % of the slots) are noted in the wave's own
+// stretch of an LDS list, slots that share a column with a neighbour or lie near a row end (a few in a million) in another.
+// Then the noted group heads are worked on densely, a lane each: a group of two is settled on the spot -- "simple" (k_rank_scan's
+// test: both with K symbols left, four different columns around, no tie group next door) to the tie list, else both to the
+// candidates -- and the outside neighbours that share a column with the far member are queued; longer groups queue all
+// their members and both neighbours.  The queue (duplicates removed by a bitmap) goes through rank_scan_slow, the scan's
+// general code; slots whose neighbourhood lies in another sub-bucket go to a list that k_rank_scan_list works off from
+// global memory.  Lists: MSD_SHARDS chunks each, a workgroup stages its entries in LDS and reserves room in the chunk of
+// its shard once.
 struct FuseArgs {
-    RankArgs ra;
-    uint32_t *defer;                           // slots left to k_rank_scan_list
-    uint32_t defer_cap;
-    unsigned long long *fcnt;                  // [0] entries of defer, [1] slots that tie on the key, [2] != 0: a list overflowed
+    RankArgs ra;                               // geometry, text, column maxima (cand / ties of it unused)
+    uint32_t *ties, *cand, *defer;             // [MSD_SHARDS][*_cap] slots
+    uint32_t tie_cap, cand_cap, defer_cap;
+    unsigned long long *cur;                   // cursors: cur[(list * MSD_SHARDS + shard) * 16], list 0 ties, 1 cand, 2 defer
+    unsigned long long *fcnt;                  // [1] slots that tie on the key, [2] != 0: a list overflowed
 };
 
-template <bool FUSED>
-__global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_msd_finish_p(MsdArgs a, int fshift, uint32_t fmask, FuseArgs f)
+// lane l gets lane l + 1's value (lane 63: 0)
+__device__ __forceinline__ uint32_t msd_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+
+// entries of the lanes in `mask` (wave-uniform) -> a staging list in LDS of capacity cap; *over = 1 when it is full
+__device__ __forceinline__ void msd_stage(unsigned long long mask, uint32_t *counter, uint16_t *list, uint32_t cap, uint32_t value,
+                                          uint32_t *over)
 {
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if ((mask >> lane) & 1ull) {
+        const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+        if (at < cap) list[at] = (uint16_t)value;
+        else *over = 1;
+    }
+}
+
+#define MSD_W_HEADS 288                        // noted per wave: first members of tie groups (expected: 15), ...
+#define MSD_W_ODD 32                           // ... slots that share a column with a neighbour / lie near a row end
+#define MSD_ST_T 1280                          // staged per sub-bucket: heads of simple tie groups, ...
+#define MSD_ST_C 1024                          // ... candidates, ...
+#define MSD_ST_Q 1024                          // ... slots for rank_scan_slow, ...
+#define MSD_ST_D 32                            // ... slots left to k_rank_scan_list (2 * RS_HALO at most)
+#define MSD_EV 62                              // lanes 1 .. 62 of a wave are settled by it
+
+__global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_msd_finish_fused(MsdArgs a, int fshift, uint32_t fmask, FuseArgs f)
+{
+    constexpr int WAVES = MSD_FN_THREADS / 64;
+    constexpr int STAGE16 = WAVES * (MSD_W_HEADS + MSD_W_ODD) + MSD_ST_T + MSD_ST_C + MSD_ST_Q + MSD_ST_D;
     __shared__ uint64_t buf[MSD_FN_CAP];
-    __shared__ uint32_t cl[2 * MSD_FN_BINS];                   // bin counts | bin offsets; afterwards the queue of the classification
+    __shared__ uint32_t cls[2 * MSD_FN_BINS + (1 << MSD_LOW_BITS)];   // bin counts | bin offsets | counts of a crowded bin; afterwards the staged lists
+    static_assert(STAGE16 * 2 <= (2 * MSD_FN_BINS + (1 << MSD_LOW_BITS)) * 4, "the staged lists fit the tables of the sort");
     __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
-    __shared__ uint32_t sub[1 << MSD_LOW_BITS];
     __shared__ uint16_t biglist[MSD_FN_CAP / MSD_BIG_BIN + 1];
     __shared__ uint32_t nbig_lds;
-    __shared__ uint32_t s_q, s_cand_n, s_tie_n, s_defer_n, s_defer_base, s_ties;
-    __shared__ uint32_t s_defer[32];
-    uint32_t *cnt = cl, *loff = cl + MSD_FN_BINS;
-    uint16_t *sq = reinterpret_cast<uint16_t *>(cl);           // MSD_FN_CAP entries
+    __shared__ uint32_t s_n[4], s_base[3], s_ties, s_over;     // staged entries: ties, candidates, defer, queue
+    __shared__ uint32_t s_wh[WAVES + 1], s_wo[WAVES + 1];      // heads / odd slots noted by every wave
+    __shared__ uint32_t seen[MSD_FN_CAP / 32];                  // slots that have been in the queue
+    uint32_t *cnt = cls, *loff = cls + MSD_FN_BINS, *sub = cls + 2 * MSD_FN_BINS;
+    uint16_t *w_heads = reinterpret_cast<uint16_t *>(cls), *w_odd = w_heads + WAVES * MSD_W_HEADS, *st_t = w_odd + WAVES * MSD_W_ODD,
+             *st_c = st_t + MSD_ST_T, *sq = st_c + MSD_ST_C, *st_d = sq + MSD_ST_Q;
     constexpr int ITEMS = MSD_FN_ITEMS;
-    const uint32_t nsub = MSD_NB * MSD_NB, G = gridDim.x;
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; s_ties = 0; }
-    uint32_t sb = blockIdx.x;
-    uint32_t have_n = sb < nsub ? a.count2[sb] : 0u;
-    uint32_t have_nn = sb + G < nsub ? a.count2[sb + G] : 0u;
-    if (have_n > MSD_FN_CAP) have_n = 0;                        // the larger ones: k_msd_finish_big
-    uint64_t wn[ITEMS];
-    auto fetch = [&](uint32_t s, uint32_t have) {
-        const uint64_t *in = a.buf2 + (uint64_t)s * MSD_FN_CAP;
+    const uint32_t have = a.count2[blockIdx.x];
+    if (have == 0 || have > MSD_FN_CAP) return;                // the larger ones: k_msd_finish_big, k_msd_defer_big
+    const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
+    uint64_t w[ITEMS];
 #pragma unroll
-        for (int r = 0; r < ITEMS; r++) {
-            const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
-            wn[r] = j < have ? in[j] : ~0ull;
-        }
-    };
-    fetch(sb, have_n);
-    uint32_t my_ties = 0;
-    for (; sb < nsub; sb += G) {
-        const uint32_t have = have_n;
-        uint64_t w[ITEMS];
-#pragma unroll
-        for (int r = 0; r < ITEMS; r++) w[r] = wn[r];
-        have_n = have_nn > MSD_FN_CAP ? 0u : have_nn;
-        have_nn = (uint64_t)sb + 2ull * G < nsub ? a.count2[sb + 2 * G] : 0u;
-        if (sb + G < nsub) fetch(sb + G, have_n);
-        if (have == 0) continue;                                // uniform
-        const uint64_t o = a.off[sb];
-        if (FUSED && threadIdx.x == 0) { s_q = 0; s_defer_n = 0; }
-        msd_finish_sort<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
-        uint64_t *out = a.out + o;
-        if (!FUSED) {
-#pragma unroll
-            for (int r = 0; r < ITEMS; r++) {
-                const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
-                if (j < have) out[j] = buf[j];
-            }
-            __syncthreads();                                    // buf is rewritten by the next round
-            continue;
-        }
-        // the sorted slots leave; every slot looks at its two neighbours either way
-        const RankArgs &ra = f.ra;
-#pragma unroll 2
-        for (int r = 0; r < ITEMS; r++) {
-            const int j = (int)(threadIdx.x + r * MSD_FN_THREADS);
-            bool want = false, defer = false;
-            if (j < (int)have) {
-                const uint64_t x = buf[j];
-                out[j] = x;
-                defer = j < 2 || j + 2 >= (int)have;            // a neighbour, or a neighbour's neighbour, lies in another sub-bucket
-                if (!defer) {
-                    const uint64_t xm2 = buf[j - 2], xm1 = buf[j - 1], xp1 = buf[j + 1], xp2 = buf[j + 2];
-                    const uint64_t key = x >> ra.pb, km1 = xm1 >> ra.pb, kp1 = xp1 >> ra.pb;
-                    const uint32_t rem = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
-                    const uint32_t remm = rs_rem<FBG_SLOTS_PACKED>(ra, xm1 & ra.pmask), remp = rs_rem<FBG_SLOTS_PACKED>(ra, xp1 & ra.pmask);
-                    const bool tie = km1 == key || kp1 == key;
-                    const bool adj = (xm2 >> ra.pb) == km1 || (xp2 >> ra.pb) == kp1;
-                    const bool run = rem != 0 && (remm == rem || remp == rem);
-                    const bool near_end = rem != 0 && rem <= 64;
-                    want = tie || adj || run || near_end;
-                    my_ties += tie ? 1u : 0u;
-                    if (want && (j < RS_HALO || j + RS_HALO >= (int)have)) { want = false; defer = true; }
-                }
-            }
-            {
-                const unsigned long long mask = __ballot(want);
-                if (mask) {
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)mask) - 1;
-                    if (lane == leader) base = atomicAdd(&s_q, (uint32_t)__popcll(mask));
-                    base = __shfl(base, leader, 64);
-                    if (want) sq[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)j;
-                }
-            }
-            if (__ballot(defer)) {                              // at most 2 * RS_HALO slots of a sub-bucket
-                if (defer) { const uint32_t e = atomicAdd(&s_defer_n, 1u); if (e < 32) s_defer[e] = (uint32_t)j; }
-            }
-        }
-        __syncthreads();
-        {
-            const uint32_t qn = s_q;
-            const RsWordView view{buf, &ra, 0, (int)have};
-            for (uint32_t q0 = 0; q0 < qn; q0 += MSD_FN_THREADS) {
-                if (q0 + (threadIdx.x & ~63u) >= qn) break;    // wave-uniform
-                const uint32_t q = q0 + threadIdx.x;
-                bool want_cand = false, want_tie = false;
-                uint64_t k = 0;
-                if (q < qn) {
-                    const int i = sq[q];
-                    k = o + (uint64_t)i;
-                    rank_scan_slow(ra, view, i, 0, (int)have, k, want_cand, want_tie);
-                }
-                rs_append(want_cand, &s_cand_n, ra.cand, ra.region, (uint32_t)k);
-                rs_append(want_tie, &s_tie_n, ra.ties, ra.tie_region, (uint32_t)k);
-            }
-            const uint32_t nd = min(s_defer_n, 32u);
-            if (threadIdx.x == 0 && nd) s_defer_base = (uint32_t)atomicAdd(f.fcnt, (unsigned long long)nd);
-        }
-        __syncthreads();
-        {
-            const uint32_t nd = min(s_defer_n, 32u);
-            if (threadIdx.x < nd) {
-                const uint32_t e = s_defer_base + threadIdx.x;
-                if (e < f.defer_cap) f.defer[e] = (uint32_t)(o + s_defer[threadIdx.x]);
-                else f.fcnt[2] = 1;
-            }
-        }
-        __syncthreads();                                        // the queue and the lists are reset by the next round
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
+        w[r] = j < have ? in[j] : ~0ull;
     }
-    if (FUSED) {
-        // the tie count: wave sums -> one LDS word -> one global add
-        uint32_t t = my_ties;
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+    if (threadIdx.x == 4) { s_ties = 0; s_over = 0; }
+    if (threadIdx.x < MSD_FN_CAP / 32) seen[threadIdx.x] = 0;
+    msd_finish_sort<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
+    const uint64_t o = a.off[blockIdx.x];
+    uint64_t *out = a.out + o;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
-        if (lane == 0 && t) atomicAdd(&s_ties, t);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            f.ra.blk_count[blockIdx.x] = s_cand_n;
-            f.ra.tie_count[blockIdx.x] = s_tie_n;
-            if (s_ties) atomicAdd(f.fcnt + 1, (unsigned long long)s_ties);
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
+        if (j < have) out[j] = buf[j];
+    }
+    if (a.probe & 64) return;                                   // timing probes (option msd_probe = 2): sort and store only, ...
+    const RankArgs &ra = f.ra;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ihave = (int)have;
+    uint32_t over = 0;
+    // ---- every slot: does it head a tie group, does it share its column with a neighbour, is it near a row end ----
+    {
+        const int rounds = (ihave + MSD_EV * WAVES - 1) / (MSD_EV * WAVES);
+        uint32_t nh = 0, no = 0, nties = 0;                     // (wave-uniform)
+        uint16_t *my_heads = w_heads + wv * MSD_W_HEADS, *my_odd = w_odd + wv * MSD_W_ODD;
+        for (int q = 0; q < rounds; q++) {
+            const int j = (q * WAVES + wv) * MSD_EV - 1 + lane;
+            const bool inr = j >= 0 && j < ihave;
+            const uint64_t x = inr ? buf[j] : 0ull;
+            const uint64_t key = x >> ra.pb;
+            const uint32_t rem = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
+            const uint64_t keyn = ((uint64_t)msd_from_next((uint32_t)(key >> 32)) << 32) | msd_from_next((uint32_t)key);
+            const uint32_t remn = msd_from_next(rem);
+            // bit l of a mask speaks of the slot of lane l (and the one after it)
+            const unsigned long long E = __ballot(key == keyn) & ~(1ull << 63);            // ties with the next slot
+            const unsigned long long R1 = __ballot(rem == remn && rem != 0) & ~(1ull << 63);   // same column as the next slot
+            const unsigned long long NE = __ballot(rem - 1u < 64u);                        // a row pointer in the 64 columns nearest the row end
+            const bool mine = inr && lane >= 1 && lane <= MSD_EV;
+            const unsigned long long D = __ballot(mine && (j < 3 || j + 3 >= ihave));      // a neighbour within 3 lies in another sub-bucket
+            const unsigned long long EV = __ballot(mine) & ~D;
+            const unsigned long long TIE = E | (E << 1);
+            // first member of its group -- or the first one this workgroup may look at (slot 3), when the group begins in the three
+            // slots that are left to k_rank_scan_list
+            const unsigned long long H = EV & ((E & ~(E << 1)) | ((E << 1) & __ballot(j == 3)));
+            const unsigned long long O = EV & ~TIE & (R1 | (R1 << 1) | NE);
+            nties += (uint32_t)__popcll(TIE & EV);
+            if ((H >> lane) & 1ull) {
+                const uint32_t at = nh + (uint32_t)__popcll(H & ((1ull << lane) - 1));
+                if (at < MSD_W_HEADS) my_heads[at] = (uint16_t)j; else over = 1;
+            }
+            nh += (uint32_t)__popcll(H);
+            if (O) {
+                if ((O >> lane) & 1ull) {
+                    const uint32_t at = no + (uint32_t)__popcll(O & ((1ull << lane) - 1));
+                    if (at < MSD_W_ODD) my_odd[at] = (uint16_t)j; else over = 1;
+                }
+                no += (uint32_t)__popcll(O);
+            }
+            msd_stage(D, &s_n[2], st_d, MSD_ST_D, (uint32_t)j, &over);
         }
+        if (lane == 0) {
+            s_wh[wv] = min(nh, (uint32_t)MSD_W_HEADS); s_wo[wv] = min(no, (uint32_t)MSD_W_ODD);
+            if (nties) atomicAdd(&s_ties, nties);
+        }
+    }
+    __syncthreads();
+    if (a.probe & 128) return;                                  // ... the pass over all slots as well, ...
+    // ---- the noted slots, a lane each: odd slots into the queue, group heads settled or queued ----
+    auto enqueue = [&](bool want, uint32_t i) {                // (all lanes of the wave call)
+        bool fresh = false;
+        if (want) fresh = ((atomicOr(&seen[i >> 5], 1u << (i & 31)) >> (i & 31)) & 1u) == 0;
+        msd_stage(__ballot(fresh), &s_n[3], sq, MSD_ST_Q, i, &over);
+    };
+    {
+        uint32_t tot_o = 0, tot_h = 0;
+#pragma unroll
+        for (int q = 0; q < WAVES; q++) { tot_o += s_wo[q]; tot_h += s_wh[q]; }
+        for (uint32_t e0 = 0; e0 < tot_o; e0 += MSD_FN_THREADS) {
+            if (e0 + (threadIdx.x & ~63u) >= tot_o) break;     // wave-uniform
+            uint32_t e = e0 + threadIdx.x, i = 0;
+            const bool on = e < tot_o;
+            if (on) {
+                int q = 0;
+                while (e >= s_wo[q]) { e -= s_wo[q]; q++; }
+                i = w_odd[q * MSD_W_ODD + e];
+            }
+            enqueue(on, i);
+        }
+        for (uint32_t e0 = 0; e0 < tot_h; e0 += MSD_FN_THREADS) {
+            if (e0 + (threadIdx.x & ~63u) >= tot_h) break;     // wave-uniform
+            uint32_t e = e0 + threadIdx.x;
+            const bool on = e < tot_h;
+            int i = 3;
+            if (on) {
+                int q = 0;
+                while (e >= s_wh[q]) { e -= s_wh[q]; q++; }
+                i = w_heads[q * MSD_W_HEADS + e];
+            }
+            // slots i - 2 .. i + 3 (3 <= i, i + 3 < have): keys k[0..5], symbols left r[0..5]; slot i is k[2]
+            uint64_t k[6];
+            uint32_t r[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                const uint64_t x = buf[i - 2 + d];
+                k[d] = x >> ra.pb;
+                r[d] = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
+            }
+            // a group of two, both members this workgroup's to settle (a group that reaches into the first or last three slots
+            // of the sub-bucket is classified slot by slot instead, like those)
+            const bool pair = on && k[1] != k[2] && k[2] == k[3] && k[3] != k[4] && i + 4 < ihave;
+            bool t_simple = false, c_pair = false, q_b = false, q_a = false;
+            if (pair) {
+                t_simple = r[2] >= (uint32_t)ra.K && r[3] >= (uint32_t)ra.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] && r[1] != r[3] &&
+                           k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
+                c_pair = !t_simple;
+                // a slot next to the pair that shares its column with the pair's far member may end up next to it (a run)
+                q_b = k[0] != k[1] && r[1] != 0 && r[1] == r[3] && i - 1 >= 3;
+                q_a = k[4] != k[5] && r[4] != 0 && r[4] == r[2] && i + 2 + 3 < ihave;
+            }
+            msd_stage(__ballot(t_simple), &s_n[0], st_t, MSD_ST_T, (uint32_t)i, &over);
+            {
+                // both members of an entangled pair
+                const unsigned long long m = __ballot(c_pair);
+                if (m) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(&s_n[1], 2u * (uint32_t)__popcll(m));
+                    base = __shfl(base, leader, 64);
+                    if (c_pair) {
+                        const uint32_t at = base + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                        if (at + 1 < MSD_ST_C) { st_c[at] = (uint16_t)i; st_c[at + 1] = (uint16_t)(i + 1); } else over = 1;
+                    }
+                }
+            }
+            enqueue(q_b, (uint32_t)(i - 1));
+            enqueue(q_a, (uint32_t)(i + 2));
+            // a longer group: every member and the slots on either side take the general code
+            const unsigned long long lng = __ballot(on && !pair);
+            if (lng) {
+                const bool mine = on && !pair;
+                int m = i, end = i;
+                if (mine) { while (end + 1 < ihave && (buf[end + 1] >> ra.pb) == k[2]) end++; }
+                enqueue(mine && k[1] != k[2] && k[0] != k[1] && i - 1 >= 3, (uint32_t)(i - 1));
+                enqueue(mine && end + 1 + 3 < ihave && (end + 2 >= ihave || (buf[end + 2] >> ra.pb) != (buf[end + 1] >> ra.pb)), (uint32_t)(end + 1));
+                for (;;) {
+                    const bool more = mine && m <= end && m + 3 < ihave;    // (the last three slots of the sub-bucket are deferred already)
+                    if (!__ballot(more)) break;
+                    enqueue(more, (uint32_t)m);
+                    m++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the queue: rank_scan_slow on the sorted sub-bucket; slots within RS_HALO of its ends are left to k_rank_scan_list ----
+    {
+        const uint32_t qn = min(s_n[3], (uint32_t)MSD_ST_Q);
+        const RsWordView view{buf, &ra, 0, ihave};
+        for (uint32_t q0 = 0; q0 < qn; q0 += MSD_FN_THREADS) {
+            if (q0 + (threadIdx.x & ~63u) >= qn) break;        // wave-uniform
+            const uint32_t e = q0 + threadIdx.x;
+            bool want_cand = false, want_tie = false, far = false;
+            uint32_t i = 0;
+            if (e < qn) {
+                i = sq[e];
+                far = (int)i < RS_HALO || (int)i + RS_HALO >= ihave;
+                if (!far) rank_scan_slow(ra, view, (int)i, 0, ihave, o + i, want_cand, want_tie);
+            }
+            msd_stage(__ballot(want_tie), &s_n[0], st_t, MSD_ST_T, i, &over);
+            msd_stage(__ballot(want_cand), &s_n[1], st_c, MSD_ST_C, i, &over);
+            msd_stage(__ballot(far), &s_n[2], st_d, MSD_ST_D, i, &over);
+        }
+    }
+    if (over) s_over = 1;
+    __syncthreads();
+    if (a.probe & 256) return;                                  // ... everything but the hand-over to the lists in global memory
+    const uint32_t shard = blockIdx.x & (MSD_SHARDS - 1);
+    if (threadIdx.x < 3) {
+        const uint32_t caps[3] = {MSD_ST_T, MSD_ST_C, MSD_ST_D};
+        const uint32_t n = min(s_n[threadIdx.x], caps[threadIdx.x]);
+        s_base[threadIdx.x] = n ? (uint32_t)atomicAdd(f.cur + ((size_t)threadIdx.x * MSD_SHARDS + shard) * 16, (unsigned long long)n) : 0u;
+    }
+    if (threadIdx.x == 3) {
+        if (s_ties) atomicAdd(f.fcnt + 1, (unsigned long long)s_ties);
+        if (s_over || s_n[0] > MSD_ST_T || s_n[1] > MSD_ST_C || s_n[2] > MSD_ST_D || s_n[3] > MSD_ST_Q) f.fcnt[2] = 1;
+    }
+    __syncthreads();
+    {
+        const uint32_t nt = min(s_n[0], (uint32_t)MSD_ST_T), nc = min(s_n[1], (uint32_t)MSD_ST_C), nd = min(s_n[2], (uint32_t)MSD_ST_D);
+        const uint32_t o32 = (uint32_t)o;
+        bool full = false;
+        for (uint32_t e = threadIdx.x; e < nt; e += MSD_FN_THREADS) {
+            const uint32_t at = s_base[0] + e;
+            if (at < f.tie_cap) f.ties[(size_t)shard * f.tie_cap + at] = o32 + st_t[e]; else full = true;
+        }
+        for (uint32_t e = threadIdx.x; e < nc; e += MSD_FN_THREADS) {
+            const uint32_t at = s_base[1] + e;
+            if (at < f.cand_cap) f.cand[(size_t)shard * f.cand_cap + at] = o32 + st_c[e]; else full = true;
+        }
+        if (threadIdx.x < nd) {
+            const uint32_t at = s_base[2] + threadIdx.x;
+            if (at < f.defer_cap) f.defer[(size_t)shard * f.defer_cap + at] = o32 + st_d[threadIdx.x]; else full = true;
+        }
+        if (full) f.fcnt[2] = 1;
     }
 }
 
@@ -598,12 +723,13 @@ __global__ __launch_bounds__(256) void k_msd_defer_big(MsdArgs a, const uint32_t
     const uint32_t sb = sb_sorted[e];
     if (e > 0 && sb_sorted[e - 1] == sb) return;
     const uint32_t have = a.count2[sb];
-    if (threadIdx.x == 0) s_base = atomicAdd(f.fcnt, (unsigned long long)have);
+    const uint32_t shard = sb & (MSD_SHARDS - 1);
+    if (threadIdx.x == 0) s_base = atomicAdd(f.cur + ((size_t)2 * MSD_SHARDS + shard) * 16, (unsigned long long)have);
     __syncthreads();
     const uint64_t o = a.off[sb];
     for (uint32_t i = threadIdx.x; i < have; i += blockDim.x) {
         const unsigned long long at = s_base + i;
-        if (at < f.defer_cap) f.defer[at] = (uint32_t)(o + i);
+        if (at < f.defer_cap) f.defer[(size_t)shard * f.defer_cap + at] = (uint32_t)(o + i);
         else f.fcnt[2] = 1;
     }
 }
@@ -656,7 +782,8 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
     a.probe = 0;
-    const bool probing = ctx->opt.msd_probe != 0;              // every kernel runs its probe variants first (a profiler reads their times)
+    const bool probing = ctx->opt.msd_probe == 1;              // every kernel runs its probe variants first (a profiler reads their times)
+    const bool fprobing = ctx->opt.msd_probe == 2;             // ... the fused pass 3 does (its lists are reset afterwards)
     if (probing)
         for (int v : {1, 16}) {
             a.probe = v;
@@ -704,28 +831,23 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
             hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
             a.probe = 0;
         }
-    // pass 3: workgroups that stay and prefetch (option msd_fuse bit 0), with the scan's classification fused in (bit 1)
-    const int fuse = ctx->opt.msd_fuse < 0 ? 0 : (int)ctx->opt.msd_fuse;
-    const bool persistent = (fuse & 1) && !probing;
-    const bool fused = persistent && (fuse & 2) && want_fused;
+    // pass 3, with the scan's classification fused in (option msd_fuse, default on) when the caller can use it
+    const int fuse = ctx->opt.msd_fuse < 0 ? 1 : (int)ctx->opt.msd_fuse;
+    const bool fused = fuse != 0 && want_fused && !probing;
     FuseArgs fz;
     memset(&fz, 0, sizeof(fz));
-    unsigned fin_blocks = 0;
-    if (persistent) {
-        int dev_cus = 0, per_cu = 0;
-        FBG_HIP_TRY(ctx, hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        if (fused) FBG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msd_finish_p<true>, MSD_FN_THREADS, 0));
-        else FBG_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_msd_finish_p<false>, MSD_FN_THREADS, 0));
-        if (per_cu < 1) per_cu = 1;
-        fin_blocks = (unsigned)std::min<uint64_t>(nsub, (uint64_t)dev_cus * per_cu);
-        fin_blocks &= ~7u;                                      // a multiple of the XCDs: a workgroup's sub-buckets keep their residue
-        if (fin_blocks < 8) fin_blocks = 8;
-    }
     if (fused) {
-        FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, fin_blocks, &fz.ra, &fz.defer, &fz.defer_cap, &fz.fcnt));
-        hipLaunchKernelGGL(k_msd_finish_p<true>, dim3(fin_blocks), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
-    } else if (persistent) {
-        hipLaunchKernelGGL(k_msd_finish_p<false>, dim3(fin_blocks), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
+        FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, &fz.ra, &fz.ties, &fz.tie_cap, &fz.cand, &fz.cand_cap, &fz.defer, &fz.defer_cap, &fz.cur, &fz.fcnt));
+        if (fprobing) {
+            for (int v : {64, 128, 256, 512}) {
+                a.probe = v;
+                hipLaunchKernelGGL(k_msd_finish_fused, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
+                a.probe = 0;
+            }
+            FBG_HIP_TRY(ctx, hipMemsetAsync(fz.cur, 0, (size_t)3 * MSD_SHARDS * 16 * 8, st));
+            FBG_HIP_TRY(ctx, hipMemsetAsync(fz.fcnt, 0, 3 * sizeof(unsigned long long), st));
+        }
+        hipLaunchKernelGGL(k_msd_finish_fused, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
     } else {
         hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
     }
@@ -760,11 +882,9 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipGetLastError());
     *sorted = ctx->keysA.as<uint64_t>();
     *ok = 1;
-    if (fused && hf[2] == 0 && hf[0] <= fz.defer_cap) {
-        // the scan's lists are made (rank_scan.hip takes it from here): the slots left to k_rank_scan_list, the slots that tie
+    if (fused && hf[2] == 0) {
+        // the scan's lists are made (rank_scan.hip takes it from here); hf[1]: the slots that tie on the key
         ctx->fz_valid = true;
-        ctx->fz_blocks = fin_blocks;
-        ctx->fz_defer_n = hf[0];
         ctx->fz_ties = hf[1];
     }
     return FBG_OK;

@@ -254,18 +254,36 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
     if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
 }
 
-// The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_p) could not classify from its sub-bucket alone:
-// rank_scan_slow on the RS_HALO slots either side of each, read from global memory.  Workgroup b appends to region
-// row_base + b of the lists.
-#define RS_LIST_BLOCKS 1024
-__global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32_t *__restrict__ list, uint64_t count, uint32_t row_base)
+// The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_fused) could not classify from its sub-bucket
+// alone: rank_scan_slow on the RS_HALO slots either side of each, read from global memory.  Lists in MSD_SHARDS chunks
+// with a cursor each (cur[(list * MSD_SHARDS + shard) * 16]: 0 ties, 1 candidates, 2 the slots to look at); a workgroup
+// reads a sixteenth of its shard's slots and appends to its shard's chunks, a reservation per wave.
+#define RS_LIST_SPLIT 16
+__device__ __forceinline__ void rs_append_chunk(bool want, unsigned long long *cursor, uint32_t *chunk, uint32_t cap, uint32_t value,
+                                                unsigned long long *over)
 {
-    __shared__ uint32_t s_cand_n, s_tie_n;
-    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
-    __syncthreads();
-    const size_t row = (size_t)(row_base + blockIdx.x) - blockIdx.x;      // rs_append adds blockIdx.x itself
-    uint32_t *cand = a.cand + row * a.region, *ties = a.ties + row * a.tie_region;
-    for (uint64_t e0 = (uint64_t)blockIdx.x * 256; e0 < count; e0 += (uint64_t)gridDim.x * 256) {
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) {
+        const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1));
+        if (at < cap) chunk[at] = value;
+        else *over = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32_t *__restrict__ defer, uint32_t defer_cap,
+                                                        unsigned long long *__restrict__ cur, unsigned long long *__restrict__ over)
+{
+    const uint32_t shard = blockIdx.x & (MSD_SHARDS - 1), part = blockIdx.x / MSD_SHARDS;
+    const uint64_t count = min(cur[((size_t)2 * MSD_SHARDS + shard) * 16], (unsigned long long)defer_cap);
+    const uint32_t *list = defer + (size_t)shard * defer_cap;
+    uint32_t *cand = a.cand + (size_t)shard * a.region, *ties = a.ties + (size_t)shard * a.tie_region;
+    for (uint64_t e0 = (uint64_t)part * 256; e0 < count; e0 += (uint64_t)RS_LIST_SPLIT * 256) {
         const uint64_t e = e0 + threadIdx.x;
         bool want_cand = false, want_tie = false;
         uint64_t k = 0;
@@ -277,22 +295,33 @@ __global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32
             const RsWordView view{a.keys + base, &a, lo_i, hi_i};
             rank_scan_slow(a, view, RS_HALO, lo_i, hi_i, k, want_cand, want_tie);
         }
-        rs_append(want_cand, &s_cand_n, cand, a.region, (uint32_t)k);
-        rs_append(want_tie, &s_tie_n, ties, a.tie_region, (uint32_t)k);
+        rs_append_chunk(want_cand, cur + ((size_t)1 * MSD_SHARDS + shard) * 16, cand, a.region, (uint32_t)k, over);
+        rs_append_chunk(want_tie, cur + ((size_t)0 * MSD_SHARDS + shard) * 16, ties, a.tie_region, (uint32_t)k, over);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { a.blk_count[row_base + blockIdx.x] = s_cand_n; a.tie_count[row_base + blockIdx.x] = s_tie_n; }
+}
+
+// cursors of the chunks -> the per-region counts the kernels below read (a chunk is a region)
+__global__ void k_fuse_counts(const unsigned long long *__restrict__ cur, uint32_t *__restrict__ tie_count, uint32_t *__restrict__ blk_count)
+{
+    const uint32_t s = threadIdx.x;
+    if (s < MSD_SHARDS) {
+        tie_count[s] = (uint32_t)min(cur[((size_t)0 * MSD_SHARDS + s) * 16], 0xffffffffull);
+        blk_count[s] = (uint32_t)min(cur[((size_t)1 * MSD_SHARDS + s) * 16], 0xffffffffull);
+    }
+    if (s == MSD_SHARDS) { tie_count[s] = 0; blk_count[s] = 0; }
 }
 
 // the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
 // shares a column with a neighbour, so each is a run of its own and its extension is 1 + its longest match with
 // any other suffix -- which is another member of the group (they agree on K symbols, nobody else does).
-template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a)
+template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a, uint32_t split)
 {
-    const uint32_t have = a.tie_count[blockIdx.x];
+    // `split` workgroups share a region
+    const uint32_t reg = blockIdx.x / split, part = blockIdx.x % split;
+    const uint32_t have = a.tie_count[reg];
     if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
-    for (uint32_t e = threadIdx.x; e < have; e += blockDim.x) {
-        const uint64_t h = a.ties[(size_t)blockIdx.x * a.tie_region + e];
+    for (uint32_t e = part * blockDim.x + threadIdx.x; e < have; e += split * blockDim.x) {
+        const uint64_t h = a.ties[(size_t)reg * a.tie_region + e];
         // the RS_TG slots from the head on, all loads at once; the group ends where the key changes
         uint64_t key[RS_TG], pos[RS_TG];
         uint32_t best[RS_TG];
@@ -387,10 +416,11 @@ __global__ void k_count_unfilled(const uint32_t *__restrict__ gmax, uint64_t n, 
 
 // candidate regions of the workgroups -> one contiguous list (offsets = exclusive scan of the counts)
 __global__ void k_cand_compact(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ counts,
-                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out)
+                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out, uint32_t split)
 {
-    const uint32_t c = counts[blockIdx.x] < region ? counts[blockIdx.x] : region, o = offsets[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) out[o + i] = regions[(size_t)blockIdx.x * region + i];
+    const uint32_t reg = blockIdx.x / split, part = blockIdx.x % split;          // `split` workgroups share a region
+    const uint32_t c = counts[reg] < region ? counts[reg] : region, o = offsets[reg];
+    for (uint32_t i = part * blockDim.x + threadIdx.x; i < c; i += split * blockDim.x) out[o + i] = regions[(size_t)reg * region + i];
 }
 
 // a slot whose key equals its successor's but not its predecessor's heads a tie group: put the group in text
@@ -664,15 +694,20 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     unsigned rs_blocks = fbg_blocks(own, RS_CHUNK, 256 * 16);
     uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
     uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
+    uint32_t split = 1;
     if (premade) {
-        // the lists were made by pass 3 of the MSD sort (fbg_rank_fuse_prepare set the regions up); what it left over is
-        // classified now, into RS_LIST_BLOCKS more regions
-        rs_blocks = ctx->fz_blocks + RS_LIST_BLOCKS;
+        // the lists were made by pass 3 of the MSD sort, in MSD_SHARDS chunks = regions (fbg_rank_fuse_prepare set a up);
+        // the slots it left over are classified now, into the same chunks
+        rs_blocks = MSD_SHARDS;
         region = a.region; tie_region = a.tie_region;
+        split = 64;
+        unsigned long long *cur = ctx->ps_d.as<unsigned long long>();
         FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)(rs_blocks + 1) * 4));
         FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-        hipLaunchKernelGGL(k_rank_scan_list, dim3(RS_LIST_BLOCKS), dim3(256), 0, st, a, ctx->ps_c.as<uint32_t>(), ctx->fz_defer_n, ctx->fz_blocks);
-        FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
+        hipLaunchKernelGGL(k_rank_scan_list, dim3(MSD_SHARDS * RS_LIST_SPLIT), dim3(256), 0, st, a, ctx->ps_c.as<uint32_t>(), ctx->fz_defer_cap, cur,
+                           a.counters + 1);
+        hipLaunchKernelGGL(k_fuse_counts, dim3(1), dim3(128), 0, st, cur, a.tie_count, a.blk_count);
+        FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 2));
     } else {
     FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rs_blocks * region * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)rs_blocks * tie_region * 4));
@@ -692,10 +727,10 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     }
     if (ctx->opt.no_aux_stream) {
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks * split), dim3(256), st, a, split);
     } else {
         FBG_TRY(rs_fork(ctx));
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks * split), dim3(256), ctx->aux, a, split);
     }
     *launches += 2;
     // from here on k_tie_simple may be running on the aux stream: an error return joins it first, so that no caller
@@ -725,7 +760,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
             uint32_t *sorted = ctx->dp_a.as<uint32_t>();
             FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
             uint32_t *flat = ctx->dp_e.as<uint32_t>();
-            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat);
+            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks * split), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat, split);
             FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
                 return rocprim::radix_sort_keys(tmp, bytes, flat, sorted, (size_t)T, 0u, 32u, st);
             }));
@@ -777,11 +812,12 @@ static int rs_pick_threshold(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, ui
     return FBG_OK;
 }
 
-// Everything k_msd_finish_p<true> (msd_sort.hip) needs to make the lists of the scan while it sorts: the arguments of the
-// scan for the packed slots at `keys` with the threshold above K, column maxima and counters zeroed, list regions for
-// `blocks` workgroups plus those of k_rank_scan_list, and the list of the slots left to that kernel.
-int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, unsigned blocks, RankArgs *out, uint32_t **defer,
-                          uint32_t *defer_cap, unsigned long long **fcnt)
+// Everything k_msd_finish_fused (msd_sort.hip) needs to make the lists of the scan while it sorts: the arguments of the scan
+// for the packed slots at `keys` with the threshold above K, column maxima and counters zeroed, and the lists -- tie heads,
+// candidates, slots left to k_rank_scan_list -- in MSD_SHARDS chunks with their cursors.
+int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, RankArgs *out, uint32_t **ties, uint32_t *tie_cap,
+                          uint32_t **cand, uint32_t *cand_cap, uint32_t **defer, uint32_t *defer_cap, unsigned long long **cur,
+                          unsigned long long **fcnt)
 {
     const uint64_t N = ctx->N, n = ctx->n;
     hipStream_t st = ctx->stream;
@@ -789,29 +825,29 @@ int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, unsign
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
     FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
     RankArgs a;
     rs_args_init(ctx, a, keys, nullptr, N, FBG_SLOTS_PACKED, g.pb, g.b, g.key_bits, g.K);
     a.g_min = (uint32_t)g.K + 1;
-    const unsigned rows = blocks + RS_LIST_BLOCKS;
-    const uint32_t region = (uint32_t)((N / blocks) / 8 + 256), tie_region = (uint32_t)((N / blocks) / 6 + 256);
-    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rows * region * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)rows * tie_region * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
-    a.big = ctx->big_groups.as<uint32_t>();
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)(rows + 1) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (size_t)(rows + 1) * 4));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_a.p, 0, (size_t)(rows + 1) * 4, st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_b.p, 0, (size_t)(rows + 1) * 4, st));
-    a.cand = ctx->list.as<uint32_t>(); a.blk_count = ctx->ps_a.as<uint32_t>(); a.region = region;
-    a.ties = ctx->tie_list.as<uint32_t>(); a.tie_count = ctx->ps_b.as<uint32_t>(); a.tie_region = tie_region;
-    // 2 * RS_HALO slots of every sub-bucket at most, and the sub-buckets that overflowed their stretch in full
-    const uint64_t cap = (uint64_t)2 * RS_HALO * 512 * 512 + (1u << 21);
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, cap * 4));
-    *defer = ctx->ps_c.as<uint32_t>();
-    *defer_cap = (uint32_t)cap;
+    // a sixth / an eighth of the slots, as the regions of k_rank_scan; 2 * RS_HALO slots of every sub-bucket at most, and the
+    // sub-buckets that overflowed their stretch in full
+    const uint32_t tcap = (uint32_t)(N / 6 / MSD_SHARDS + 4096), ccap = (uint32_t)(N / 8 / MSD_SHARDS + 4096);
+    const uint32_t dcap = (uint32_t)(((uint64_t)2 * RS_HALO * 512 * 512 + (1u << 21)) / MSD_SHARDS + 1024);
+    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)MSD_SHARDS * tcap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)MSD_SHARDS * ccap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, (size_t)MSD_SHARDS * dcap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)(MSD_SHARDS + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (size_t)(MSD_SHARDS + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_d, (size_t)3 * MSD_SHARDS * 16 * 8));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_d.p, 0, (size_t)3 * MSD_SHARDS * 16 * 8, st));
+    a.cand = ctx->list.as<uint32_t>(); a.blk_count = ctx->ps_a.as<uint32_t>(); a.region = ccap;
+    a.ties = ctx->tie_list.as<uint32_t>(); a.tie_count = ctx->ps_b.as<uint32_t>(); a.tie_region = tcap;
+    *ties = a.ties; *tie_cap = tcap; *cand = a.cand; *cand_cap = ccap;
+    *defer = ctx->ps_c.as<uint32_t>(); *defer_cap = dcap;
+    *cur = ctx->ps_d.as<unsigned long long>();
     *fcnt = ctx->scalars.as<unsigned long long>() + 116;
     FBG_HIP_TRY(ctx, hipMemsetAsync(*fcnt, 0, 3 * sizeof(unsigned long long), st));
-    ctx->fz_region = region; ctx->fz_tie_region = tie_region;
+    ctx->fz_region = ccap; ctx->fz_tie_region = tcap; ctx->fz_defer_cap = dcap;
     *out = a;
     return FBG_OK;
 }
