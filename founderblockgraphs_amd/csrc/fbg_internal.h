@@ -124,7 +124,8 @@ struct fbg_ctx {
     uint32_t part_gmin = 0;    // largest threshold any partition scanned with (0: none, nothing to verify)
     // pass 3 of the MSD sort made the scan's lists (msd_sort.hip k_msd_finish_p<true>; consumed by fbg_rank_scan_try)
     bool fz_valid = false;
-    uint32_t fz_region = 0, fz_tie_region = 0, fz_defer_cap = 0;   // chunk capacities of the candidate / tie / leftover lists
+    uint32_t fz_nsub = 0, fz_tcap = 0, fz_ccap = 0, fz_dcap = 0;   // its regions: sub-buckets, tie heads / candidates / left-over slots of each
+    uint32_t fz_cap2 = 0;          // chunk capacity of the lists k_rank_scan_list makes of the left-over slots
     uint64_t fz_ties = 0;          // slots that tie on the key (all of them counted)
 
     // scratch
@@ -208,9 +209,10 @@ int fbg_rank_part_rescan(fbg_ctx *ctx);
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
 int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches, bool want_fused);   // msd_sort.hip
 struct RankArgs;
-int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, RankArgs *out, uint32_t **ties, uint32_t *tie_cap,
-                          uint32_t **cand, uint32_t *cand_cap, uint32_t **defer, uint32_t *defer_cap, unsigned long long **cur,
-                          unsigned long long **fcnt);                                                 // rank_scan.hip
+int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, uint32_t nsub, uint32_t tcap, uint32_t ccap, uint32_t dcap,
+                          RankArgs *out, uint32_t **ties, uint32_t **cand, uint32_t **defer, uint32_t **cnt_t, uint32_t **cnt_c,
+                          uint32_t **cnt_d, unsigned long long **fcnt);                               // rank_scan.hip
+#define FBG_FUSE_MAX_RANGES 4096   // sub-buckets too large for the fused pass 3 (their slots are classified from global memory)
 #define MSD_SHARDS 64          // chunks of the lists the fused pass 3 of the MSD sort makes for the scan (one cursor each)
 int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
                       uint64_t *count, int *ok, int *launches);                                       // msd_sort_pairs.hip                        // suffix_sort.hip

@@ -415,28 +415,35 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
 // With the sub-bucket sorted in LDS the workgroup also does what k_rank_scan (rank_scan.hip) does in a pass of its own
 // over the sorted slots when the threshold lies above K (rs_pick_threshold: g_min = K + 1; the caller checks afterwards
 // that this was the regime): only slots that tie on the key, share their column with a neighbour, sit next to a tie
-// group or lie in the 64 columns nearest a row end can matter.  Instructions are what this kernel is short of -- scalar
-// ones more than vector ones (one scalar unit per CU) -- so the pass over all slots does the least it can: a wave looks
-// at 64 consecutive slots, a lane each, the neighbours' key and symbols-left by DPP shifts (lanes 1..62 are settled,
-// consecutive waves overlap by two slots); the first members of tie groups (3 % of the slots) are noted in the wave's own
-// stretch of an LDS list, slots that share a column with a neighbour or lie near a row end (a few in a million) in another.
-// Then the noted group heads are worked on densely, a lane each: a group of two is settled on the spot -- "simple" (k_rank_scan's
-// test: both with K symbols left, four different columns around, no tie group next door) to the tie list, else both to the
-// candidates -- and the outside neighbours that share a column with the far member are queued; longer groups queue all
-// their members and both neighbours.  The queue (duplicates removed by a bitmap) goes through rank_scan_slow, the scan's
-// general code; slots whose neighbourhood lies in another sub-bucket go to a list that k_rank_scan_list works off from
-// global memory.  Lists: MSD_SHARDS chunks each, a workgroup stages its entries in LDS and reserves room in the chunk of
-// its shard once.
+// group or lie in the 64 columns nearest a row end can matter.  What this kernel is short of is neither bandwidth nor
+// instruction slots but time: three workgroups per CU keep the LDS busy, a dependent LDS access takes several hundred
+// cycles, and a workgroup lives as long as its chain of dependent accesses and barriers (a first version that noted
+// group heads in an LDS list and worked them off after a barrier took 7.7 ms against 4.2 + 4.1 for the two kernels it
+// replaces: profiles/r04_fused_probe_v2_order.txt).  So the classification works from registers: a wave looks at 64
+// consecutive slots, a lane each -- all its slots are fetched from LDS at once --, the keys and symbols-left of the two
+// slots before and the three after by DPP shifts (lanes 2..60 are settled, consecutive waves overlap by five slots).  A
+// group of two is settled by its head's lane: "simple" (k_rank_scan's test: both with K symbols left, four different
+// columns around, no tie group next door) goes to the tie list, else both go to the candidates; a lane keeps what it
+// finds in registers and reserves its places once, at the end.  Everything else is rare and takes the general code
+// through a queue in LDS (rank_scan_slow, duplicates removed by a bitmap): outside neighbours that share a column with
+// the far member of a pair, groups of three and more with both neighbours, slots that share a column with a neighbour
+// or lie near a row end.  Slots whose neighbourhood lies in another sub-bucket go to a list that k_rank_scan_list works
+// off from global memory.  Lists: a fixed region per sub-bucket and list, no reservations in global memory.
+#define MSD_TCAP 1024                          // region of a sub-bucket: heads of simple tie groups, ...
+#define MSD_CCAP 512                           // ... candidates, ...
+#define MSD_DCAP 32                            // ... slots left to k_rank_scan_list (2 * RS_HALO at most)
 struct FuseArgs {
     RankArgs ra;                               // geometry, text, column maxima (cand / ties of it unused)
-    uint32_t *ties, *cand, *defer;             // [MSD_SHARDS][*_cap] slots
-    uint32_t tie_cap, cand_cap, defer_cap;
-    unsigned long long *cur;                   // cursors: cur[(list * MSD_SHARDS + shard) * 16], list 0 ties, 1 cand, 2 defer
-    unsigned long long *fcnt;                  // [1] slots that tie on the key, [2] != 0: a list overflowed
+    uint32_t *ties, *cand, *defer;             // [nsub][MSD_TCAP], [nsub][MSD_CCAP], [nsub][MSD_DCAP] slots
+    uint32_t *cnt_t, *cnt_c, *cnt_d;           // [nsub] entries of the regions
+    unsigned long long *fcnt;                  // [1] slots that tie on the key, [2] != 0: a region overflowed
 };
 
-// lane l gets lane l + 1's value (lane 63: 0)
+// lane l gets lane l + 1's / lane l - 1's value (beyond the wave: 0)
 __device__ __forceinline__ uint32_t msd_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t msd_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint64_t msd_from_next(uint64_t v) { return ((uint64_t)msd_from_next((uint32_t)(v >> 32)) << 32) | msd_from_next((uint32_t)v); }
+__device__ __forceinline__ uint64_t msd_from_prev(uint64_t v) { return ((uint64_t)msd_from_prev((uint32_t)(v >> 32)) << 32) | msd_from_prev((uint32_t)v); }
 
 // entries of the lanes in `mask` (wave-uniform) -> a staging list in LDS of capacity cap; *over = 1 when it is full
 __device__ __forceinline__ void msd_stage(unsigned long long mask, uint32_t *counter, uint16_t *list, uint32_t cap, uint32_t value,
@@ -455,34 +462,33 @@ __device__ __forceinline__ void msd_stage(unsigned long long mask, uint32_t *cou
     }
 }
 
-#define MSD_W_HEADS 288                        // noted per wave: first members of tie groups (expected: 15), ...
-#define MSD_W_ODD 32                           // ... slots that share a column with a neighbour / lie near a row end
-#define MSD_ST_T 1280                          // staged per sub-bucket: heads of simple tie groups, ...
-#define MSD_ST_C 1024                          // ... candidates, ...
-#define MSD_ST_Q 1024                          // ... slots for rank_scan_slow, ...
-#define MSD_ST_D 32                            // ... slots left to k_rank_scan_list (2 * RS_HALO at most)
-#define MSD_EV 62                              // lanes 1 .. 62 of a wave are settled by it
+#define MSD_ST_Q 1024                          // queue for rank_scan_slow
+#define MSD_EV_LO 2                            // lanes MSD_EV_LO .. MSD_EV_HI of a wave are settled by it
+#define MSD_EV_HI 60
+#define MSD_EV (MSD_EV_HI - MSD_EV_LO + 1)
+#define MSD_ROUNDS ((MSD_FN_CAP + MSD_EV * (MSD_FN_THREADS / 64) - 1) / (MSD_EV * (MSD_FN_THREADS / 64)))
 
 __global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_msd_finish_fused(MsdArgs a, int fshift, uint32_t fmask, FuseArgs f)
 {
     constexpr int WAVES = MSD_FN_THREADS / 64;
-    constexpr int STAGE16 = WAVES * (MSD_W_HEADS + MSD_W_ODD) + MSD_ST_T + MSD_ST_C + MSD_ST_Q + MSD_ST_D;
     __shared__ uint64_t buf[MSD_FN_CAP];
-    __shared__ uint32_t cls[2 * MSD_FN_BINS + (1 << MSD_LOW_BITS)];   // bin counts | bin offsets | counts of a crowded bin; afterwards the staged lists
-    static_assert(STAGE16 * 2 <= (2 * MSD_FN_BINS + (1 << MSD_LOW_BITS)) * 4, "the staged lists fit the tables of the sort");
+    __shared__ uint32_t cls[2 * MSD_FN_BINS];                   // bin counts | bin offsets; afterwards the queue and the deferred slots
+    __shared__ uint32_t sub[1 << MSD_LOW_BITS];
     __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
     __shared__ uint16_t biglist[MSD_FN_CAP / MSD_BIG_BIN + 1];
     __shared__ uint32_t nbig_lds;
-    __shared__ uint32_t s_n[4], s_base[3], s_ties, s_over;     // staged entries: ties, candidates, defer, queue
-    __shared__ uint32_t s_wh[WAVES + 1], s_wo[WAVES + 1];      // heads / odd slots noted by every wave
+    __shared__ uint32_t s_n[4], s_ties, s_over;                 // entries: ties, candidates, deferred, queue
     __shared__ uint32_t seen[MSD_FN_CAP / 32];                  // slots that have been in the queue
-    uint32_t *cnt = cls, *loff = cls + MSD_FN_BINS, *sub = cls + 2 * MSD_FN_BINS;
-    uint16_t *w_heads = reinterpret_cast<uint16_t *>(cls), *w_odd = w_heads + WAVES * MSD_W_HEADS, *st_t = w_odd + WAVES * MSD_W_ODD,
-             *st_c = st_t + MSD_ST_T, *sq = st_c + MSD_ST_C, *st_d = sq + MSD_ST_Q;
+    uint32_t *cnt = cls, *loff = cls + MSD_FN_BINS;
+    uint16_t *sq = reinterpret_cast<uint16_t *>(cls), *st_d = sq + MSD_ST_Q;
     constexpr int ITEMS = MSD_FN_ITEMS;
-    const uint32_t have = a.count2[blockIdx.x];
-    if (have == 0 || have > MSD_FN_CAP) return;                // the larger ones: k_msd_finish_big, k_msd_defer_big
-    const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
+    const uint32_t sb = blockIdx.x;
+    const uint32_t have = a.count2[sb];
+    if (have == 0 || have > MSD_FN_CAP) {                       // the larger ones: k_msd_finish_big, k_msd_defer_big
+        if (threadIdx.x == 0) { f.cnt_t[sb] = 0; f.cnt_c[sb] = 0; f.cnt_d[sb] = 0; }
+        return;
+    }
+    const uint64_t *in = a.buf2 + (uint64_t)sb * MSD_FN_CAP;
     uint64_t w[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -491,9 +497,9 @@ __global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(
     }
     if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
     if (threadIdx.x == 4) { s_ties = 0; s_over = 0; }
-    if (threadIdx.x < MSD_FN_CAP / 32) seen[threadIdx.x] = 0;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + MSD_FN_CAP / 32) seen[threadIdx.x - 64] = 0;
     msd_finish_sort<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
-    const uint64_t o = a.off[blockIdx.x];
+    const uint64_t o = a.off[sb];
     uint64_t *out = a.out + o;
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -504,141 +510,98 @@ __global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(
     const RankArgs &ra = f.ra;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ihave = (int)have;
+    const uint32_t o32 = (uint32_t)o;
+    uint32_t *ties = f.ties + (size_t)sb * MSD_TCAP, *cand = f.cand + (size_t)sb * MSD_CCAP;
     uint32_t over = 0;
-    // ---- every slot: does it head a tie group, does it share its column with a neighbour, is it near a row end ----
-    {
-        const int rounds = (ihave + MSD_EV * WAVES - 1) / (MSD_EV * WAVES);
-        uint32_t nh = 0, no = 0, nties = 0;                     // (wave-uniform)
-        uint16_t *my_heads = w_heads + wv * MSD_W_HEADS, *my_odd = w_odd + wv * MSD_W_ODD;
-        for (int q = 0; q < rounds; q++) {
-            const int j = (q * WAVES + wv) * MSD_EV - 1 + lane;
-            const bool inr = j >= 0 && j < ihave;
-            const uint64_t x = inr ? buf[j] : 0ull;
-            const uint64_t key = x >> ra.pb;
-            const uint32_t rem = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
-            const uint64_t keyn = ((uint64_t)msd_from_next((uint32_t)(key >> 32)) << 32) | msd_from_next((uint32_t)key);
-            const uint32_t remn = msd_from_next(rem);
-            // bit l of a mask speaks of the slot of lane l (and the one after it)
-            const unsigned long long E = __ballot(key == keyn) & ~(1ull << 63);            // ties with the next slot
-            const unsigned long long R1 = __ballot(rem == remn && rem != 0) & ~(1ull << 63);   // same column as the next slot
-            const unsigned long long NE = __ballot(rem - 1u < 64u);                        // a row pointer in the 64 columns nearest the row end
-            const bool mine = inr && lane >= 1 && lane <= MSD_EV;
-            const unsigned long long D = __ballot(mine && (j < 3 || j + 3 >= ihave));      // a neighbour within 3 lies in another sub-bucket
-            const unsigned long long EV = __ballot(mine) & ~D;
-            const unsigned long long TIE = E | (E << 1);
-            // first member of its group -- or the first one this workgroup may look at (slot 3), when the group begins in the three
-            // slots that are left to k_rank_scan_list
-            const unsigned long long H = EV & ((E & ~(E << 1)) | ((E << 1) & __ballot(j == 3)));
-            const unsigned long long O = EV & ~TIE & (R1 | (R1 << 1) | NE);
-            nties += (uint32_t)__popcll(TIE & EV);
-            if ((H >> lane) & 1ull) {
-                const uint32_t at = nh + (uint32_t)__popcll(H & ((1ull << lane) - 1));
-                if (at < MSD_W_HEADS) my_heads[at] = (uint16_t)j; else over = 1;
-            }
-            nh += (uint32_t)__popcll(H);
-            if (O) {
-                if ((O >> lane) & 1ull) {
-                    const uint32_t at = no + (uint32_t)__popcll(O & ((1ull << lane) - 1));
-                    if (at < MSD_W_ODD) my_odd[at] = (uint16_t)j; else over = 1;
-                }
-                no += (uint32_t)__popcll(O);
-            }
-            msd_stage(D, &s_n[2], st_d, MSD_ST_D, (uint32_t)j, &over);
-        }
-        if (lane == 0) {
-            s_wh[wv] = min(nh, (uint32_t)MSD_W_HEADS); s_wo[wv] = min(no, (uint32_t)MSD_W_ODD);
-            if (nties) atomicAdd(&s_ties, nties);
-        }
-    }
-    __syncthreads();
-    if (a.probe & 128) return;                                  // ... the pass over all slots as well, ...
-    // ---- the noted slots, a lane each: odd slots into the queue, group heads settled or queued ----
     auto enqueue = [&](bool want, uint32_t i) {                // (all lanes of the wave call)
         bool fresh = false;
         if (want) fresh = ((atomicOr(&seen[i >> 5], 1u << (i & 31)) >> (i & 31)) & 1u) == 0;
         msd_stage(__ballot(fresh), &s_n[3], sq, MSD_ST_Q, i, &over);
     };
+    // ---- every slot, from registers ----
     {
-        uint32_t tot_o = 0, tot_h = 0;
+        uint64_t xs[MSD_ROUNDS];
 #pragma unroll
-        for (int q = 0; q < WAVES; q++) { tot_o += s_wo[q]; tot_h += s_wh[q]; }
-        for (uint32_t e0 = 0; e0 < tot_o; e0 += MSD_FN_THREADS) {
-            if (e0 + (threadIdx.x & ~63u) >= tot_o) break;     // wave-uniform
-            uint32_t e = e0 + threadIdx.x, i = 0;
-            const bool on = e < tot_o;
-            if (on) {
-                int q = 0;
-                while (e >= s_wo[q]) { e -= s_wo[q]; q++; }
-                i = w_odd[q * MSD_W_ODD + e];
-            }
-            enqueue(on, i);
+        for (int q = 0; q < MSD_ROUNDS; q++) {
+            const int j = (q * WAVES + wv) * MSD_EV - MSD_EV_LO + lane;
+            xs[q] = (j >= 0 && j < ihave) ? buf[j] : 0ull;
         }
-        for (uint32_t e0 = 0; e0 < tot_h; e0 += MSD_FN_THREADS) {
-            if (e0 + (threadIdx.x & ~63u) >= tot_h) break;     // wave-uniform
-            uint32_t e = e0 + threadIdx.x;
-            const bool on = e < tot_h;
-            int i = 3;
-            if (on) {
-                int q = 0;
-                while (e >= s_wh[q]) { e -= s_wh[q]; q++; }
-                i = w_heads[q * MSD_W_HEADS + e];
-            }
-            // slots i - 2 .. i + 3 (3 <= i, i + 3 < have): keys k[0..5], symbols left r[0..5]; slot i is k[2]
-            uint64_t k[6];
-            uint32_t r[6];
+        uint32_t t_pack = 0, c_pack = 0, nt_l = 0, nc_l = 0;    // what this lane found: slots of simple pairs / of entangled ones, two each at most
+        uint32_t nties = 0;                                     // (wave-uniform)
 #pragma unroll
-            for (int d = 0; d < 6; d++) {
-                const uint64_t x = buf[i - 2 + d];
-                k[d] = x >> ra.pb;
-                r[d] = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
-            }
+        for (int q = 0; q < MSD_ROUNDS; q++) {
+            const int j0 = (q * WAVES + wv) * MSD_EV;           // the first slot this round settles
+            if (j0 >= ihave) break;                             // wave-uniform
+            const int j = j0 - MSD_EV_LO + lane;
+            const bool inr = j >= 0 && j < ihave;
+            const uint64_t key = xs[q] >> ra.pb;
+            const uint32_t rem = rs_rem<FBG_SLOTS_PACKED>(ra, xs[q] & ra.pmask);
+            const uint64_t kp1 = msd_from_next(key), kp2 = msd_from_next(kp1), kp3 = msd_from_next(kp2);
+            const uint64_t km1 = msd_from_prev(key), km2 = msd_from_prev(km1);
+            const uint32_t rp1 = msd_from_next(rem), rp2 = msd_from_next(rp1);
+            const uint32_t rm1 = msd_from_prev(rem);
+            const bool mine = inr && lane >= MSD_EV_LO && lane <= MSD_EV_HI;
+            const bool dflt = mine && (j < 3 || j + 3 >= ihave);           // a neighbour within 3 lies in another sub-bucket
+            const bool ev = mine && !dflt;
+            const bool e0 = key == kp1, em1 = km1 == key;
+            const bool tie = ev && (e0 || em1);
+            nties += (uint32_t)__popcll(__ballot(tie));
+            // first member of its group -- or the first one this workgroup may look at (slot 3), when the group begins in the
+            // three slots that are left to k_rank_scan_list
+            const bool head = ev && ((e0 && !em1) || (em1 && j == 3));
             // a group of two, both members this workgroup's to settle (a group that reaches into the first or last three slots
             // of the sub-bucket is classified slot by slot instead, like those)
-            const bool pair = on && k[1] != k[2] && k[2] == k[3] && k[3] != k[4] && i + 4 < ihave;
-            bool t_simple = false, c_pair = false, q_b = false, q_a = false;
-            if (pair) {
-                t_simple = r[2] >= (uint32_t)ra.K && r[3] >= (uint32_t)ra.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] && r[1] != r[3] &&
-                           k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
-                c_pair = !t_simple;
-                // a slot next to the pair that shares its column with the pair's far member may end up next to it (a run)
-                q_b = k[0] != k[1] && r[1] != 0 && r[1] == r[3] && i - 1 >= 3;
-                q_a = k[4] != k[5] && r[4] != 0 && r[4] == r[2] && i + 2 + 3 < ihave;
-            }
-            msd_stage(__ballot(t_simple), &s_n[0], st_t, MSD_ST_T, (uint32_t)i, &over);
-            {
-                // both members of an entangled pair
-                const unsigned long long m = __ballot(c_pair);
-                if (m) {
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)m) - 1;
-                    if (lane == leader) base = atomicAdd(&s_n[1], 2u * (uint32_t)__popcll(m));
-                    base = __shfl(base, leader, 64);
-                    if (c_pair) {
-                        const uint32_t at = base + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1));
-                        if (at + 1 < MSD_ST_C) { st_c[at] = (uint16_t)i; st_c[at + 1] = (uint16_t)(i + 1); } else over = 1;
+            const bool pair = head && !em1 && kp1 != kp2 && j + 4 < ihave;
+            const bool simple = pair && rem >= (uint32_t)ra.K && rp1 >= (uint32_t)ra.K && rem != rp1 && km2 != km1 && rm1 != rem && rm1 != rp1 &&
+                                kp2 != kp3 && rp2 != rem && rp2 != rp1;
+            const bool cpair = pair && !simple;
+            // a slot next to the pair that shares its column with the pair's far member may end up next to it (a run)
+            const bool q_b = pair && km2 != km1 && rm1 != 0 && rm1 == rp1 && j - 1 >= 3;
+            const bool q_a = pair && kp2 != kp3 && rp2 != 0 && rp2 == rem && j + 2 + 3 < ihave;
+            const bool lng = head && !pair;
+            const bool odd = ev && !e0 && !em1 && ((rem != 0 && (rem == rp1 || rem == rm1)) || rem - 1u < 64u);
+            bool spill_t = false, spill_c = false;
+            if (simple) { if (nt_l < 2) t_pack |= (uint32_t)j << (16 * nt_l); else spill_t = true; nt_l += spill_t ? 0u : 1u; }
+            if (cpair) { if (nc_l < 2) c_pack |= (uint32_t)j << (16 * nc_l); else spill_c = true; nc_l += spill_c ? 0u : 1u; }
+            if (__ballot(q_b || q_a || lng || odd || dflt || spill_t || spill_c)) {     // rare
+                enqueue(q_b, (uint32_t)(j - 1));
+                enqueue(q_a, (uint32_t)(j + 2));
+                enqueue(odd || spill_t || spill_c, (uint32_t)j);
+                enqueue(spill_c, (uint32_t)(j + 1));
+                msd_stage(__ballot(dflt), &s_n[2], st_d, MSD_DCAP, (uint32_t)j, &over);
+                if (__ballot(lng)) {
+                    // a longer group: every member and the slots on either side take the general code
+                    int m = j, end = j;
+                    if (lng) { while (end + 1 < ihave && (buf[end + 1] >> ra.pb) == key) end++; }
+                    enqueue(lng && !em1 && km2 != km1 && j - 1 >= 3, (uint32_t)(j - 1));
+                    enqueue(lng && end + 1 + 3 < ihave && (buf[end + 2] >> ra.pb) != (buf[end + 1] >> ra.pb), (uint32_t)(end + 1));
+                    for (;;) {
+                        const bool more = lng && m <= end && m + 3 < ihave;   // (the last three slots of the sub-bucket are deferred already)
+                        if (!__ballot(more)) break;
+                        enqueue(more, (uint32_t)m);
+                        m++;
                     }
                 }
             }
-            enqueue(q_b, (uint32_t)(i - 1));
-            enqueue(q_a, (uint32_t)(i + 2));
-            // a longer group: every member and the slots on either side take the general code
-            const unsigned long long lng = __ballot(on && !pair);
-            if (lng) {
-                const bool mine = on && !pair;
-                int m = i, end = i;
-                if (mine) { while (end + 1 < ihave && (buf[end + 1] >> ra.pb) == k[2]) end++; }
-                enqueue(mine && k[1] != k[2] && k[0] != k[1] && i - 1 >= 3, (uint32_t)(i - 1));
-                enqueue(mine && end + 1 + 3 < ihave && (end + 2 >= ihave || (buf[end + 2] >> ra.pb) != (buf[end + 1] >> ra.pb)), (uint32_t)(end + 1));
-                for (;;) {
-                    const bool more = mine && m <= end && m + 3 < ihave;    // (the last three slots of the sub-bucket are deferred already)
-                    if (!__ballot(more)) break;
-                    enqueue(more, (uint32_t)m);
-                    m++;
-                }
-            }
+        }
+        if (lane == 0 && nties) atomicAdd(&s_ties, nties);
+        // the lane's finds: one reservation per list
+        uint32_t bt = 0, bc = 0;
+        if (nt_l) bt = atomicAdd(&s_n[0], nt_l);
+        if (nc_l) bc = atomicAdd(&s_n[1], 2 * nc_l);
+        if (nt_l) {
+            if (bt + nt_l <= MSD_TCAP) { ties[bt] = o32 + (t_pack & 0xffffu); if (nt_l > 1) ties[bt + 1] = o32 + (t_pack >> 16); }
+            else over = 1;
+        }
+        if (nc_l) {
+            if (bc + 2 * nc_l <= MSD_CCAP) {
+                cand[bc] = o32 + (c_pack & 0xffffu); cand[bc + 1] = o32 + (c_pack & 0xffffu) + 1;
+                if (nc_l > 1) { cand[bc + 2] = o32 + (c_pack >> 16); cand[bc + 3] = o32 + (c_pack >> 16) + 1; }
+            } else over = 1;
         }
     }
     __syncthreads();
+    if (a.probe & 128) return;                                  // ... the pass over all slots as well
     // ---- the queue: rank_scan_slow on the sorted sub-bucket; slots within RS_HALO of its ends are left to k_rank_scan_list ----
     {
         const uint32_t qn = min(s_n[3], (uint32_t)MSD_ST_Q);
@@ -653,42 +616,22 @@ __global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(
                 far = (int)i < RS_HALO || (int)i + RS_HALO >= ihave;
                 if (!far) rank_scan_slow(ra, view, (int)i, 0, ihave, o + i, want_cand, want_tie);
             }
-            msd_stage(__ballot(want_tie), &s_n[0], st_t, MSD_ST_T, i, &over);
-            msd_stage(__ballot(want_cand), &s_n[1], st_c, MSD_ST_C, i, &over);
-            msd_stage(__ballot(far), &s_n[2], st_d, MSD_ST_D, i, &over);
+            if (want_tie) { const uint32_t at = atomicAdd(&s_n[0], 1u); if (at < MSD_TCAP) ties[at] = o32 + i; else over = 1; }
+            if (want_cand) { const uint32_t at = atomicAdd(&s_n[1], 1u); if (at < MSD_CCAP) cand[at] = o32 + i; else over = 1; }
+            msd_stage(__ballot(far), &s_n[2], st_d, MSD_DCAP, i, &over);
         }
+        if (qn) __syncthreads();                                // (uniform)
     }
     if (over) s_over = 1;
-    __syncthreads();
-    if (a.probe & 256) return;                                  // ... everything but the hand-over to the lists in global memory
-    const uint32_t shard = blockIdx.x & (MSD_SHARDS - 1);
-    if (threadIdx.x < 3) {
-        const uint32_t caps[3] = {MSD_ST_T, MSD_ST_C, MSD_ST_D};
-        const uint32_t n = min(s_n[threadIdx.x], caps[threadIdx.x]);
-        s_base[threadIdx.x] = n ? (uint32_t)atomicAdd(f.cur + ((size_t)threadIdx.x * MSD_SHARDS + shard) * 16, (unsigned long long)n) : 0u;
-    }
-    if (threadIdx.x == 3) {
-        if (s_ties) atomicAdd(f.fcnt + 1, (unsigned long long)s_ties);
-        if (s_over || s_n[0] > MSD_ST_T || s_n[1] > MSD_ST_C || s_n[2] > MSD_ST_D || s_n[3] > MSD_ST_Q) f.fcnt[2] = 1;
-    }
-    __syncthreads();
     {
-        const uint32_t nt = min(s_n[0], (uint32_t)MSD_ST_T), nc = min(s_n[1], (uint32_t)MSD_ST_C), nd = min(s_n[2], (uint32_t)MSD_ST_D);
-        const uint32_t o32 = (uint32_t)o;
-        bool full = false;
-        for (uint32_t e = threadIdx.x; e < nt; e += MSD_FN_THREADS) {
-            const uint32_t at = s_base[0] + e;
-            if (at < f.tie_cap) f.ties[(size_t)shard * f.tie_cap + at] = o32 + st_t[e]; else full = true;
-        }
-        for (uint32_t e = threadIdx.x; e < nc; e += MSD_FN_THREADS) {
-            const uint32_t at = s_base[1] + e;
-            if (at < f.cand_cap) f.cand[(size_t)shard * f.cand_cap + at] = o32 + st_c[e]; else full = true;
-        }
-        if (threadIdx.x < nd) {
-            const uint32_t at = s_base[2] + threadIdx.x;
-            if (at < f.defer_cap) f.defer[(size_t)shard * f.defer_cap + at] = o32 + st_d[threadIdx.x]; else full = true;
-        }
-        if (full) f.fcnt[2] = 1;
+        const uint32_t nd = min(s_n[2], (uint32_t)MSD_DCAP);
+        if (threadIdx.x < nd) f.defer[(size_t)sb * MSD_DCAP + threadIdx.x] = o32 + st_d[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        f.cnt_t[sb] = min(s_n[0], (uint32_t)MSD_TCAP); f.cnt_c[sb] = min(s_n[1], (uint32_t)MSD_CCAP); f.cnt_d[sb] = min(s_n[2], (uint32_t)MSD_DCAP);
+        if (s_ties) atomicAdd(f.fcnt + 1, (unsigned long long)s_ties);
+        if (s_over || s_n[0] > MSD_TCAP || s_n[1] > MSD_CCAP || s_n[2] > MSD_DCAP || s_n[3] > MSD_ST_Q) f.fcnt[2] = 1;
     }
 }
 
@@ -714,24 +657,18 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
                                                   a.out + a.off[sb], fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
 }
 
-// FUSED: the slots of the sub-buckets k_msd_finish_big sorted go to k_rank_scan_list, all of them (same grid)
-__global__ __launch_bounds__(256) void k_msd_defer_big(MsdArgs a, const uint32_t *__restrict__ sb_sorted, uint32_t entries, FuseArgs f)
+// FUSED: the slots of the sub-buckets k_msd_finish_big sorted go to k_rank_scan_list, all of them: as (first slot, count) ranges
+// (same grid; ranges[0] counts them, ranges[2 + 2 e], ranges[3 + 2 e] = range e)
+__global__ void k_msd_defer_big(MsdArgs a, const uint32_t *__restrict__ sb_sorted, uint32_t entries, unsigned long long *__restrict__ ranges,
+                                uint32_t max_ranges, unsigned long long *__restrict__ fcnt)
 {
-    __shared__ unsigned long long s_base;
-    const uint32_t e = blockIdx.x;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= entries) return;
     const uint32_t sb = sb_sorted[e];
     if (e > 0 && sb_sorted[e - 1] == sb) return;
-    const uint32_t have = a.count2[sb];
-    const uint32_t shard = sb & (MSD_SHARDS - 1);
-    if (threadIdx.x == 0) s_base = atomicAdd(f.cur + ((size_t)2 * MSD_SHARDS + shard) * 16, (unsigned long long)have);
-    __syncthreads();
-    const uint64_t o = a.off[sb];
-    for (uint32_t i = threadIdx.x; i < have; i += blockDim.x) {
-        const unsigned long long at = s_base + i;
-        if (at < f.defer_cap) f.defer[(size_t)shard * f.defer_cap + at] = (uint32_t)(o + i);
-        else f.fcnt[2] = 1;
-    }
+    const unsigned long long at = atomicAdd(ranges, 1ull);
+    if (at < max_ranges) { ranges[2 + 2 * at] = a.off[sb]; ranges[3 + 2 * at] = a.count2[sb]; }
+    else fcnt[2] = 1;
 }
 
 // Sorts the packed slots of the current text by their key bits.  *ok = 0: a capacity was exceeded (keys spread
@@ -837,14 +774,14 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FuseArgs fz;
     memset(&fz, 0, sizeof(fz));
     if (fused) {
-        FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, &fz.ra, &fz.ties, &fz.tie_cap, &fz.cand, &fz.cand_cap, &fz.defer, &fz.defer_cap, &fz.cur, &fz.fcnt));
+        FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, (uint32_t)nsub, MSD_TCAP, MSD_CCAP, MSD_DCAP, &fz.ra, &fz.ties, &fz.cand, &fz.defer, &fz.cnt_t,
+                                      &fz.cnt_c, &fz.cnt_d, &fz.fcnt));
         if (fprobing) {
-            for (int v : {64, 128, 256, 512}) {
+            for (int v : {64, 128}) {
                 a.probe = v;
                 hipLaunchKernelGGL(k_msd_finish_fused, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
                 a.probe = 0;
             }
-            FBG_HIP_TRY(ctx, hipMemsetAsync(fz.cur, 0, (size_t)3 * MSD_SHARDS * 16 * 8, st));
             FBG_HIP_TRY(ctx, hipMemsetAsync(fz.fcnt, 0, 3 * sizeof(unsigned long long), st));
         }
         hipLaunchKernelGGL(k_msd_finish_fused, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
@@ -872,7 +809,8 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
         e = rocprim::radix_sort_pairs(ctx->tmp.p, have, a.arena_sb, sb_sorted, a.arena_w, w_sorted, (size_t)entries, 0u, 32u, st);
         if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_msd_finish_big, dim3(entries), dim3(MSD_BIG_THREADS), 0, st, a, sb_sorted, w_sorted, entries, fshift, fmask);
-        if (fused) hipLaunchKernelGGL(k_msd_defer_big, dim3(entries), dim3(256), 0, st, a, sb_sorted, entries, fz);
+        if (fused) hipLaunchKernelGGL(k_msd_defer_big, dim3(fbg_blocks(entries, 256)), dim3(256), 0, st, a, sb_sorted, entries, ctx->ps_d.as<unsigned long long>(),
+                                      (uint32_t)FBG_FUSE_MAX_RANGES, fz.fcnt);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
         if (fused) FBG_HIP_TRY(ctx, hipMemcpyAsync(hf, fz.fcnt, 24, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));

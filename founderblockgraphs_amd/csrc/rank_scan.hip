@@ -255,10 +255,11 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
 }
 
 // The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_fused) could not classify from its sub-bucket
-// alone: rank_scan_slow on the RS_HALO slots either side of each, read from global memory.  Lists in MSD_SHARDS chunks
-// with a cursor each (cur[(list * MSD_SHARDS + shard) * 16]: 0 ties, 1 candidates, 2 the slots to look at); a workgroup
-// reads a sixteenth of its shard's slots and appends to its shard's chunks, a reservation per wave.
-#define RS_LIST_SPLIT 16
+// alone -- up to dcap of every sub-bucket (regions of `defer`, counts in cnt_d), and the sub-buckets too large for that
+// kernel in full (ranges[0] ranges: first slot ranges[2 + 2 e], slots ranges[3 + 2 e]) --: rank_scan_slow on the RS_HALO
+// slots either side of each, read from global memory.  What it finds goes to lists of MSD_SHARDS chunks with a cursor
+// each (cur[(list * MSD_SHARDS + shard) * 16]: 0 ties, 1 candidates), a reservation per wave.
+#define RS_LIST_BLOCKS 2048
 __device__ __forceinline__ void rs_append_chunk(bool want, unsigned long long *cursor, uint32_t *chunk, uint32_t cap, uint32_t value,
                                                 unsigned long long *over)
 {
@@ -276,27 +277,39 @@ __device__ __forceinline__ void rs_append_chunk(bool want, unsigned long long *c
     }
 }
 
-__global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32_t *__restrict__ defer, uint32_t defer_cap,
-                                                        unsigned long long *__restrict__ cur, unsigned long long *__restrict__ over)
+__global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32_t *__restrict__ defer, const uint32_t *__restrict__ cnt_d,
+                                                        uint32_t nsub, uint32_t dcap, const unsigned long long *__restrict__ ranges,
+                                                        uint32_t max_ranges, unsigned long long *__restrict__ cur,
+                                                        unsigned long long *__restrict__ over)
 {
-    const uint32_t shard = blockIdx.x & (MSD_SHARDS - 1), part = blockIdx.x / MSD_SHARDS;
-    const uint64_t count = min(cur[((size_t)2 * MSD_SHARDS + shard) * 16], (unsigned long long)defer_cap);
-    const uint32_t *list = defer + (size_t)shard * defer_cap;
+    const uint32_t shard = blockIdx.x & (MSD_SHARDS - 1);
     uint32_t *cand = a.cand + (size_t)shard * a.region, *ties = a.ties + (size_t)shard * a.tie_region;
-    for (uint64_t e0 = (uint64_t)part * 256; e0 < count; e0 += (uint64_t)RS_LIST_SPLIT * 256) {
-        const uint64_t e = e0 + threadIdx.x;
+    unsigned long long *cur_t = cur + ((size_t)0 * MSD_SHARDS + shard) * 16, *cur_c = cur + ((size_t)1 * MSD_SHARDS + shard) * 16;
+    auto look = [&](bool on, uint64_t k) {                     // (all lanes of the wave call)
         bool want_cand = false, want_tie = false;
-        uint64_t k = 0;
-        if (e < count) {
-            k = list[e];
+        if (on) {
             const int64_t base = (int64_t)k - RS_HALO;                     // slot of window index 0
             const int lo_i = (int)max((int64_t)0, (int64_t)a.own_lo - base);
             const int hi_i = (int)min((int64_t)(2 * RS_HALO + 1), (int64_t)a.own_hi - base);
             const RsWordView view{a.keys + base, &a, lo_i, hi_i};
             rank_scan_slow(a, view, RS_HALO, lo_i, hi_i, k, want_cand, want_tie);
         }
-        rs_append_chunk(want_cand, cur + ((size_t)1 * MSD_SHARDS + shard) * 16, cand, a.region, (uint32_t)k, over);
-        rs_append_chunk(want_tie, cur + ((size_t)0 * MSD_SHARDS + shard) * 16, ties, a.tie_region, (uint32_t)k, over);
+        rs_append_chunk(want_cand, cur_c, cand, a.region, (uint32_t)k, over);
+        rs_append_chunk(want_tie, cur_t, ties, a.tie_region, (uint32_t)k, over);
+    };
+    const uint64_t virt = (uint64_t)nsub * dcap;               // entry e of sub-bucket sb: sb * dcap + e
+    for (uint64_t v0 = (uint64_t)blockIdx.x * 256; v0 < virt; v0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t v = v0 + threadIdx.x;
+        const bool on = v < virt && (uint32_t)(v % dcap) < cnt_d[v / dcap];
+        look(on, on ? defer[v] : 0u);
+    }
+    const uint32_t nr = (uint32_t)min(ranges[0], (unsigned long long)max_ranges);
+    for (uint32_t r = 0; r < nr; r++) {
+        const uint64_t first = ranges[2 + 2 * r], n = ranges[3 + 2 * r];
+        for (uint64_t e0 = (uint64_t)blockIdx.x * 256; e0 < n; e0 += (uint64_t)gridDim.x * 256) {
+            const uint64_t e = e0 + threadIdx.x;
+            look(e < n, first + e);
+        }
     }
 }
 
@@ -314,13 +327,15 @@ __global__ void k_fuse_counts(const unsigned long long *__restrict__ cur, uint32
 // the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
 // shares a column with a neighbour, so each is a run of its own and its extension is 1 + its longest match with
 // any other suffix -- which is another member of the group (they agree on K symbols, nobody else does).
-template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a, uint32_t split)
+template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a, uint32_t split, uint32_t regions)
 {
-    // `split` workgroups share a region
-    const uint32_t reg = blockIdx.x / split, part = blockIdx.x % split;
+    // `split` workgroups share a region; split = 0: small regions (those of the fused pass 3 of the MSD sort), a wave each
+    const uint32_t reg = split ? blockIdx.x / split : blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (reg >= regions) return;
     const uint32_t have = a.tie_count[reg];
-    if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
-    for (uint32_t e = part * blockDim.x + threadIdx.x; e < have; e += split * blockDim.x) {
+    if (have > a.tie_region) { if ((threadIdx.x & 63) == 0) a.counters[1] = 1; return; }
+    const uint32_t first = split ? (blockIdx.x % split) * blockDim.x + threadIdx.x : (threadIdx.x & 63), step = split ? split * blockDim.x : 64u;
+    for (uint32_t e = first; e < have; e += step) {
         const uint64_t h = a.ties[(size_t)reg * a.tie_region + e];
         // the RS_TG slots from the head on, all loads at once; the group ends where the key changes
         uint64_t key[RS_TG], pos[RS_TG];
@@ -416,11 +431,14 @@ __global__ void k_count_unfilled(const uint32_t *__restrict__ gmax, uint64_t n, 
 
 // candidate regions of the workgroups -> one contiguous list (offsets = exclusive scan of the counts)
 __global__ void k_cand_compact(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ counts,
-                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out, uint32_t split)
+                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out, uint32_t split, uint32_t nreg)
 {
-    const uint32_t reg = blockIdx.x / split, part = blockIdx.x % split;          // `split` workgroups share a region
+    // `split` workgroups share a region; split = 0: small regions, a wave each
+    const uint32_t reg = split ? blockIdx.x / split : blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (reg >= nreg) return;
     const uint32_t c = counts[reg] < region ? counts[reg] : region, o = offsets[reg];
-    for (uint32_t i = part * blockDim.x + threadIdx.x; i < c; i += split * blockDim.x) out[o + i] = regions[(size_t)reg * region + i];
+    const uint32_t first = split ? (blockIdx.x % split) * blockDim.x + threadIdx.x : (threadIdx.x & 63), step = split ? split * blockDim.x : 64u;
+    for (uint32_t i = first; i < c; i += step) out[o + i] = regions[(size_t)reg * region + i];
 }
 
 // a slot whose key equals its successor's but not its predecessor's heads a tie group: put the group in text
@@ -684,31 +702,36 @@ static int rs_join(fbg_ctx *ctx)
     return FBG_OK;
 }
 
+// The candidates, flat and unsorted in dp_e: sorted (SA order), tie groups put in final order.  On return a.cand / a.pm name
+// the sorted list and its scratch.
+static int rs_order_candidates(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t T, int *launches)
+{
+    hipStream_t st = ctx->stream;
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_a, T * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_b, T * 4));
+    uint32_t *sorted = ctx->dp_a.as<uint32_t>();
+    uint32_t *flat = ctx->dp_e.as<uint32_t>();
+    FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+        return rocprim::radix_sort_keys(tmp, bytes, flat, sorted, (size_t)T, 0u, 32u, st);
+    }));
+    a.cand = sorted;
+    a.pm = ctx->dp_b.as<uint32_t>();
+    RS_LAUNCH(k_tie_groups, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
+    RS_LAUNCH(k_tie_big, layout, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
+    *launches += 3;
+    return FBG_OK;
+}
+
 // k_rank_scan over the owned slots, the small tie groups, then the candidates: compacted, sorted, tie groups put
 // in final order.  On return a.cand / a.pm name the sorted list and its scratch; *T = ~0 when a workgroup's
 // candidate region overflowed (similar rows: the caller takes another path).
-static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches, bool premade = false)
+static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches)
 {
     hipStream_t st = ctx->stream;
     const uint64_t own = a.own_hi - a.own_lo;
-    unsigned rs_blocks = fbg_blocks(own, RS_CHUNK, 256 * 16);
-    uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
-    uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
-    uint32_t split = 1;
-    if (premade) {
-        // the lists were made by pass 3 of the MSD sort, in MSD_SHARDS chunks = regions (fbg_rank_fuse_prepare set a up);
-        // the slots it left over are classified now, into the same chunks
-        rs_blocks = MSD_SHARDS;
-        region = a.region; tie_region = a.tie_region;
-        split = 64;
-        unsigned long long *cur = ctx->ps_d.as<unsigned long long>();
-        FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)(rs_blocks + 1) * 4));
-        FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-        hipLaunchKernelGGL(k_rank_scan_list, dim3(MSD_SHARDS * RS_LIST_SPLIT), dim3(256), 0, st, a, ctx->ps_c.as<uint32_t>(), ctx->fz_defer_cap, cur,
-                           a.counters + 1);
-        hipLaunchKernelGGL(k_fuse_counts, dim3(1), dim3(128), 0, st, cur, a.tie_count, a.blk_count);
-        FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 2));
-    } else {
+    const unsigned rs_blocks = fbg_blocks(own, RS_CHUNK, 256 * 16);
+    const uint32_t region = (uint32_t)((own / rs_blocks) / 8 + 256);    // a workgroup may find 1/8 of its slots + slack
+    const uint32_t tie_region = (uint32_t)((own / rs_blocks) / 6 + 256);
     FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)rs_blocks * region * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)rs_blocks * tie_region * 4));
     FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
@@ -725,12 +748,11 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
-    }
     if (ctx->opt.no_aux_stream) {
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks * split), dim3(256), st, a, split);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a, 1u, rs_blocks);
     } else {
         FBG_TRY(rs_fork(ctx));
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks * split), dim3(256), ctx->aux, a, split);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a, 1u, rs_blocks);
     }
     *launches += 2;
     // from here on k_tie_simple may be running on the aux stream: an error return joins it first, so that no caller
@@ -753,22 +775,73 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
         *T_out = T;
         if (mx > region) { *T_out = ~0ull; return rs_join(ctx); }
         if (T > 0) {
-            // candidates in SA order; tie groups first (final order), then the runs
-            FBG_TRY(fbg_reserve(ctx, ctx->dp_a, T * 4));
-            FBG_TRY(fbg_reserve(ctx, ctx->dp_b, T * 4));
             // regions are in SA order already (workgroup b owns chunks b, b+G, ...: not contiguous) -> compact, then sort
-            uint32_t *sorted = ctx->dp_a.as<uint32_t>();
             FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
             uint32_t *flat = ctx->dp_e.as<uint32_t>();
-            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks * split), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat, split);
-            FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-                return rocprim::radix_sort_keys(tmp, bytes, flat, sorted, (size_t)T, 0u, 32u, st);
-            }));
-            a.cand = sorted;
-            a.pm = ctx->dp_b.as<uint32_t>();
-            RS_LAUNCH(k_tie_groups, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T, 1);
-            RS_LAUNCH(k_tie_big, layout, dim3(RS_BIG_GROUPS), dim3(256), st, a, 0);
-            *launches += 3;
+            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat, 1u, rs_blocks);
+            FBG_TRY(rs_order_candidates(ctx, a, layout, T, launches));
+        }
+        return FBG_OK;
+    }();
+    if (rc_rest != FBG_OK) { (void)rs_join(ctx); return rc_rest; }
+    return FBG_OK;
+}
+
+// The same when pass 3 of the MSD sort has made the lists (msd_sort.hip, k_msd_finish_fused; fbg_rank_fuse_prepare set the
+// buffers up): a region of tie heads and one of candidates per sub-bucket.  The slots that kernel left over are classified now,
+// into lists of MSD_SHARDS chunks; then both pairs of lists are worked off as above.
+static int rs_classify_premade(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t nsub = ctx->fz_nsub;
+    RankArgs a1 = a, a2 = a;                                    // the lists of pass 3 / of k_rank_scan_list
+    a1.cand = ctx->list.as<uint32_t>(); a1.blk_count = ctx->ps_b.as<uint32_t>(); a1.region = ctx->fz_ccap;
+    a1.ties = ctx->tie_list.as<uint32_t>(); a1.tie_count = ctx->ps_a.as<uint32_t>(); a1.tie_region = ctx->fz_tcap;
+    const uint32_t cap2 = ctx->fz_cap2;
+    a2.cand = ctx->ps_h.as<uint32_t>(); a2.region = cap2;
+    a2.ties = ctx->ps_g.as<uint32_t>(); a2.tie_region = cap2;
+    uint32_t *counts2 = ctx->dp_c.as<uint32_t>();              // [0, 65) candidates, [80, 145) ties of the chunks
+    a2.blk_count = counts2; a2.tie_count = counts2 + 80;
+    unsigned long long *cur = ctx->ps_f.as<unsigned long long>();
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
+    hipLaunchKernelGGL(k_rank_scan_list, dim3(RS_LIST_BLOCKS), dim3(256), 0, st, a2, ctx->ps_c.as<uint32_t>(), ctx->ps_e.as<uint32_t>(), nsub, ctx->fz_dcap,
+                       ctx->ps_d.as<unsigned long long>(), (uint32_t)FBG_FUSE_MAX_RANGES, cur, a.counters + 1);
+    hipLaunchKernelGGL(k_fuse_counts, dim3(1), dim3(128), 0, st, cur, a2.tie_count, a2.blk_count);
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 2));
+    {
+        hipStream_t ts = st;
+        if (!ctx->opt.no_aux_stream) { FBG_TRY(rs_fork(ctx)); ts = ctx->aux; }
+        RS_LAUNCH(k_tie_simple, layout, dim3(fbg_blocks(nsub, 4)), dim3(256), ts, a1, 0u, nsub);
+        RS_LAUNCH(k_tie_simple, layout, dim3(MSD_SHARDS * 4), dim3(256), ts, a2, 4u, (uint32_t)MSD_SHARDS);
+    }
+    *launches += 2;
+    const int rc_rest = [&]() -> int {
+        uint32_t *offs1 = ctx->dp_d.as<uint32_t>(), *offs2 = counts2 + 160;
+        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::exclusive_scan(tmp, bytes, a1.blk_count, offs1, 0u, (size_t)(nsub + 1), rocprim::plus<uint32_t>(), st);
+        }));
+        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::exclusive_scan(tmp, bytes, a2.blk_count, offs2, 0u, (size_t)(MSD_SHARDS + 1), rocprim::plus<uint32_t>(), st);
+        }));
+        uint32_t *d_max = reinterpret_cast<uint32_t *>(a.counters + 6);
+        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
+            return rocprim::reduce(tmp, bytes, a2.blk_count, d_max, 0u, (size_t)MSD_SHARDS, rocprim::maximum<uint32_t>(), st);
+        }));
+        uint32_t tot1 = 0, tot2 = 0, mx = 0;
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot1, offs1 + nsub, 4, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot2, offs2 + MSD_SHARDS, 4, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint64_t T = (uint64_t)tot1 + tot2;
+        *T_out = T;
+        if (mx > cap2 || T >= (1ull << 32)) { *T_out = ~0ull; return rs_join(ctx); }
+        if (T > 0) {
+            FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
+            uint32_t *flat = ctx->dp_e.as<uint32_t>();
+            hipLaunchKernelGGL(k_cand_compact, dim3(fbg_blocks(nsub, 4)), dim3(256), 0, st, a1.cand, a1.blk_count, offs1, a1.region, flat, 0u, nsub);
+            hipLaunchKernelGGL(k_cand_compact, dim3(MSD_SHARDS * 4), dim3(256), 0, st, a2.cand, a2.blk_count, offs2, a2.region, flat + tot1, 4u,
+                               (uint32_t)MSD_SHARDS);
+            FBG_TRY(rs_order_candidates(ctx, a, layout, T, launches));
         }
         return FBG_OK;
     }();
@@ -813,11 +886,12 @@ static int rs_pick_threshold(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, ui
 }
 
 // Everything k_msd_finish_fused (msd_sort.hip) needs to make the lists of the scan while it sorts: the arguments of the scan
-// for the packed slots at `keys` with the threshold above K, column maxima and counters zeroed, and the lists -- tie heads,
-// candidates, slots left to k_rank_scan_list -- in MSD_SHARDS chunks with their cursors.
-int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, RankArgs *out, uint32_t **ties, uint32_t *tie_cap,
-                          uint32_t **cand, uint32_t *cand_cap, uint32_t **defer, uint32_t *defer_cap, unsigned long long **cur,
-                          unsigned long long **fcnt)
+// for the packed slots at `keys` with the threshold above K, column maxima and counters zeroed, a region of tcap tie heads,
+// ccap candidates and dcap left-over slots for each of the nsub sub-buckets with their counts, and what k_rank_scan_list
+// needs afterwards (cursors and chunks of its own lists, the ranges of the oversized sub-buckets).
+int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, uint32_t nsub, uint32_t tcap, uint32_t ccap, uint32_t dcap,
+                          RankArgs *out, uint32_t **ties, uint32_t **cand, uint32_t **defer, uint32_t **cnt_t, uint32_t **cnt_c,
+                          uint32_t **cnt_d, unsigned long long **fcnt)
 {
     const uint64_t N = ctx->N, n = ctx->n;
     hipStream_t st = ctx->stream;
@@ -829,25 +903,28 @@ int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, RankAr
     RankArgs a;
     rs_args_init(ctx, a, keys, nullptr, N, FBG_SLOTS_PACKED, g.pb, g.b, g.key_bits, g.K);
     a.g_min = (uint32_t)g.K + 1;
-    // a sixth / an eighth of the slots, as the regions of k_rank_scan; 2 * RS_HALO slots of every sub-bucket at most, and the
-    // sub-buckets that overflowed their stretch in full
-    const uint32_t tcap = (uint32_t)(N / 6 / MSD_SHARDS + 4096), ccap = (uint32_t)(N / 8 / MSD_SHARDS + 4096);
-    const uint32_t dcap = (uint32_t)(((uint64_t)2 * RS_HALO * 512 * 512 + (1u << 21)) / MSD_SHARDS + 1024);
-    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)MSD_SHARDS * tcap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)MSD_SHARDS * ccap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, (size_t)MSD_SHARDS * dcap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)(MSD_SHARDS + 1) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (size_t)(MSD_SHARDS + 1) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_d, (size_t)3 * MSD_SHARDS * 16 * 8));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_d.p, 0, (size_t)3 * MSD_SHARDS * 16 * 8, st));
-    a.cand = ctx->list.as<uint32_t>(); a.blk_count = ctx->ps_a.as<uint32_t>(); a.region = ccap;
-    a.ties = ctx->tie_list.as<uint32_t>(); a.tie_count = ctx->ps_b.as<uint32_t>(); a.tie_region = tcap;
-    *ties = a.ties; *tie_cap = tcap; *cand = a.cand; *cand_cap = ccap;
-    *defer = ctx->ps_c.as<uint32_t>(); *defer_cap = dcap;
-    *cur = ctx->ps_d.as<unsigned long long>();
+    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)nsub * tcap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)nsub * ccap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, (size_t)nsub * dcap * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)(nsub + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (size_t)(nsub + 1) * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_e, (size_t)(nsub + 1) * 4));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_b.as<uint32_t>() + nsub, 0, 4, st));           // (the scan of the counts reads nsub + 1 of them)
+    // k_rank_scan_list: the left-over slots (2 * RS_HALO of every sub-bucket at most, the oversized sub-buckets in full) may all
+    // turn out candidates
+    const uint32_t cap2 = (uint32_t)(((uint64_t)nsub * dcap + (1u << 21)) / MSD_SHARDS + 1024);
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_g, (size_t)MSD_SHARDS * cap2 * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)MSD_SHARDS * cap2 * 4));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_f, (size_t)2 * MSD_SHARDS * 16 * 8));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_f.p, 0, (size_t)2 * MSD_SHARDS * 16 * 8, st));
+    FBG_TRY(fbg_reserve(ctx, ctx->ps_d, (size_t)(2 + 2 * FBG_FUSE_MAX_RANGES) * 8));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_d.p, 0, 16, st));
+    FBG_TRY(fbg_reserve(ctx, ctx->dp_c, 256 * 4));
+    *ties = ctx->tie_list.as<uint32_t>(); *cand = ctx->list.as<uint32_t>(); *defer = ctx->ps_c.as<uint32_t>();
+    *cnt_t = ctx->ps_a.as<uint32_t>(); *cnt_c = ctx->ps_b.as<uint32_t>(); *cnt_d = ctx->ps_e.as<uint32_t>();
     *fcnt = ctx->scalars.as<unsigned long long>() + 116;
     FBG_HIP_TRY(ctx, hipMemsetAsync(*fcnt, 0, 3 * sizeof(unsigned long long), st));
-    ctx->fz_region = ccap; ctx->fz_tie_region = tcap; ctx->fz_defer_cap = dcap;
+    ctx->fz_nsub = nsub; ctx->fz_tcap = tcap; ctx->fz_ccap = ccap; ctx->fz_dcap = dcap; ctx->fz_cap2 = cap2;
     *out = a;
     return FBG_OK;
 }
@@ -881,8 +958,6 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     uint64_t T = 0;
     if (premade) {
         a.g_min = (uint32_t)geom.K + 1;
-        a.cand = ctx->list.as<uint32_t>(); a.blk_count = ctx->ps_a.as<uint32_t>(); a.region = ctx->fz_region;
-        a.ties = ctx->tie_list.as<uint32_t>(); a.tie_count = ctx->ps_b.as<uint32_t>(); a.tie_region = ctx->fz_tie_region;
     } else {
         FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
         FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
@@ -890,7 +965,8 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
         FBG_TRY(rs_pick_threshold(ctx, a, keys, N, geom, &reject, &launches));
         if (reject) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
     }
-    FBG_TRY(rs_classify(ctx, a, layout, &T, &launches, premade));
+    if (premade) FBG_TRY(rs_classify_premade(ctx, a, layout, &T, &launches));
+    else FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
     if (T == ~0ull) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
     if (T > 0) {
         RS_LAUNCH(k_runs, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);
