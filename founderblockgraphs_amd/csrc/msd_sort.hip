@@ -24,6 +24,7 @@
 #include "rank_common.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <cmath>
 
 #define MSD_DIG 9
 #define MSD_NB (1 << MSD_DIG)
@@ -437,6 +438,9 @@ struct FuseArgs {
     uint32_t *ties, *cand, *defer;             // [nsub][MSD_TCAP], [nsub][MSD_CCAP], [nsub][MSD_DCAP] slots
     uint32_t *cnt_t, *cnt_c, *cnt_d;           // [nsub] entries of the regions
     unsigned long long *fcnt;                  // [1] slots that tie on the key, [2] != 0: a region overflowed
+    // x = fract(position / row length) in single precision is off by less than eps / 2, whatever the position: two slots of one
+    // column differ by less than eps (or by more than 1 - eps), a slot in the 64 columns nearest its row's end has x >= near_end
+    float inv_row_len, eps, near_end;
 };
 
 // lane l gets lane l + 1's / lane l - 1's value (beyond the wave: 0)
@@ -462,25 +466,25 @@ __device__ __forceinline__ void msd_stage(unsigned long long mask, uint32_t *cou
     }
 }
 
-#define MSD_ST_Q 1024                          // queue for rank_scan_slow
-#define MSD_EV_LO 2                            // lanes MSD_EV_LO .. MSD_EV_HI of a wave are settled by it
-#define MSD_EV_HI 60
-#define MSD_EV (MSD_EV_HI - MSD_EV_LO + 1)
-#define MSD_ROUNDS ((MSD_FN_CAP + MSD_EV * (MSD_FN_THREADS / 64) - 1) / (MSD_EV * (MSD_FN_THREADS / 64)))
+#define MSD_ST_Q 4064                          // queue for rank_scan_slow: room for every slot of a sub-bucket
+#define MSD_W_LIST 256                         // noted per wave: first members of tie groups (expected: 15), slots that may share a column with a neighbour
+#define MSD_EV 62                              // lanes 1 .. 62 of a wave are settled by it
 
 __global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_msd_finish_fused(MsdArgs a, int fshift, uint32_t fmask, FuseArgs f)
 {
     constexpr int WAVES = MSD_FN_THREADS / 64;
     __shared__ uint64_t buf[MSD_FN_CAP];
     __shared__ uint32_t cls[2 * MSD_FN_BINS];                   // bin counts | bin offsets; afterwards the queue and the deferred slots
-    __shared__ uint32_t sub[1 << MSD_LOW_BITS];
+    __shared__ uint32_t sub[1 << MSD_LOW_BITS];                 // counts of a crowded bin; afterwards what the waves noted
+    static_assert(WAVES * MSD_W_LIST * 2 <= (1 << MSD_LOW_BITS) * 4 && (MSD_ST_Q + MSD_DCAP) * 2 <= 2 * MSD_FN_BINS * 4, "the lists fit the tables of the sort");
     __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
     __shared__ uint16_t biglist[MSD_FN_CAP / MSD_BIG_BIN + 1];
     __shared__ uint32_t nbig_lds;
     __shared__ uint32_t s_n[4], s_ties, s_over;                 // entries: ties, candidates, deferred, queue
+    __shared__ uint32_t s_wl[WAVES];                            // entries noted by every wave
     __shared__ uint32_t seen[MSD_FN_CAP / 32];                  // slots that have been in the queue
     uint32_t *cnt = cls, *loff = cls + MSD_FN_BINS;
-    uint16_t *sq = reinterpret_cast<uint16_t *>(cls), *st_d = sq + MSD_ST_Q;
+    uint16_t *sq = reinterpret_cast<uint16_t *>(cls), *st_d = sq + MSD_ST_Q, *w_list = reinterpret_cast<uint16_t *>(sub);
     constexpr int ITEMS = MSD_FN_ITEMS;
     const uint32_t sb = blockIdx.x;
     const uint32_t have = a.count2[sb];
@@ -518,90 +522,111 @@ __global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(
         if (want) fresh = ((atomicOr(&seen[i >> 5], 1u << (i & 31)) >> (i & 31)) & 1u) == 0;
         msd_stage(__ballot(fresh), &s_n[3], sq, MSD_ST_Q, i, &over);
     };
-    // ---- every slot, from registers ----
+    // ---- every slot: a dozen instructions.  Does it tie with the next one; may it share its column with it, or lie near a row end:
+    //      (position / row length) in single precision says no for all but a few in a thousand, never wrongly (f.eps) ----
     {
-        uint64_t xs[MSD_ROUNDS];
-#pragma unroll
-        for (int q = 0; q < MSD_ROUNDS; q++) {
-            const int j = (q * WAVES + wv) * MSD_EV - MSD_EV_LO + lane;
-            xs[q] = (j >= 0 && j < ihave) ? buf[j] : 0ull;
-        }
-        uint32_t t_pack = 0, c_pack = 0, nt_l = 0, nc_l = 0;    // what this lane found: slots of simple pairs / of entangled ones, two each at most
-        uint32_t nties = 0;                                     // (wave-uniform)
-#pragma unroll
-        for (int q = 0; q < MSD_ROUNDS; q++) {
-            const int j0 = (q * WAVES + wv) * MSD_EV;           // the first slot this round settles
-            if (j0 >= ihave) break;                             // wave-uniform
-            const int j = j0 - MSD_EV_LO + lane;
+        uint16_t *my_list = w_list + wv * MSD_W_LIST;
+        const int rounds = (ihave + MSD_EV * WAVES - 1) / (MSD_EV * WAVES);
+        uint32_t nl = 0, nties = 0;                             // (wave-uniform)
+        for (int q = 0; q < rounds; q++) {
+            const int j = (q * WAVES + wv) * MSD_EV - 1 + lane;
             const bool inr = j >= 0 && j < ihave;
-            const uint64_t key = xs[q] >> ra.pb;
-            const uint32_t rem = rs_rem<FBG_SLOTS_PACKED>(ra, xs[q] & ra.pmask);
-            const uint64_t kp1 = msd_from_next(key), kp2 = msd_from_next(kp1), kp3 = msd_from_next(kp2);
-            const uint64_t km1 = msd_from_prev(key), km2 = msd_from_prev(km1);
-            const uint32_t rp1 = msd_from_next(rem), rp2 = msd_from_next(rp1);
-            const uint32_t rm1 = msd_from_prev(rem);
-            const bool mine = inr && lane >= MSD_EV_LO && lane <= MSD_EV_HI;
-            const bool dflt = mine && (j < 3 || j + 3 >= ihave);           // a neighbour within 3 lies in another sub-bucket
-            const bool ev = mine && !dflt;
-            const bool e0 = key == kp1, em1 = km1 == key;
-            const bool tie = ev && (e0 || em1);
-            nties += (uint32_t)__popcll(__ballot(tie));
-            // first member of its group -- or the first one this workgroup may look at (slot 3), when the group begins in the
-            // three slots that are left to k_rank_scan_list
-            const bool head = ev && ((e0 && !em1) || (em1 && j == 3));
-            // a group of two, both members this workgroup's to settle (a group that reaches into the first or last three slots
-            // of the sub-bucket is classified slot by slot instead, like those)
-            const bool pair = head && !em1 && kp1 != kp2 && j + 4 < ihave;
-            const bool simple = pair && rem >= (uint32_t)ra.K && rp1 >= (uint32_t)ra.K && rem != rp1 && km2 != km1 && rm1 != rem && rm1 != rp1 &&
-                                kp2 != kp3 && rp2 != rem && rp2 != rp1;
-            const bool cpair = pair && !simple;
-            // a slot next to the pair that shares its column with the pair's far member may end up next to it (a run)
-            const bool q_b = pair && km2 != km1 && rm1 != 0 && rm1 == rp1 && j - 1 >= 3;
-            const bool q_a = pair && kp2 != kp3 && rp2 != 0 && rp2 == rem && j + 2 + 3 < ihave;
-            const bool lng = head && !pair;
-            const bool odd = ev && !e0 && !em1 && ((rem != 0 && (rem == rp1 || rem == rm1)) || rem - 1u < 64u);
-            bool spill_t = false, spill_c = false;
-            if (simple) { if (nt_l < 2) t_pack |= (uint32_t)j << (16 * nt_l); else spill_t = true; nt_l += spill_t ? 0u : 1u; }
-            if (cpair) { if (nc_l < 2) c_pack |= (uint32_t)j << (16 * nc_l); else spill_c = true; nc_l += spill_c ? 0u : 1u; }
-            if (__ballot(q_b || q_a || lng || odd || dflt || spill_t || spill_c)) {     // rare
-                enqueue(q_b, (uint32_t)(j - 1));
-                enqueue(q_a, (uint32_t)(j + 2));
-                enqueue(odd || spill_t || spill_c, (uint32_t)j);
-                enqueue(spill_c, (uint32_t)(j + 1));
-                msd_stage(__ballot(dflt), &s_n[2], st_d, MSD_DCAP, (uint32_t)j, &over);
-                if (__ballot(lng)) {
-                    // a longer group: every member and the slots on either side take the general code
-                    int m = j, end = j;
-                    if (lng) { while (end + 1 < ihave && (buf[end + 1] >> ra.pb) == key) end++; }
-                    enqueue(lng && !em1 && km2 != km1 && j - 1 >= 3, (uint32_t)(j - 1));
-                    enqueue(lng && end + 1 + 3 < ihave && (buf[end + 2] >> ra.pb) != (buf[end + 1] >> ra.pb), (uint32_t)(end + 1));
-                    for (;;) {
-                        const bool more = lng && m <= end && m + 3 < ihave;   // (the last three slots of the sub-bucket are deferred already)
-                        if (!__ballot(more)) break;
-                        enqueue(more, (uint32_t)m);
-                        m++;
-                    }
-                }
+            const uint64_t x = inr ? buf[j] : 0ull;
+            const uint64_t xn = (j + 1 >= 0 && j + 1 < ihave) ? buf[j + 1] : ~0ull;
+            const float fr = __builtin_amdgcn_fractf((float)((uint32_t)x & (uint32_t)ra.pmask) * f.inv_row_len);
+            const float d = fr - __uint_as_float(msd_from_next(__float_as_uint(fr)));
+            // bit l of a mask speaks of the slot of lane l (and the one after it)
+            const unsigned long long E = __ballot(((x ^ xn) >> ra.pb) == 0);               // ties with the next slot
+            const unsigned long long R1 = __ballot(fabsf(d) < f.eps || fabsf(d) > 1.0f - f.eps) & ~(1ull << 63);   // may share the next slot's column
+            // may lie in the 64 columns nearest the row end, or be a '#' (a fraction just below 1 may have been rounded up to 0)
+            const unsigned long long NE = __ballot(fr >= f.near_end || fr < f.eps);
+            const bool mine = inr && lane >= 1 && lane <= MSD_EV;
+            const unsigned long long D = __ballot(mine && (j < 3 || j + 3 >= ihave));      // a neighbour within 3 lies in another sub-bucket
+            const unsigned long long EV = __ballot(mine) & ~D;
+            const unsigned long long TIE = E | (E << 1);
+            // first member of its group -- or the first one this workgroup may look at (slot 3), when the group begins in the three
+            // slots that are left to k_rank_scan_list
+            const unsigned long long H = EV & ((E & ~(E << 1)) | ((E << 1) & __ballot(j == 3)));
+            const unsigned long long O = EV & ~TIE & (R1 | (R1 << 1) | NE);
+            const unsigned long long L = H | O;
+            nties += (uint32_t)__popcll(TIE & EV);
+            if ((L >> lane) & 1ull) {
+                const uint32_t at = nl + (uint32_t)__popcll(L & ((1ull << lane) - 1));
+                if (at < MSD_W_LIST) my_list[at] = (uint16_t)((uint32_t)j | (((O >> lane) & 1ull) ? 0x8000u : 0u)); else over = 1;
             }
+            nl += (uint32_t)__popcll(L);
+            msd_stage(D, &s_n[2], st_d, MSD_DCAP, (uint32_t)j, &over);
         }
-        if (lane == 0 && nties) atomicAdd(&s_ties, nties);
-        // the lane's finds: one reservation per list
-        uint32_t bt = 0, bc = 0;
-        if (nt_l) bt = atomicAdd(&s_n[0], nt_l);
-        if (nc_l) bc = atomicAdd(&s_n[1], 2 * nc_l);
-        if (nt_l) {
-            if (bt + nt_l <= MSD_TCAP) { ties[bt] = o32 + (t_pack & 0xffffu); if (nt_l > 1) ties[bt + 1] = o32 + (t_pack >> 16); }
-            else over = 1;
-        }
-        if (nc_l) {
-            if (bc + 2 * nc_l <= MSD_CCAP) {
-                cand[bc] = o32 + (c_pack & 0xffffu); cand[bc + 1] = o32 + (c_pack & 0xffffu) + 1;
-                if (nc_l > 1) { cand[bc + 2] = o32 + (c_pack >> 16); cand[bc + 3] = o32 + (c_pack >> 16) + 1; }
-            } else over = 1;
+        if (lane == 0) {
+            s_wl[wv] = min(nl, (uint32_t)MSD_W_LIST);
+            if (nties) atomicAdd(&s_ties, nties);
         }
     }
     __syncthreads();
     if (a.probe & 128) return;                                  // ... the pass over all slots as well
+    // ---- the noted slots, a lane each ----
+    {
+        uint32_t wl[WAVES], tot = 0;
+#pragma unroll
+        for (int q = 0; q < WAVES; q++) { wl[q] = s_wl[q]; tot += wl[q]; }
+        for (uint32_t e0 = 0; e0 < tot; e0 += MSD_FN_THREADS) {
+            if (e0 + (threadIdx.x & ~63u) >= tot) break;       // wave-uniform
+            uint32_t e = e0 + threadIdx.x;
+            const bool on = e < tot;
+            uint32_t src = 0;
+#pragma unroll
+            for (int q = 0; q < WAVES; q++) { if (on && e >= wl[q] && src == (uint32_t)q) { e -= wl[q]; src = q + 1; } }
+            const uint32_t v = on ? w_list[src * MSD_W_LIST + e] : 3u;
+            const int i = (int)(v & 0xfffu);
+            const bool is_odd = on && (v & 0x8000u);
+            // slots i - 2 .. i + 3 (3 <= i, i + 3 < have): keys k[0..5], symbols left r[0..5]; slot i is k[2]
+            uint64_t k[6];
+            uint32_t r[6];
+#pragma unroll
+            for (int dd = 0; dd < 6; dd++) {
+                const uint64_t x = buf[i - 2 + dd];
+                k[dd] = x >> ra.pb;
+                r[dd] = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
+            }
+            // a slot that does not tie: the general code if it does share its column with a neighbour or lies near a row end
+            enqueue(is_odd && r[2] != 0 && (r[2] == r[1] || r[2] == r[3] || r[2] <= 64), (uint32_t)i);
+            const bool head = on && !is_odd;
+            // a group of two, both members this workgroup's to settle (a group that reaches into the first or last three slots
+            // of the sub-bucket is classified slot by slot instead, like those)
+            const bool pair = head && k[1] != k[2] && k[2] == k[3] && k[3] != k[4] && i + 4 < ihave;
+            bool t_simple = false, c_pair = false, q_b = false, q_a = false;
+            if (pair) {
+                t_simple = r[2] >= (uint32_t)ra.K && r[3] >= (uint32_t)ra.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] && r[1] != r[3] &&
+                           k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
+                c_pair = !t_simple;
+                // a slot next to the pair that shares its column with the pair's far member may end up next to it (a run); with the
+                // near member: the pass over all slots has noted it
+                q_b = k[0] != k[1] && r[1] != 0 && r[1] == r[3] && i - 1 >= 3;
+                q_a = k[4] != k[5] && r[4] != 0 && r[4] == r[2] && i + 2 + 3 < ihave;
+            }
+            if (t_simple) { const uint32_t at = atomicAdd(&s_n[0], 1u); if (at < MSD_TCAP) ties[at] = o32 + (uint32_t)i; else over = 1; }
+            if (c_pair) {
+                const uint32_t at = atomicAdd(&s_n[1], 2u);
+                if (at + 1 < MSD_CCAP) { cand[at] = o32 + (uint32_t)i; cand[at + 1] = o32 + (uint32_t)i + 1; } else over = 1;
+            }
+            if (__ballot(q_b || q_a)) { enqueue(q_b, (uint32_t)(i - 1)); enqueue(q_a, (uint32_t)(i + 2)); }
+            const bool lng = head && !pair;
+            if (__ballot(lng)) {
+                // a longer group: every member and the slots on either side take the general code
+                int m = i, end = i;
+                if (lng) { while (end + 1 < ihave && (buf[end + 1] >> ra.pb) == k[2]) end++; }
+                enqueue(lng && k[1] != k[2] && k[0] != k[1] && i - 1 >= 3, (uint32_t)(i - 1));
+                enqueue(lng && end + 1 + 3 < ihave && (buf[end + 2] >> ra.pb) != (buf[end + 1] >> ra.pb), (uint32_t)(end + 1));
+                for (;;) {
+                    const bool more = lng && m <= end && m + 3 < ihave;   // (the last three slots of the sub-bucket are deferred already)
+                    if (!__ballot(more)) break;
+                    enqueue(more, (uint32_t)m);
+                    m++;
+                }
+            }
+        }
+    }
+    __syncthreads();
     // ---- the queue: rank_scan_slow on the sorted sub-bucket; slots within RS_HALO of its ends are left to k_rank_scan_list ----
     {
         const uint32_t qn = min(s_n[3], (uint32_t)MSD_ST_Q);
@@ -770,12 +795,18 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
         }
     // pass 3, with the scan's classification fused in (option msd_fuse, default on) when the caller can use it
     const int fuse = ctx->opt.msd_fuse < 0 ? 1 : (int)ctx->opt.msd_fuse;
-    const bool fused = fuse != 0 && want_fused && !probing;
+    // (fractions of the row length in single precision must tell columns apart: rows of a thousand columns and more)
+    const double row_len = (double)(ctx->n + 1);
+    const double fz_delta = (ldexp(1.0, g.pb - 24) + 2.0) / row_len + ldexp(1.0, g.pb - 21) / row_len + 1e-6;
+    const bool fused = fuse != 0 && want_fused && !probing && 2.0 * fz_delta < 0.01 && g.pb <= 32;
     FuseArgs fz;
     memset(&fz, 0, sizeof(fz));
     if (fused) {
         FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, (uint32_t)nsub, MSD_TCAP, MSD_CCAP, MSD_DCAP, &fz.ra, &fz.ties, &fz.cand, &fz.defer, &fz.cnt_t,
                                       &fz.cnt_c, &fz.cnt_d, &fz.fcnt));
+        fz.inv_row_len = (float)(1.0 / row_len);
+        fz.eps = (float)(2.0 * fz_delta);
+        fz.near_end = (float)(1.0 - 65.0 / row_len - fz_delta);
         if (fprobing) {
             for (int v : {64, 128}) {
                 a.probe = v;
