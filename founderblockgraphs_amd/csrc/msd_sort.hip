@@ -794,7 +794,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
             a.probe = 0;
         }
     // pass 3, with the scan's classification fused in (option msd_fuse, default on) when the caller can use it
-    const int fuse = ctx->opt.msd_fuse < 0 ? 1 : (int)ctx->opt.msd_fuse;
+    const int fuse = ctx->opt.msd_fuse < 0 ? 0 : (int)ctx->opt.msd_fuse;
     // (fractions of the row length in single precision must tell columns apart: rows of a thousand columns and more)
     const double row_len = (double)(ctx->n + 1);
     const double fz_delta = (ldexp(1.0, g.pb - 24) + 2.0) / row_len + ldexp(1.0, g.pb - 21) / row_len + 1e-6;

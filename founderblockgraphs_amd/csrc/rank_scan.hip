@@ -254,6 +254,217 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
     if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
 }
 
+// ---- the same scan with a tenth of the instructions per slot (packed slots, threshold above K, no partitions) ----------
+// k_rank_scan spends 160 vector instructions per 64 slots and is bound by that, not by the 8 bytes per slot it reads
+// (4.05 ms for 10^9 slots; 1.3 ms at the rate memory delivers).  With the threshold above K a slot can only matter if it
+// ties on the key, shares its column with a neighbour, sits next to a tie group or lies in the 64 columns nearest a row
+// end -- one slot in fifteen -- and the others should cost next to nothing:
+//   * a chunk of RL_CHUNK slots (+ RS_HALO either side) is staged in LDS as it comes, together with x = fract(position /
+//     row length) in single precision per slot: four instructions instead of the thirteen of the exact remainder, off by
+//     less than eps / 2 (fbg_lean_setup), so that |x - x'| < eps or > 1 - eps whenever two slots share a column, and
+//     x >= near_end or x < eps for a slot near a row end: filters that never say no wrongly;
+//   * a wave looks at 64 consecutive slots, a lane each: "ties with the next slot", "may share the column of the next /
+//     the one after" are wave-wide masks (one compare and ballot each), the cases of k_rank_scan's fast path are scalar
+//     logic on shifted copies of them.  Lanes 3 .. 61 are settled, consecutive rows overlap by five slots;
+//   * heads of groups of two and slots the filters let through (4 % of the slots) are noted in the wave's own stretch of
+//     an LDS list and worked on afterwards, a lane each, with exact arithmetic: a pair is "simple" (k_rank_scan's test)
+//     and goes to the tie list, or both members go to the candidates; a slot that shares its column with a neighbour
+//     (with either member of a pair next to it) becomes a candidate;
+//   * the rest -- members of groups of three and more, their neighbours, slots near a row end or near the ends of the
+//     array: a few in a thousand -- queue up for rank_scan_slow, the general code.
+// Every slot is settled by the workgroup that owns it (a pair by the owner of its head): same lists, same entries as
+// k_rank_scan's, in another order.
+#define RL_ROWS 8
+#define RL_EV_LO 3
+#define RL_EV_HI 61
+#define RL_EV (RL_EV_HI - RL_EV_LO + 1)
+#define RL_THREADS 256
+#define RL_WAVES (RL_THREADS / 64)
+#define RL_CHUNK (RL_WAVES * RL_ROWS * RL_EV)
+#define RL_STAGED (RL_CHUNK + 2 * RS_HALO)
+#define RL_ITEMS ((RL_STAGED + RL_THREADS - 1) / RL_THREADS)
+#define RL_WLIST (RL_ROWS * RL_EV)             // what a wave can note / queue in a chunk
+
+struct LeanArgs { float inv_row_len, eps, near_end; };
+
+__global__ __launch_bounds__(RL_THREADS) void k_rank_scan_lean(RankArgs a, LeanArgs f)
+{
+    __shared__ uint64_t sw[RL_STAGED + 8];                      // slot base - RS_HALO + i at index i (rows read up to two beyond)
+    __shared__ float sf[RL_STAGED + 8];
+    __shared__ uint16_t s_note[RL_WAVES * RL_WLIST], s_queue[RL_WAVES * RL_WLIST + RL_CHUNK];   // per wave; the queue also takes what the noted slots add
+    __shared__ uint32_t s_nn[RL_WAVES], s_nq[RL_WAVES], s_qx, s_cand_n, s_tie_n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t nchunks = (a.own_hi - a.own_lo + RL_CHUNK - 1) / RL_CHUNK;
+    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
+    for (int i = threadIdx.x; i < 8; i += RL_THREADS) { sw[RL_STAGED + i] = 0; sf[RL_STAGED + i] = 0.5f; }
+    uint64_t w[RL_ITEMS];
+    auto fetch = [&](uint64_t c) {
+        const uint64_t base = a.own_lo + c * RL_CHUNK;
+        const int lo_i = c == 0 ? RS_HALO : 0;
+        const int hi_i = (int)min((uint64_t)RL_STAGED, a.own_hi - base + RS_HALO);
+#pragma unroll
+        for (int r = 0; r < RL_ITEMS; r++) {
+            const int i = (int)threadIdx.x + r * RL_THREADS;
+            w[r] = (i >= lo_i && i < hi_i) ? a.keys[base + (uint64_t)i - RS_HALO] : 0ull;
+        }
+    };
+    if (blockIdx.x < nchunks) fetch(blockIdx.x);
+    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint64_t base = a.own_lo + c * RL_CHUNK;                 // slot of index RS_HALO
+        const int lo_i = c == 0 ? RS_HALO : 0;                         // index of the first / one past the last slot there is
+        const int hi_i = (int)min((uint64_t)RL_STAGED, a.own_hi - base + RS_HALO);
+        const bool last = base + RL_CHUNK >= a.own_hi;
+#pragma unroll
+        for (int r = 0; r < RL_ITEMS; r++) {
+            const int i = (int)threadIdx.x + r * RL_THREADS;
+            if (i < RL_STAGED) {
+                sw[i] = w[r];
+                sf[i] = __builtin_amdgcn_fractf((float)((uint32_t)w[r] & (uint32_t)a.pmask) * f.inv_row_len);
+            }
+        }
+        if (threadIdx.x == 0) s_qx = 0;
+        __syncthreads();
+        if (c + gridDim.x < nchunks) fetch(c + gridDim.x);             // in flight during this chunk's work
+        // ---- every slot ----
+        {
+            uint16_t *my_note = s_note + wv * RL_WLIST, *my_queue = s_queue + wv * RL_WLIST;
+            uint32_t nn = 0, nq = 0;                                    // (wave-uniform)
+            for (int r = 0; r < RL_ROWS; r++) {
+                const int i0 = RS_HALO + (wv * RL_ROWS + r) * RL_EV;   // the first slot this row settles
+                if (i0 >= hi_i) break;                                  // wave-uniform
+                const int i = i0 - RL_EV_LO + lane;
+                const uint64_t x = sw[i], xn = sw[i + 1];
+                const float fr = sf[i], d1 = fr - sf[i + 1], d2 = fr - sf[i + 2];
+                const bool v0 = i >= lo_i && i < hi_i, v1 = i + 1 >= lo_i && i + 1 < hi_i, v2 = i + 2 >= lo_i && i + 2 < hi_i;
+                // bit l of a mask speaks of the slot of lane l (and those after it)
+                const unsigned long long E = __ballot(v0 && v1 && ((x ^ xn) >> a.pb) == 0);                          // ties with the next slot
+                const unsigned long long R1 = __ballot(v0 && v1 && (fabsf(d1) < f.eps || fabsf(d1) > 1.0f - f.eps));   // may share the next slot's column
+                const unsigned long long R2 = __ballot(v0 && v2 && (fabsf(d2) < f.eps || fabsf(d2) > 1.0f - f.eps));   // ... that of the slot after the next
+                const unsigned long long NE = __ballot(fr >= f.near_end || fr < f.eps);    // may lie near its row's end, or be a '#'
+                const bool mine = v0 && lane >= RL_EV_LO && lane <= RL_EV_HI && i < RS_HALO + RL_CHUNK;
+                // the ends of the array: the general code knows what a missing neighbour means
+                const unsigned long long XQ = __ballot(mine && ((c == 0 && i < 2 * RS_HALO) || (last && i + RS_HALO >= hi_i)));
+                const unsigned long long OWN = __ballot(mine) & ~XQ;
+                const unsigned long long TIE = E | (E << 1);
+                const unsigned long long PH = E & ~(E << 1) & ~(E >> 1);                    // head of a group of exactly two
+                const unsigned long long PT = PH << 1;
+                const unsigned long long LONG = TIE & ~(PH | PT);                           // member of a group of three and more
+                const unsigned long long ADJL = ((LONG >> 1) | (LONG << 1)) & ~TIE;         // next to one: any member may end up next to it
+                const unsigned long long RUN = R1 | (R1 << 1) | ((PT << 1) & (R2 << 2)) | ((PH >> 1) & R2);
+                const unsigned long long Q = XQ | (OWN & (LONG | ADJL));
+                const unsigned long long NH = OWN & PH, NO = OWN & ~TIE & ~ADJL & (RUN | NE);
+                const unsigned long long NT = NH | NO;
+                if ((NT >> lane) & 1ull)
+                    my_note[nn + (uint32_t)__popcll(NT & ((1ull << lane) - 1))] = (uint16_t)((uint32_t)i | (((NO >> lane) & 1ull) ? 0x8000u : 0u));
+                nn += (uint32_t)__popcll(NT);
+                if (Q) {
+                    if ((Q >> lane) & 1ull) my_queue[nq + (uint32_t)__popcll(Q & ((1ull << lane) - 1))] = (uint16_t)i;
+                    nq += (uint32_t)__popcll(Q);
+                }
+            }
+            if (lane == 0) { s_nn[wv] = nn; s_nq[wv] = nq; }
+        }
+        __syncthreads();
+        // ---- the noted slots, a lane each, exactly ----
+        {
+            uint32_t wl[RL_WAVES], tot = 0;
+#pragma unroll
+            for (int q = 0; q < RL_WAVES; q++) { wl[q] = s_nn[q]; tot += wl[q]; }
+            uint16_t *xq = s_queue + RL_WAVES * RL_WLIST;               // what this phase adds to the queue
+            for (uint32_t e0 = 0; e0 < tot; e0 += RL_THREADS) {
+                if (e0 + (threadIdx.x & ~63u) >= tot) break;           // wave-uniform
+                uint32_t e = e0 + threadIdx.x;
+                const bool on = e < tot;
+                uint32_t src = 0;
+#pragma unroll
+                for (int q = 0; q < RL_WAVES; q++) { if (on && e >= wl[q] && src == (uint32_t)q) { e -= wl[q]; src = q + 1; } }
+                const uint32_t v = on ? s_note[src * RL_WLIST + e] : (uint32_t)RS_HALO;
+                const int i = (int)(v & 0x7fffu);
+                const bool is_odd = on && (v & 0x8000u), is_head = on && !(v & 0x8000u);
+                // slots i - 2 .. i + 3 (all there: the ends of the array took the other way): keys k[0..5], symbols left r[0..5]; slot i is k[2]
+                uint64_t k[6];
+                uint32_t r[6];
+#pragma unroll
+                for (int dd = 0; dd < 6; dd++) {
+                    const uint64_t x = sw[i - 2 + dd];
+                    k[dd] = x >> a.pb;
+                    r[dd] = rs_rem<FBG_SLOTS_PACKED>(a, x & a.pmask);
+                }
+                const uint32_t slot = (uint32_t)(base + (uint64_t)(i - RS_HALO));
+                // a group of two: simple = both with K real symbols, their two columns and those of the slots before and after
+                // all different, no tie group right next to it (k_rank_scan)
+                const bool simple = is_head && r[2] >= (uint32_t)a.K && r[3] >= (uint32_t)a.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] &&
+                                    r[1] != r[3] && k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
+                const bool cpair = is_head && !simple;
+                // a slot that does not tie (nor sits next to a longer group): a run with a neighbour -- either half of a tied pair
+                // may end up next to it --, or near its row's end (the general code computes its extension)
+                bool run = false, near = false;
+                if (is_odd && r[2] != 0) {
+                    run = r[1] == r[2] || r[3] == r[2] || (k[0] == k[1] && r[0] == r[2]) || (k[3] == k[4] && r[4] == r[2]);
+                    near = !run && r[2] <= 64;
+                }
+                if (!a.values_only) {
+                    rs_append(simple, &s_tie_n, a.ties, a.tie_region, slot);
+                    rs_append(cpair || run, &s_cand_n, a.cand, a.region, slot);
+                    rs_append(cpair, &s_cand_n, a.cand, a.region, slot + 1);
+                }
+                const unsigned long long nm = __ballot(near);
+                if (nm) {
+                    uint32_t qb = 0;
+                    const int leader = __ffsll((long long)nm) - 1;
+                    if (lane == leader) qb = atomicAdd(&s_qx, (uint32_t)__popcll(nm));
+                    qb = __shfl(qb, leader, 64);
+                    if (near) xq[qb + (uint32_t)__popcll(nm & ((1ull << lane) - 1))] = (uint16_t)i;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the queue: the general code ----
+        {
+            uint32_t wl[RL_WAVES + 1], tot = 0;
+#pragma unroll
+            for (int q = 0; q < RL_WAVES; q++) { wl[q] = s_nq[q]; tot += wl[q]; }
+            wl[RL_WAVES] = s_qx; tot += wl[RL_WAVES];
+            const RsWordView view{sw, &a, lo_i, hi_i};
+            for (uint32_t e0 = 0; e0 < tot; e0 += RL_THREADS) {
+                if (e0 + (threadIdx.x & ~63u) >= tot) break;           // wave-uniform
+                uint32_t e = e0 + threadIdx.x;
+                const bool on = e < tot;
+                uint32_t src = 0;
+#pragma unroll
+                for (int q = 0; q < RL_WAVES; q++) { if (on && e >= wl[q] && src == (uint32_t)q) { e -= wl[q]; src = q + 1; } }
+                bool want_cand = false, want_tie = false;
+                uint64_t kslot = 0;
+                if (on) {
+                    const int i = s_queue[src * RL_WLIST + e];
+                    kslot = base + (uint64_t)(i - RS_HALO);
+                    const bool is_tie = (i > lo_i && (sw[i - 1] >> a.pb) == (sw[i] >> a.pb)) || (i + 1 < hi_i && (sw[i + 1] >> a.pb) == (sw[i] >> a.pb));
+                    if (!(a.values_only && is_tie)) rank_scan_slow(a, view, i, lo_i, hi_i, kslot, want_cand, want_tie);
+                }
+                if (!a.values_only) {
+                    rs_append(want_cand, &s_cand_n, a.cand, a.region, (uint32_t)kslot);
+                    rs_append(want_tie, &s_tie_n, a.ties, a.tie_region, (uint32_t)kslot);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
+}
+
+// Can fractions of the row length in single precision tell the columns apart?  x = fract((float)position * (float)(1 / row length)):
+// the position is rounded to 24 bits (2^(pb - 24) / 2 off at most), the product twice more (2^-23 of position / row length
+// together, plus the inverse's own rounding): delta bounds the error with room to spare.
+static bool rs_lean_setup(const RankArgs &a, int pb, LeanArgs *f)
+{
+    const double L = (double)a.row_len;
+    const double delta = (ldexp(1.0, pb - 24) + 2.0) / L + ldexp(1.0, pb - 21) / L + 1e-6;
+    f->inv_row_len = (float)(1.0 / L);
+    f->eps = (float)(2.0 * delta);
+    f->near_end = (float)(1.0 - 65.0 / L - delta);
+    return 2.0 * delta < 0.01 && pb <= 32;
+}
+
 // The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_fused) could not classify from its sub-bucket
 // alone -- up to dcap of every sub-bucket (regions of `defer`, counts in cnt_d), and the sub-buckets too large for that
 // kernel in full (ranges[0] ranges: first slot ranges[2 + 2 e], slots ranges[3 + 2 e]) --: rank_scan_slow on the RS_HALO
@@ -746,7 +957,11 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     a.ties = ctx->tie_list.as<uint32_t>();
     a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
+    LeanArgs lf;
+    if (layout == FBG_SLOTS_PACKED && a.g_min > (uint32_t)a.K && !a.values_only && !a.part_mode && !ctx->opt.rank_no_lean && rs_lean_setup(a, a.pb, &lf))
+        hipLaunchKernelGGL(k_rank_scan_lean, dim3(rs_blocks), dim3(RL_THREADS), 0, st, a, lf);
+    else
+        RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     if (ctx->opt.no_aux_stream) {
         RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a, 1u, rs_blocks);
