@@ -254,215 +254,196 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
     if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
 }
 
-// ---- the same scan with a tenth of the instructions per slot (packed slots, threshold above K, no partitions) ----------
-// k_rank_scan spends 160 vector instructions per 64 slots and is bound by that, not by the 8 bytes per slot it reads
-// (4.05 ms for 10^9 slots; 1.3 ms at the rate memory delivers).  With the threshold above K a slot can only matter if it
-// ties on the key, shares its column with a neighbour, sits next to a tie group or lies in the 64 columns nearest a row
-// end -- one slot in fifteen -- and the others should cost next to nothing:
-//   * a chunk of RL_CHUNK slots (+ RS_HALO either side) is staged in LDS as it comes, together with x = fract(position /
-//     row length) in single precision per slot: four instructions instead of the thirteen of the exact remainder, off by
-//     less than eps / 2 (fbg_lean_setup), so that |x - x'| < eps or > 1 - eps whenever two slots share a column, and
-//     x >= near_end or x < eps for a slot near a row end: filters that never say no wrongly;
-//   * a wave looks at 64 consecutive slots, a lane each: "ties with the next slot", "may share the column of the next /
-//     the one after" are wave-wide masks (one compare and ballot each), the cases of k_rank_scan's fast path are scalar
-//     logic on shifted copies of them.  Lanes 3 .. 61 are settled, consecutive rows overlap by five slots;
-//   * heads of groups of two and slots the filters let through (4 % of the slots) are noted in the wave's own stretch of
-//     an LDS list and worked on afterwards, a lane each, with exact arithmetic: a pair is "simple" (k_rank_scan's test)
-//     and goes to the tie list, or both members go to the candidates; a slot that shares its column with a neighbour
-//     (with either member of a pair next to it) becomes a candidate;
+// ---- the same scan with half the instructions per slot (packed slots below 2^31, threshold above K, no partitions) ----
+// k_rank_scan issues 200 instructions per 64 slots (86 vector, 101 scalar, 10 LDS: profiles/r04_sq_counters_scan_v1.txt)
+// and is bound by that -- a SIMD issues one instruction of any kind every 3 to 4 cycles at the occupancy these kernels
+// reach -- not by the 8 bytes per slot it reads (4.05 ms for 10^9 slots; 1.3 ms at the rate memory delivers).  With the
+// threshold above K a slot can only matter if it ties on the key, shares its column with a neighbour, sits next to a tie
+// group or lies in the 64 columns nearest a row end -- one slot in fifteen -- and the others should cost as little as can be:
+//   * no LDS staging, no barriers: a wave streams through a stretch of the slots of its own, 64 consecutive slots at a
+//     time, a lane each, the next row's loads in flight; the neighbours' values come by DPP shifts (lanes 3 .. 60 are
+//     settled, consecutive rows overlap by six slots);
+//   * x = fract(position / row length) in single precision stands in for the column: four instructions instead of the
+//     thirteen of the exact remainder, off by less than eps / 2 (rs_lean_setup), so that |x - x'| < eps or > 1 - eps
+//     whenever two slots share a column, and x >= near_end or x < eps for a slot near a row end: filters that never say
+//     no wrongly;
+//   * "ties with the next slot", "may share the column of the next / the one after" are wave-wide masks (one compare and
+//     ballot each); the cases of k_rank_scan's fast path are scalar logic on shifted copies of them;
+//   * heads of groups of two and slots the filters let through (4 % of the slots) are noted in the wave's own list in
+//     LDS; whenever 64 have come together they are worked on, a lane each, with exact arithmetic (the slots around them
+//     read from global memory again: cache hits): a pair is "simple" (k_rank_scan's test) and goes to the tie list, or
+//     both members go to the candidates; a slot that shares its column with a neighbour (with either member of a pair
+//     next to it) becomes a candidate;
 //   * the rest -- members of groups of three and more, their neighbours, slots near a row end or near the ends of the
-//     array: a few in a thousand -- queue up for rank_scan_slow, the general code.
-// Every slot is settled by the workgroup that owns it (a pair by the owner of its head): same lists, same entries as
+//     array: a few in a thousand -- collect in a second list for rank_scan_slow, the general code.
+// Every slot is settled by the wave that owns it (a pair by the owner of its head): same lists, same entries as
 // k_rank_scan's, in another order.
-#define RL_ROWS 8
 #define RL_EV_LO 3
-#define RL_EV_HI 61
+#define RL_EV_HI 60
 #define RL_EV (RL_EV_HI - RL_EV_LO + 1)
 #define RL_THREADS 256
 #define RL_WAVES (RL_THREADS / 64)
-#define RL_CHUNK (RL_WAVES * RL_ROWS * RL_EV)
-#define RL_STAGED (RL_CHUNK + 2 * RS_HALO)
-#define RL_ITEMS ((RL_STAGED + RL_THREADS - 1) / RL_THREADS)
-#define RL_WLIST (RL_ROWS * RL_EV)             // what a wave can note / queue in a chunk
+#define RL_LIST 128                            // a wave's list: worked off whenever 64 entries have come together
 
-struct LeanArgs { float inv_row_len, eps, near_end; };
+struct LeanArgs { float inv_row_len, eps, near_end; uint64_t per_wave; };
 
-__global__ __launch_bounds__(RL_THREADS) void k_rank_scan_lean(RankArgs a, LeanArgs f)
+// lane l gets lane l + 1's value (lane 63: 0)
+__device__ __forceinline__ uint32_t rl_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t rl_lanes_below(unsigned long long m)      // bits of m below this lane's
 {
-    __shared__ uint64_t sw[RL_STAGED + 8];                      // slot base - RS_HALO + i at index i (rows read up to two beyond)
-    __shared__ float sf[RL_STAGED + 8];
-    __shared__ uint16_t s_note[RL_WAVES * RL_WLIST], s_queue[RL_WAVES * RL_WLIST + RL_CHUNK];   // per wave; the queue also takes what the noted slots add
-    __shared__ uint32_t s_nn[RL_WAVES], s_nq[RL_WAVES], s_qx, s_cand_n, s_tie_n;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint64_t nchunks = (a.own_hi - a.own_lo + RL_CHUNK - 1) / RL_CHUNK;
-    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
-    for (int i = threadIdx.x; i < 8; i += RL_THREADS) { sw[RL_STAGED + i] = 0; sf[RL_STAGED + i] = 0.5f; }
-    uint64_t w[RL_ITEMS];
-    auto fetch = [&](uint64_t c) {
-        const uint64_t base = a.own_lo + c * RL_CHUNK;
-        const int lo_i = c == 0 ? RS_HALO : 0;
-        const int hi_i = (int)min((uint64_t)RL_STAGED, a.own_hi - base + RS_HALO);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// the noted slots [0, n) of a wave's list (n <= 64), a lane each: bit 31 = a slot that does not tie (else: the head of a pair)
+__device__ __forceinline__ void rl_noted(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *my_queue, uint32_t &nq,
+                                         uint32_t *s_cand_n, uint32_t *s_tie_n)
+{
+    const int lane = threadIdx.x & 63;
+    const bool on = (uint32_t)lane < n;
+    const uint32_t v = on ? list[lane] : 0u;
+    const uint64_t slot = on ? (uint64_t)(v & 0x7fffffffu) : a.own_lo + 8;
+    const bool is_odd = on && (v >> 31), is_head = on && !(v >> 31);
+    // slots slot - 2 .. slot + 3 (all there: the ends of the array take the other way): keys k[0..5], symbols left r[0..5]
+    uint64_t k[6];
+    uint32_t r[6];
 #pragma unroll
-        for (int r = 0; r < RL_ITEMS; r++) {
-            const int i = (int)threadIdx.x + r * RL_THREADS;
-            w[r] = (i >= lo_i && i < hi_i) ? a.keys[base + (uint64_t)i - RS_HALO] : 0ull;
-        }
-    };
-    if (blockIdx.x < nchunks) fetch(blockIdx.x);
-    for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint64_t base = a.own_lo + c * RL_CHUNK;                 // slot of index RS_HALO
-        const int lo_i = c == 0 ? RS_HALO : 0;                         // index of the first / one past the last slot there is
-        const int hi_i = (int)min((uint64_t)RL_STAGED, a.own_hi - base + RS_HALO);
-        const bool last = base + RL_CHUNK >= a.own_hi;
-#pragma unroll
-        for (int r = 0; r < RL_ITEMS; r++) {
-            const int i = (int)threadIdx.x + r * RL_THREADS;
-            if (i < RL_STAGED) {
-                sw[i] = w[r];
-                sf[i] = __builtin_amdgcn_fractf((float)((uint32_t)w[r] & (uint32_t)a.pmask) * f.inv_row_len);
-            }
-        }
-        if (threadIdx.x == 0) s_qx = 0;
-        __syncthreads();
-        if (c + gridDim.x < nchunks) fetch(c + gridDim.x);             // in flight during this chunk's work
-        // ---- every slot ----
-        {
-            uint16_t *my_note = s_note + wv * RL_WLIST, *my_queue = s_queue + wv * RL_WLIST;
-            uint32_t nn = 0, nq = 0;                                    // (wave-uniform)
-            for (int r = 0; r < RL_ROWS; r++) {
-                const int i0 = RS_HALO + (wv * RL_ROWS + r) * RL_EV;   // the first slot this row settles
-                if (i0 >= hi_i) break;                                  // wave-uniform
-                const int i = i0 - RL_EV_LO + lane;
-                const uint64_t x = sw[i], xn = sw[i + 1];
-                const float fr = sf[i], d1 = fr - sf[i + 1], d2 = fr - sf[i + 2];
-                const bool v0 = i >= lo_i && i < hi_i, v1 = i + 1 >= lo_i && i + 1 < hi_i, v2 = i + 2 >= lo_i && i + 2 < hi_i;
-                // bit l of a mask speaks of the slot of lane l (and those after it)
-                const unsigned long long E = __ballot(v0 && v1 && ((x ^ xn) >> a.pb) == 0);                          // ties with the next slot
-                const unsigned long long R1 = __ballot(v0 && v1 && (fabsf(d1) < f.eps || fabsf(d1) > 1.0f - f.eps));   // may share the next slot's column
-                const unsigned long long R2 = __ballot(v0 && v2 && (fabsf(d2) < f.eps || fabsf(d2) > 1.0f - f.eps));   // ... that of the slot after the next
-                const unsigned long long NE = __ballot(fr >= f.near_end || fr < f.eps);    // may lie near its row's end, or be a '#'
-                const bool mine = v0 && lane >= RL_EV_LO && lane <= RL_EV_HI && i < RS_HALO + RL_CHUNK;
-                // the ends of the array: the general code knows what a missing neighbour means
-                const unsigned long long XQ = __ballot(mine && ((c == 0 && i < 2 * RS_HALO) || (last && i + RS_HALO >= hi_i)));
-                const unsigned long long OWN = __ballot(mine) & ~XQ;
-                const unsigned long long TIE = E | (E << 1);
-                const unsigned long long PH = E & ~(E << 1) & ~(E >> 1);                    // head of a group of exactly two
-                const unsigned long long PT = PH << 1;
-                const unsigned long long LONG = TIE & ~(PH | PT);                           // member of a group of three and more
-                const unsigned long long ADJL = ((LONG >> 1) | (LONG << 1)) & ~TIE;         // next to one: any member may end up next to it
-                const unsigned long long RUN = R1 | (R1 << 1) | ((PT << 1) & (R2 << 2)) | ((PH >> 1) & R2);
-                const unsigned long long Q = XQ | (OWN & (LONG | ADJL));
-                const unsigned long long NH = OWN & PH, NO = OWN & ~TIE & ~ADJL & (RUN | NE);
-                const unsigned long long NT = NH | NO;
-                if ((NT >> lane) & 1ull)
-                    my_note[nn + (uint32_t)__popcll(NT & ((1ull << lane) - 1))] = (uint16_t)((uint32_t)i | (((NO >> lane) & 1ull) ? 0x8000u : 0u));
-                nn += (uint32_t)__popcll(NT);
-                if (Q) {
-                    if ((Q >> lane) & 1ull) my_queue[nq + (uint32_t)__popcll(Q & ((1ull << lane) - 1))] = (uint16_t)i;
-                    nq += (uint32_t)__popcll(Q);
-                }
-            }
-            if (lane == 0) { s_nn[wv] = nn; s_nq[wv] = nq; }
-        }
-        __syncthreads();
-        // ---- the noted slots, a lane each, exactly ----
-        {
-            uint32_t wl[RL_WAVES], tot = 0;
-#pragma unroll
-            for (int q = 0; q < RL_WAVES; q++) { wl[q] = s_nn[q]; tot += wl[q]; }
-            uint16_t *xq = s_queue + RL_WAVES * RL_WLIST;               // what this phase adds to the queue
-            for (uint32_t e0 = 0; e0 < tot; e0 += RL_THREADS) {
-                if (e0 + (threadIdx.x & ~63u) >= tot) break;           // wave-uniform
-                uint32_t e = e0 + threadIdx.x;
-                const bool on = e < tot;
-                uint32_t src = 0;
-#pragma unroll
-                for (int q = 0; q < RL_WAVES; q++) { if (on && e >= wl[q] && src == (uint32_t)q) { e -= wl[q]; src = q + 1; } }
-                const uint32_t v = on ? s_note[src * RL_WLIST + e] : (uint32_t)RS_HALO;
-                const int i = (int)(v & 0x7fffu);
-                const bool is_odd = on && (v & 0x8000u), is_head = on && !(v & 0x8000u);
-                // slots i - 2 .. i + 3 (all there: the ends of the array took the other way): keys k[0..5], symbols left r[0..5]; slot i is k[2]
-                uint64_t k[6];
-                uint32_t r[6];
-#pragma unroll
-                for (int dd = 0; dd < 6; dd++) {
-                    const uint64_t x = sw[i - 2 + dd];
-                    k[dd] = x >> a.pb;
-                    r[dd] = rs_rem<FBG_SLOTS_PACKED>(a, x & a.pmask);
-                }
-                const uint32_t slot = (uint32_t)(base + (uint64_t)(i - RS_HALO));
-                // a group of two: simple = both with K real symbols, their two columns and those of the slots before and after
-                // all different, no tie group right next to it (k_rank_scan)
-                const bool simple = is_head && r[2] >= (uint32_t)a.K && r[3] >= (uint32_t)a.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] &&
-                                    r[1] != r[3] && k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
-                const bool cpair = is_head && !simple;
-                // a slot that does not tie (nor sits next to a longer group): a run with a neighbour -- either half of a tied pair
-                // may end up next to it --, or near its row's end (the general code computes its extension)
-                bool run = false, near = false;
-                if (is_odd && r[2] != 0) {
-                    run = r[1] == r[2] || r[3] == r[2] || (k[0] == k[1] && r[0] == r[2]) || (k[3] == k[4] && r[4] == r[2]);
-                    near = !run && r[2] <= 64;
-                }
-                if (!a.values_only) {
-                    rs_append(simple, &s_tie_n, a.ties, a.tie_region, slot);
-                    rs_append(cpair || run, &s_cand_n, a.cand, a.region, slot);
-                    rs_append(cpair, &s_cand_n, a.cand, a.region, slot + 1);
-                }
-                const unsigned long long nm = __ballot(near);
-                if (nm) {
-                    uint32_t qb = 0;
-                    const int leader = __ffsll((long long)nm) - 1;
-                    if (lane == leader) qb = atomicAdd(&s_qx, (uint32_t)__popcll(nm));
-                    qb = __shfl(qb, leader, 64);
-                    if (near) xq[qb + (uint32_t)__popcll(nm & ((1ull << lane) - 1))] = (uint16_t)i;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- the queue: the general code ----
-        {
-            uint32_t wl[RL_WAVES + 1], tot = 0;
-#pragma unroll
-            for (int q = 0; q < RL_WAVES; q++) { wl[q] = s_nq[q]; tot += wl[q]; }
-            wl[RL_WAVES] = s_qx; tot += wl[RL_WAVES];
-            const RsWordView view{sw, &a, lo_i, hi_i};
-            for (uint32_t e0 = 0; e0 < tot; e0 += RL_THREADS) {
-                if (e0 + (threadIdx.x & ~63u) >= tot) break;           // wave-uniform
-                uint32_t e = e0 + threadIdx.x;
-                const bool on = e < tot;
-                uint32_t src = 0;
-#pragma unroll
-                for (int q = 0; q < RL_WAVES; q++) { if (on && e >= wl[q] && src == (uint32_t)q) { e -= wl[q]; src = q + 1; } }
-                bool want_cand = false, want_tie = false;
-                uint64_t kslot = 0;
-                if (on) {
-                    const int i = s_queue[src * RL_WLIST + e];
-                    kslot = base + (uint64_t)(i - RS_HALO);
-                    const bool is_tie = (i > lo_i && (sw[i - 1] >> a.pb) == (sw[i] >> a.pb)) || (i + 1 < hi_i && (sw[i + 1] >> a.pb) == (sw[i] >> a.pb));
-                    if (!(a.values_only && is_tie)) rank_scan_slow(a, view, i, lo_i, hi_i, kslot, want_cand, want_tie);
-                }
-                if (!a.values_only) {
-                    rs_append(want_cand, &s_cand_n, a.cand, a.region, (uint32_t)kslot);
-                    rs_append(want_tie, &s_tie_n, a.ties, a.tie_region, (uint32_t)kslot);
-                }
-            }
-        }
-        __syncthreads();
+    for (int dd = 0; dd < 6; dd++) {
+        const uint64_t x = a.keys[slot - 2 + dd];
+        k[dd] = x >> a.pb;
+        r[dd] = rs_rem<FBG_SLOTS_PACKED>(a, x & a.pmask);
     }
-    if (threadIdx.x == 0 && !a.values_only) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
+    // a group of two: simple = both with K real symbols, their two columns and those of the slots before and after all
+    // different, no tie group right next to it (k_rank_scan)
+    const bool simple = is_head && r[2] >= (uint32_t)a.K && r[3] >= (uint32_t)a.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] && r[1] != r[3] &&
+                        k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
+    const bool cpair = is_head && !simple;
+    // a slot that does not tie (nor sits next to a longer group): a run with a neighbour -- either half of a tied pair may
+    // end up next to it --, or near its row's end (the general code computes its extension)
+    bool run = false, near = false;
+    if (is_odd && r[2] != 0) {
+        run = r[1] == r[2] || r[3] == r[2] || (k[0] == k[1] && r[0] == r[2]) || (k[3] == k[4] && r[4] == r[2]);
+        near = !run && r[2] <= 64;
+    }
+    rs_append(simple, s_tie_n, a.ties, a.tie_region, (uint32_t)slot);
+    rs_append(cpair || run, s_cand_n, a.cand, a.region, (uint32_t)slot);
+    rs_append(cpair, s_cand_n, a.cand, a.region, (uint32_t)slot + 1);
+    const unsigned long long nm = __ballot(near);
+    if (nm) {
+        if (near) my_queue[nq + rl_lanes_below(nm)] = (uint32_t)slot;
+        nq += (uint32_t)__popcll(nm);
+    }
+}
+
+// the queued slots [0, n) of a wave's list (n <= 64): rank_scan_slow on the RS_HALO slots either side, from global memory
+__device__ __forceinline__ void rl_queued(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *s_cand_n, uint32_t *s_tie_n)
+{
+    const int lane = threadIdx.x & 63;
+    bool want_cand = false, want_tie = false;
+    uint64_t k = 0;
+    if ((uint32_t)lane < n) {
+        k = list[lane];
+        const int64_t base = (int64_t)k - RS_HALO;                     // slot of window index 0
+        const int lo_i = (int)max((int64_t)0, (int64_t)a.own_lo - base);
+        const int hi_i = (int)min((int64_t)(2 * RS_HALO + 1), (int64_t)a.own_hi - base);
+        const RsWordView view{a.keys + base, &a, lo_i, hi_i};
+        rank_scan_slow(a, view, RS_HALO, lo_i, hi_i, k, want_cand, want_tie);
+    }
+    rs_append(want_cand, s_cand_n, a.cand, a.region, (uint32_t)k);
+    rs_append(want_tie, s_tie_n, a.ties, a.tie_region, (uint32_t)k);
+}
+
+// the first 64 entries of a list are done with: the rest moves to the front
+__device__ __forceinline__ void rl_shift(uint32_t *list, uint32_t &n)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t rest = n - 64;
+    const uint32_t v = (uint32_t)lane < rest ? list[64 + lane] : 0u;
+    if ((uint32_t)lane < rest) list[lane] = v;
+    n = rest;
+}
+
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rank_scan_lean(RankArgs a, LeanArgs f)
+{
+    __shared__ uint32_t s_note[RL_WAVES][RL_LIST], s_queue[RL_WAVES][RL_LIST];
+    __shared__ uint32_t s_cand_n, s_tie_n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
+    __syncthreads();
+    uint32_t *my_note = s_note[wv], *my_queue = s_queue[wv];
+    uint32_t nn = 0, nq = 0;                                            // (wave-uniform)
+    const uint64_t wlo = a.own_lo + ((uint64_t)blockIdx.x * RL_WAVES + wv) * f.per_wave;     // per_wave: a multiple of RL_EV
+    const uint64_t whi = min(a.own_hi, wlo + f.per_wave);
+    const unsigned long long EVM = ((1ull << (RL_EV_HI + 1)) - 1) & ~((1ull << RL_EV_LO) - 1);   // the lanes that settle their slots
+    auto load_row = [&](uint64_t k0) -> uint64_t {
+        const int64_t k = (int64_t)k0 - RL_EV_LO + lane;
+        return (k >= (int64_t)a.own_lo && k < (int64_t)a.own_hi) ? a.keys[k] : 0ull;
+    };
+    uint64_t xnext = wlo < whi ? load_row(wlo) : 0ull;
+    for (uint64_t k0 = wlo; k0 < whi; k0 += RL_EV) {
+        const uint64_t x = xnext;
+        if (k0 + RL_EV < whi) xnext = load_row(k0 + RL_EV);            // in flight during this row's work
+        const uint32_t slot = (uint32_t)k0 - RL_EV_LO + (uint32_t)lane;
+        // rows within reach of the ends of the array (or of this wave's last slot, where a row is not full): the general
+        // code knows what a missing neighbour means
+        if (k0 < a.own_lo + 2 * RS_HALO || k0 + RL_EV + 2 * RS_HALO > a.own_hi || k0 + RL_EV > whi) {
+            const unsigned long long Q = EVM & __ballot((uint64_t)k0 - RL_EV_LO + lane < whi);
+            if ((Q >> lane) & 1ull) my_queue[nq + rl_lanes_below(Q)] = slot;
+            nq += (uint32_t)__popcll(Q);
+        } else {
+            const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+            const uint32_t dh = hi ^ rl_from_next(hi), dl = (lo ^ rl_from_next(lo)) >> a.pb;    // (pb < 32: the position lies in the low word)
+            const float fr = __builtin_amdgcn_fractf((float)(lo & (uint32_t)a.pmask) * f.inv_row_len);
+            const float f1 = __uint_as_float(rl_from_next(__float_as_uint(fr))), f2 = __uint_as_float(rl_from_next(__float_as_uint(f1)));
+            const float d1 = fabsf(fr - f1), d2 = fabsf(fr - f2);
+            // bit l of a mask speaks of the slot of lane l (and those after it); lane 63 has no neighbour, nobody asks
+            const unsigned long long E = __ballot((dh | dl) == 0);                           // ties with the next slot
+            const unsigned long long R1 = __ballot(d1 < f.eps) | __ballot(d1 > 1.0f - f.eps);   // may share the next slot's column
+            const unsigned long long R2 = __ballot(d2 < f.eps) | __ballot(d2 > 1.0f - f.eps);   // ... that of the slot after the next
+            const unsigned long long NE = __ballot(fr >= f.near_end) | __ballot(fr < f.eps);     // may lie near its row's end, or be a '#'
+            const unsigned long long TIE = E | (E << 1);
+            const unsigned long long PH = E & ~((E << 1) | (E >> 1));                        // head of a group of exactly two
+            const unsigned long long LONG = TIE & ~(PH | (PH << 1));                         // member of a group of three and more
+            const unsigned long long ADJL = ((LONG >> 1) | (LONG << 1)) & ~TIE;              // next to one: any member may end up next to it
+            const unsigned long long RUN = R1 | (R1 << 1) | ((PH & R2) << 2) | ((PH >> 1) & R2);
+            const unsigned long long Q = EVM & (LONG | ADJL);
+            const unsigned long long NO = EVM & ~(TIE | ADJL) & (RUN | NE);
+            const unsigned long long NT = (EVM & PH) | NO;
+            if (NT) {
+                if ((NT >> lane) & 1ull) my_note[nn + rl_lanes_below(NT)] = slot | (((NO >> lane) & 1ull) ? 0x80000000u : 0u);
+                nn += (uint32_t)__popcll(NT);
+            }
+            if (Q) {
+                if ((Q >> lane) & 1ull) my_queue[nq + rl_lanes_below(Q)] = slot;
+                nq += (uint32_t)__popcll(Q);
+            }
+        }
+        while (nq >= 64) { rl_queued(a, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
+        if (nn >= 64) {                                                 // (adds up to 64 slots to the queue: 63 + 64 fit)
+            rl_noted(a, my_note, 64, my_queue, nq, &s_cand_n, &s_tie_n);
+            rl_shift(my_note, nn);
+            while (nq >= 64) { rl_queued(a, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
+        }
+    }
+    if (nn) rl_noted(a, my_note, nn, my_queue, nq, &s_cand_n, &s_tie_n);
+    while (nq >= 64) { rl_queued(a, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
+    if (nq) rl_queued(a, my_queue, nq, &s_cand_n, &s_tie_n);
+    __syncthreads();
+    if (threadIdx.x == 0) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
 }
 
 // Can fractions of the row length in single precision tell the columns apart?  x = fract((float)position * (float)(1 / row length)):
 // the position is rounded to 24 bits (2^(pb - 24) / 2 off at most), the product twice more (2^-23 of position / row length
 // together, plus the inverse's own rounding): delta bounds the error with room to spare.
-static bool rs_lean_setup(const RankArgs &a, int pb, LeanArgs *f)
+static bool rs_lean_setup(const RankArgs &a, int pb, unsigned blocks, LeanArgs *f)
 {
+    const uint64_t own = a.own_hi - a.own_lo, waves = (uint64_t)blocks * RL_WAVES;
+    f->per_wave = ((own + waves - 1) / waves + RL_EV - 1) / RL_EV * RL_EV;
     const double L = (double)a.row_len;
     const double delta = (ldexp(1.0, pb - 24) + 2.0) / L + ldexp(1.0, pb - 21) / L + 1e-6;
     f->inv_row_len = (float)(1.0 / L);
     f->eps = (float)(2.0 * delta);
     f->near_end = (float)(1.0 - 65.0 / L - delta);
-    return 2.0 * delta < 0.01 && pb <= 32;
+    return 2.0 * delta < 0.01 && pb <= 31;
 }
 
 // The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_fused) could not classify from its sub-bucket
@@ -958,7 +939,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     LeanArgs lf;
-    if (layout == FBG_SLOTS_PACKED && a.g_min > (uint32_t)a.K && !a.values_only && !a.part_mode && !ctx->opt.rank_no_lean && rs_lean_setup(a, a.pb, &lf))
+    if (layout == FBG_SLOTS_PACKED && a.g_min > (uint32_t)a.K && !a.values_only && !a.part_mode && !ctx->opt.rank_no_lean && rs_lean_setup(a, a.pb, rs_blocks, &lf))
         hipLaunchKernelGGL(k_rank_scan_lean, dim3(rs_blocks), dim3(RL_THREADS), 0, st, a, lf);
     else
         RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
