@@ -274,7 +274,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->msa_own, &ctx->text, &ctx->pos, &ctx->tot, &ctx->segtab, &ctx->exc_scratch, &ctx->prow, &ctx->igrow, &ctx->rec,
                       &ctx->xlist, &ctx->gmax, &ctx->excol, &ctx->xslot, &ctx->xbits, &ctx->exc, &ctx->colT, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->grp, &ctx->flags,
-                      &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->msd_w, &ctx->msd_v, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
+                      &ctx->list, &ctx->tie_list, &ctx->big_groups, &ctx->kargs, &ctx->msd_w, &ctx->msd_v, &ctx->tmp, &ctx->small, &ctx->scalars, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c,
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d,
                       &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h, &ctx->gwin, &ctx->gbits, &ctx->gwin_rows,

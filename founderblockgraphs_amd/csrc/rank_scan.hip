@@ -285,7 +285,13 @@ template <int L, bool PLAIN> __global__ __launch_bounds__(RS_THREADS) __attribut
 #define RL_WAVES (RL_THREADS / 64)
 #define RL_LIST 128                            // a wave's list: worked off whenever 64 entries have come together
 
-struct LeanArgs { float inv_row_len, eps, near_end; uint64_t per_wave; };
+struct LeanArgs {
+    const uint64_t *keys;                      // what the rows need of the scan's arguments
+    uint64_t own_lo, own_hi;
+    uint32_t per_wave, pmask;
+    int pb;
+    float inv_row_len, eps, one_minus_eps, near_end;
+};
 
 // lane l gets lane l + 1's value (lane 63: 0)
 __device__ __forceinline__ uint32_t rl_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
@@ -294,48 +300,16 @@ __device__ __forceinline__ uint32_t rl_lanes_below(unsigned long long m)      //
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// the noted slots [0, n) of a wave's list (n <= 64), a lane each: bit 31 = a slot that does not tie (else: the head of a pair)
-__device__ __forceinline__ void rl_noted(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *my_queue, uint32_t &nq,
-                                         uint32_t *s_cand_n, uint32_t *s_tie_n)
+// the noted slots [0, n) of a wave's list (n <= 64): heads of simple pairs, to the tie list
+__device__ __attribute__((noinline)) void rl_noted(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *s_tie_n)
 {
     const int lane = threadIdx.x & 63;
     const bool on = (uint32_t)lane < n;
-    const uint32_t v = on ? list[lane] : 0u;
-    const uint64_t slot = on ? (uint64_t)(v & 0x7fffffffu) : a.own_lo + 8;
-    const bool is_odd = on && (v >> 31), is_head = on && !(v >> 31);
-    // slots slot - 2 .. slot + 3 (all there: the ends of the array take the other way): keys k[0..5], symbols left r[0..5]
-    uint64_t k[6];
-    uint32_t r[6];
-#pragma unroll
-    for (int dd = 0; dd < 6; dd++) {
-        const uint64_t x = a.keys[slot - 2 + dd];
-        k[dd] = x >> a.pb;
-        r[dd] = rs_rem<FBG_SLOTS_PACKED>(a, x & a.pmask);
-    }
-    // a group of two: simple = both with K real symbols, their two columns and those of the slots before and after all
-    // different, no tie group right next to it (k_rank_scan)
-    const bool simple = is_head && r[2] >= (uint32_t)a.K && r[3] >= (uint32_t)a.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] && r[1] != r[3] &&
-                        k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
-    const bool cpair = is_head && !simple;
-    // a slot that does not tie (nor sits next to a longer group): a run with a neighbour -- either half of a tied pair may
-    // end up next to it --, or near its row's end (the general code computes its extension)
-    bool run = false, near = false;
-    if (is_odd && r[2] != 0) {
-        run = r[1] == r[2] || r[3] == r[2] || (k[0] == k[1] && r[0] == r[2]) || (k[3] == k[4] && r[4] == r[2]);
-        near = !run && r[2] <= 64;
-    }
-    rs_append(simple, s_tie_n, a.ties, a.tie_region, (uint32_t)slot);
-    rs_append(cpair || run, s_cand_n, a.cand, a.region, (uint32_t)slot);
-    rs_append(cpair, s_cand_n, a.cand, a.region, (uint32_t)slot + 1);
-    const unsigned long long nm = __ballot(near);
-    if (nm) {
-        if (near) my_queue[nq + rl_lanes_below(nm)] = (uint32_t)slot;
-        nq += (uint32_t)__popcll(nm);
-    }
+    rs_append(on, s_tie_n, a.ties, a.tie_region, on ? list[lane] : 0u);
 }
 
 // the queued slots [0, n) of a wave's list (n <= 64): rank_scan_slow on the RS_HALO slots either side, from global memory
-__device__ __forceinline__ void rl_queued(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *s_cand_n, uint32_t *s_tie_n)
+__device__ __attribute__((noinline)) void rl_queued(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *s_cand_n, uint32_t *s_tie_n)
 {
     const int lane = threadIdx.x & 63;
     bool want_cand = false, want_tie = false;
@@ -362,88 +336,104 @@ __device__ __forceinline__ void rl_shift(uint32_t *list, uint32_t &n)
     n = rest;
 }
 
-__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rank_scan_lean(RankArgs a, LeanArgs f)
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rank_scan_lean(const RankArgs *__restrict__ ap, LeanArgs f)
 {
+    // (the scan's arguments stay in memory: the rows below need a handful of them, and in scalar registers all of them
+    // together crowd out the masks)
     __shared__ uint32_t s_note[RL_WAVES][RL_LIST], s_queue[RL_WAVES][RL_LIST];
     __shared__ uint32_t s_cand_n, s_tie_n;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // (told to be uniform: the loop below runs on scalar registers)
     if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
     __syncthreads();
     uint32_t *my_note = s_note[wv], *my_queue = s_queue[wv];
     uint32_t nn = 0, nq = 0;                                            // (wave-uniform)
-    const uint64_t wlo = a.own_lo + ((uint64_t)blockIdx.x * RL_WAVES + wv) * f.per_wave;     // per_wave: a multiple of RL_EV
-    const uint64_t whi = min(a.own_hi, wlo + f.per_wave);
+    const uint32_t own_lo = (uint32_t)f.own_lo, own_hi = (uint32_t)f.own_hi;   // (below 2^31: rs_lean_setup)
+    const uint32_t wlo = own_lo + ((uint32_t)blockIdx.x * RL_WAVES + (uint32_t)wv) * f.per_wave;   // per_wave: a multiple of RL_EV
+    const uint32_t whi = min(own_hi, wlo + f.per_wave);
     const unsigned long long EVM = ((1ull << (RL_EV_HI + 1)) - 1) & ~((1ull << RL_EV_LO) - 1);   // the lanes that settle their slots
-    auto load_row = [&](uint64_t k0) -> uint64_t {
-        const int64_t k = (int64_t)k0 - RL_EV_LO + lane;
-        return (k >= (int64_t)a.own_lo && k < (int64_t)a.own_hi) ? a.keys[k] : 0ull;
+    const unsigned long long RNG = ~(1ull << 63);                       // the lanes whose mask bits somebody may ask for
+    const uint64_t *__restrict__ keys = f.keys;
+    auto load_row = [&](uint32_t k0) -> uint64_t {
+        // (a row that reaches beyond the array is a row the general code takes: what its lanes out there load does not matter)
+        const uint32_t k = min(max(k0 - RL_EV_LO + (uint32_t)lane, own_lo), own_hi - 1);
+        return keys[k];
     };
     uint64_t xnext = wlo < whi ? load_row(wlo) : 0ull;
-    for (uint64_t k0 = wlo; k0 < whi; k0 += RL_EV) {
+    for (uint32_t k0 = wlo; k0 < whi; k0 += RL_EV) {
         const uint64_t x = xnext;
         if (k0 + RL_EV < whi) xnext = load_row(k0 + RL_EV);            // in flight during this row's work
-        const uint32_t slot = (uint32_t)k0 - RL_EV_LO + (uint32_t)lane;
+        const uint32_t slot = k0 - RL_EV_LO + (uint32_t)lane;
         // rows within reach of the ends of the array (or of this wave's last slot, where a row is not full): the general
         // code knows what a missing neighbour means
-        if (k0 < a.own_lo + 2 * RS_HALO || k0 + RL_EV + 2 * RS_HALO > a.own_hi || k0 + RL_EV > whi) {
-            const unsigned long long Q = EVM & __ballot((uint64_t)k0 - RL_EV_LO + lane < whi);
+        if (k0 < own_lo + 2 * RS_HALO || k0 + RL_EV + 2 * RS_HALO > own_hi || k0 + RL_EV > whi) {
+            const unsigned long long Q = EVM & __ballot(slot < whi);
             if ((Q >> lane) & 1ull) my_queue[nq + rl_lanes_below(Q)] = slot;
             nq += (uint32_t)__popcll(Q);
         } else {
             const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-            const uint32_t dh = hi ^ rl_from_next(hi), dl = (lo ^ rl_from_next(lo)) >> a.pb;    // (pb < 32: the position lies in the low word)
-            const float fr = __builtin_amdgcn_fractf((float)(lo & (uint32_t)a.pmask) * f.inv_row_len);
+            const uint32_t dh = hi ^ rl_from_next(hi), dl = (lo ^ rl_from_next(lo)) >> f.pb;    // (pb < 32: the position lies in the low word)
+            const float fr = __builtin_amdgcn_fractf((float)(lo & f.pmask) * f.inv_row_len);
             const float f1 = __uint_as_float(rl_from_next(__float_as_uint(fr))), f2 = __uint_as_float(rl_from_next(__float_as_uint(f1)));
             const float d1 = fabsf(fr - f1), d2 = fabsf(fr - f2);
             // bit l of a mask speaks of the slot of lane l (and those after it); lane 63 has no neighbour, nobody asks
             const unsigned long long E = __ballot((dh | dl) == 0);                           // ties with the next slot
-            const unsigned long long R1 = __ballot(d1 < f.eps) | __ballot(d1 > 1.0f - f.eps);   // may share the next slot's column
-            const unsigned long long R2 = __ballot(d2 < f.eps) | __ballot(d2 > 1.0f - f.eps);   // ... that of the slot after the next
+            const unsigned long long R1 = __ballot(d1 < f.eps) | __ballot(d1 > f.one_minus_eps);   // may share the next slot's column
+            const unsigned long long R2 = __ballot(d2 < f.eps) | __ballot(d2 > f.one_minus_eps);   // ... that of the slot after the next
             const unsigned long long NE = __ballot(fr >= f.near_end) | __ballot(fr < f.eps);     // may lie near its row's end, or be a '#'
-            const unsigned long long TIE = E | (E << 1);
-            const unsigned long long PH = E & ~((E << 1) | (E >> 1));                        // head of a group of exactly two
-            const unsigned long long LONG = TIE & ~(PH | (PH << 1));                         // member of a group of three and more
-            const unsigned long long ADJL = ((LONG >> 1) | (LONG << 1)) & ~TIE;              // next to one: any member may end up next to it
-            const unsigned long long RUN = R1 | (R1 << 1) | ((PH & R2) << 2) | ((PH >> 1) & R2);
-            const unsigned long long Q = EVM & (LONG | ADJL);
-            const unsigned long long NO = EVM & ~(TIE | ADJL) & (RUN | NE);
-            const unsigned long long NT = (EVM & PH) | NO;
-            if (NT) {
-                if ((NT >> lane) & 1ull) my_note[nn + rl_lanes_below(NT)] = slot | (((NO >> lane) & 1ull) ? 0x80000000u : 0u);
-                nn += (uint32_t)__popcll(NT);
+            unsigned long long SS, Q;                                   // heads of pairs that are simple for sure; slots for the general code
+            if (((R1 | R2 | NE | (E & (E << 1))) & RNG) == 0) {
+                // seven rows in ten: no slot of the row can share a column with one nearby or lie near a row end, no group of three:
+                // every tie is a pair, simple unless another pair sits right next to it
+                SS = EVM & E & ~((E << 2) | (E >> 2));
+                Q = EVM & E & ~SS;
+                Q |= Q << 1;
+            } else {
+                const unsigned long long TIE = E | (E << 1);
+                const unsigned long long PH = E & ~((E << 1) | (E >> 1));                    // head of a group of exactly two
+                const unsigned long long LONG = TIE & ~(PH | (PH << 1));                     // member of a group of three and more
+                const unsigned long long ADJL = ((LONG >> 1) | (LONG << 1)) & ~TIE;          // next to one: any member may end up next to it
+                // k_rank_scan's test of a pair (h, h + 1), with "may" for "does": both with K real symbols left (NE covers the K <= 64
+                // columns where not), their two columns and those of the slots before and after all different, no tie group next door
+                SS = EVM & PH & ~(NE | (NE >> 1) | R1 | (R1 << 1) | (R2 << 1) | R2 | (R1 >> 1) | (E << 2) | (E >> 2));
+                const unsigned long long QP = EVM & PH & ~SS;                                // pairs for the general code, both members
+                // a slot that does not tie: a run with a neighbour -- either half of a tied pair may end up next to it --, or near its row's end
+                const unsigned long long RUN = R1 | (R1 << 1) | ((PH & R2) << 2) | ((PH >> 1) & R2);
+                Q = QP | (QP << 1) | (EVM & (LONG | ADJL | (~TIE & (RUN | NE))));
+            }
+            if (SS) {
+                if ((SS >> lane) & 1ull) my_note[nn + rl_lanes_below(SS)] = slot;
+                nn += (uint32_t)__popcll(SS);
             }
             if (Q) {
                 if ((Q >> lane) & 1ull) my_queue[nq + rl_lanes_below(Q)] = slot;
                 nq += (uint32_t)__popcll(Q);
             }
         }
-        while (nq >= 64) { rl_queued(a, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
-        if (nn >= 64) {                                                 // (adds up to 64 slots to the queue: 63 + 64 fit)
-            rl_noted(a, my_note, 64, my_queue, nq, &s_cand_n, &s_tie_n);
-            rl_shift(my_note, nn);
-            while (nq >= 64) { rl_queued(a, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
-        }
+        while (nq >= 64) { rl_queued(*ap, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
+        if (nn >= 64) { rl_noted(*ap, my_note, 64, &s_tie_n); rl_shift(my_note, nn); }
     }
-    if (nn) rl_noted(a, my_note, nn, my_queue, nq, &s_cand_n, &s_tie_n);
-    while (nq >= 64) { rl_queued(a, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
-    if (nq) rl_queued(a, my_queue, nq, &s_cand_n, &s_tie_n);
+    if (nn) rl_noted(*ap, my_note, nn, &s_tie_n);
+    if (nq) rl_queued(*ap, my_queue, nq, &s_cand_n, &s_tie_n);
     __syncthreads();
-    if (threadIdx.x == 0) { a.blk_count[blockIdx.x] = s_cand_n; a.tie_count[blockIdx.x] = s_tie_n; }
+    if (threadIdx.x == 0) { ap->blk_count[blockIdx.x] = s_cand_n; ap->tie_count[blockIdx.x] = s_tie_n; }
 }
 
 // Can fractions of the row length in single precision tell the columns apart?  x = fract((float)position * (float)(1 / row length)):
-// the position is rounded to 24 bits (2^(pb - 24) / 2 off at most), the product twice more (2^-23 of position / row length
-// together, plus the inverse's own rounding): delta bounds the error with room to spare.
+// the position is rounded to 24 bits (2^(pb - 25) off at most), the product once and the inverse once (2^-23 of position / row
+// length together; delta allows twice that), fract is exact: delta bounds the error.
 static bool rs_lean_setup(const RankArgs &a, int pb, unsigned blocks, LeanArgs *f)
 {
     const uint64_t own = a.own_hi - a.own_lo, waves = (uint64_t)blocks * RL_WAVES;
-    f->per_wave = ((own + waves - 1) / waves + RL_EV - 1) / RL_EV * RL_EV;
+    f->per_wave = (uint32_t)(((own + waves - 1) / waves + RL_EV - 1) / RL_EV * RL_EV);
+    f->keys = a.keys; f->own_lo = a.own_lo; f->own_hi = a.own_hi; f->pmask = (uint32_t)a.pmask; f->pb = pb;
     const double L = (double)a.row_len;
-    const double delta = (ldexp(1.0, pb - 24) + 2.0) / L + ldexp(1.0, pb - 21) / L + 1e-6;
+    const double delta = (ldexp(1.0, pb - 25) + ldexp(1.0, pb - 22) + 2.0) / L + 1e-6;
     f->inv_row_len = (float)(1.0 / L);
     f->eps = (float)(2.0 * delta);
+    f->one_minus_eps = 1.0f - f->eps;
     f->near_end = (float)(1.0 - 65.0 / L - delta);
-    return 2.0 * delta < 0.01 && pb <= 31;
+    return 2.0 * delta < 0.01 && pb <= 31 && a.own_hi < (1ull << 31);
 }
 
 // The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_fused) could not classify from its sub-bucket
@@ -940,7 +930,13 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     LeanArgs lf;
     if (layout == FBG_SLOTS_PACKED && a.g_min > (uint32_t)a.K && !a.values_only && !a.part_mode && !ctx->opt.rank_no_lean && rs_lean_setup(a, a.pb, rs_blocks, &lf))
-        hipLaunchKernelGGL(k_rank_scan_lean, dim3(rs_blocks), dim3(RL_THREADS), 0, st, a, lf);
+    {
+        // the scan's arguments travel through memory
+        FBG_TRY(fbg_reserve(ctx, ctx->kargs, sizeof(RankArgs)));
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->kargs.p, &a, sizeof(RankArgs), hipMemcpyHostToDevice, st));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));             // (a lives on this stack frame)
+        hipLaunchKernelGGL(k_rank_scan_lean, dim3(rs_blocks), dim3(RL_THREADS), 0, st, (const RankArgs *)ctx->kargs.p, lf);
+    }
     else
         RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
