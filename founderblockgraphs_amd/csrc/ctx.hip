@@ -175,7 +175,7 @@ static const OptKey g_opt_keys[] = {
     {"bp_min", &FbgOptions::bp_min}, {"record_scatter", &FbgOptions::record_scatter}, {"lcp_text", &FbgOptions::lcp_text},
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
-    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force}, {"msd_probe", &FbgOptions::msd_probe}, {"msd_xcd", &FbgOptions::msd_xcd}, {"msd_fuse", &FbgOptions::msd_fuse}, {"rank_no_lean", &FbgOptions::rank_no_lean},
+    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force}, {"msd_probe", &FbgOptions::msd_probe}, {"msd_xcd", &FbgOptions::msd_xcd}, {"rank_no_lean", &FbgOptions::rank_no_lean},
     {"span_scan", &FbgOptions::span_scan},
 };
 

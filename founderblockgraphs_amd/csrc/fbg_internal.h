@@ -37,7 +37,7 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0, msd_probe = 0, msd_xcd = -1, msd_fuse = -1, rank_no_lean = 0,
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0, msd_probe = 0, msd_xcd = -1, rank_no_lean = 0,
             span_scan = 0;
 };
 
@@ -122,11 +122,6 @@ struct fbg_ctx {
     uint64_t part_count = 0;   // owned slots (keys / vals arrays: FBG_PART_HALO + part_count + FBG_PART_HALO)
     uint64_t part_T = 0;       // candidates found by phase 1
     uint32_t part_gmin = 0;    // largest threshold any partition scanned with (0: none, nothing to verify)
-    // pass 3 of the MSD sort made the scan's lists (msd_sort.hip k_msd_finish_p<true>; consumed by fbg_rank_scan_try)
-    bool fz_valid = false;
-    uint32_t fz_nsub = 0, fz_tcap = 0, fz_ccap = 0, fz_dcap = 0;   // its regions: sub-buckets, tie heads / candidates / left-over slots of each
-    uint32_t fz_cap2 = 0;          // chunk capacity of the lists k_rank_scan_list makes of the left-over slots
-    uint64_t fz_ties = 0;          // slots that tie on the key (all of them counted)
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tie_list, big_groups, tmp, small, scalars;
@@ -208,13 +203,7 @@ int fbg_rank_part_runs(fbg_ctx *ctx, const uint8_t *d_blobs, uint32_t *d_gmax, i
 int fbg_rank_part_unfilled(fbg_ctx *ctx, uint64_t *unfilled);
 int fbg_rank_part_rescan(fbg_ctx *ctx);
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
-int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches, bool want_fused);   // msd_sort.hip
-struct RankArgs;
-int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, uint32_t nsub, uint32_t tcap, uint32_t ccap, uint32_t dcap,
-                          RankArgs *out, uint32_t **ties, uint32_t **cand, uint32_t **defer, uint32_t **cnt_t, uint32_t **cnt_c,
-                          uint32_t **cnt_d, unsigned long long **fcnt);                               // rank_scan.hip
-#define FBG_FUSE_MAX_RANGES 4096   // sub-buckets too large for the fused pass 3 (their slots are classified from global memory)
-#define MSD_SHARDS 64          // chunks of the lists the fused pass 3 of the MSD sort makes for the scan (one cursor each)
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip
 int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
                       uint64_t *count, int *ok, int *launches);                                       // msd_sort_pairs.hip                        // suffix_sort.hip
 int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches);                      // msd_sort_pairs.hip

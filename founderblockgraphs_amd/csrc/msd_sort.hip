@@ -21,7 +21,6 @@
 // rocPRIM instead (suffix_sort.hip).  Equal keys end up in position order.
 #include "fbg_internal.h"
 #include "msd_keys.h"
-#include "rank_common.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cmath>
@@ -33,7 +32,7 @@
 #define MSD_FN_THREADS 512
 #define MSD_FN_CAP 4096                        // slots per sub-bucket stretch (mean at 10^9 suffixes: 3815; the few that overflow: arena)
 #define MSD_FN_ITEMS (MSD_FN_CAP / MSD_FN_THREADS)
-#define MSD_FN_BITS 10
+#define MSD_FN_BITS 11
 #define MSD_FN_BINS (1 << MSD_FN_BITS)
 #define MSD_BIG_THREADS 1024
 #define MSD_BIG_CAP 16384                      // largest sub-bucket (k_msd_finish_big)
@@ -353,17 +352,34 @@ __device__ __forceinline__ void msd_finish_sort(uint64_t *buf, uint32_t *cnt, ui
         }
         __syncthreads();
     }
+    if (nbig) {
+        // the slots of the crowded bins go to their places now: nobody else reads those bins' stretches
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * THREADS;
+            if (j < have && cnt[(uint32_t)(w[r] >> fshift) & fmask] > MSD_BIG_BIN) buf[rk[r]] = w[r];
+        }
+        __syncthreads();
+    }
+    // Every slot counts the smaller slots of its bin -- taken in the order in which they lie in buf now, bin by bin: the lanes
+    // of a wave sit in the same few bins, read the same words (no bank conflicts: with the slots in arrival order those cost
+    // 45 % on top of the reads) and loop as often as the largest of their 30 bins has slots, not the largest of 64 bins
+    // scattered over the sub-bucket.
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
         if (j < have) {
-            const uint32_t bin = (uint32_t)(w[r] >> fshift) & fmask;
+            const uint64_t y = buf[j];
+            const uint32_t bin = (uint32_t)(y >> fshift) & fmask;
             const uint32_t b0 = loff[bin], c = cnt[bin];
-            if (nbig && c > MSD_BIG_BIN) continue;                // placed by its bin's histogram above
-            if (lowbits == 0 && c > MSD_BIG_BIN) { rk[r] = b0 + rk[r]; continue; }   // no key bits left: the bin's keys are equal
-            uint32_t smaller = 0;
-            for (uint32_t q = 0; q < c; q++) smaller += buf[b0 + q] < w[r] ? 1u : 0u;
-            rk[r] = b0 + smaller;
+            uint32_t at = j;                                     // a crowded bin: placed above, or (no key bits left) its keys are equal
+            if (!(c > MSD_BIG_BIN && (nbig || lowbits == 0))) {
+                uint32_t smaller = 0;
+                for (uint32_t q = 0; q < c; q++) smaller += buf[b0 + q] < y ? 1u : 0u;
+                at = b0 + smaller;
+            }
+            w[r] = y;
+            rk[r] = at;
         }
     }
     __syncthreads();
@@ -412,254 +428,6 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
                                                 fshift - a.pb, sub, biglist, &nbig_lds, a.probe);
 }
 
-// ---- pass 3 with the classification of the extension scan fused in ------------------------------------------------
-// With the sub-bucket sorted in LDS the workgroup also does what k_rank_scan (rank_scan.hip) does in a pass of its own
-// over the sorted slots when the threshold lies above K (rs_pick_threshold: g_min = K + 1; the caller checks afterwards
-// that this was the regime): only slots that tie on the key, share their column with a neighbour, sit next to a tie
-// group or lie in the 64 columns nearest a row end can matter.  What this kernel is short of is neither bandwidth nor
-// instruction slots but time: three workgroups per CU keep the LDS busy, a dependent LDS access takes several hundred
-// cycles, and a workgroup lives as long as its chain of dependent accesses and barriers (a first version that noted
-// group heads in an LDS list and worked them off after a barrier took 7.7 ms against 4.2 + 4.1 for the two kernels it
-// replaces: profiles/r04_fused_probe_v2_order.txt).  So the classification works from registers: a wave looks at 64
-// consecutive slots, a lane each -- all its slots are fetched from LDS at once --, the keys and symbols-left of the two
-// slots before and the three after by DPP shifts (lanes 2..60 are settled, consecutive waves overlap by five slots).  A
-// group of two is settled by its head's lane: "simple" (k_rank_scan's test: both with K symbols left, four different
-// columns around, no tie group next door) goes to the tie list, else both go to the candidates; a lane keeps what it
-// finds in registers and reserves its places once, at the end.  Everything else is rare and takes the general code
-// through a queue in LDS (rank_scan_slow, duplicates removed by a bitmap): outside neighbours that share a column with
-// the far member of a pair, groups of three and more with both neighbours, slots that share a column with a neighbour
-// or lie near a row end.  Slots whose neighbourhood lies in another sub-bucket go to a list that k_rank_scan_list works
-// off from global memory.  Lists: a fixed region per sub-bucket and list, no reservations in global memory.
-#define MSD_TCAP 1024                          // region of a sub-bucket: heads of simple tie groups, ...
-#define MSD_CCAP 512                           // ... candidates, ...
-#define MSD_DCAP 32                            // ... slots left to k_rank_scan_list (2 * RS_HALO at most)
-struct FuseArgs {
-    RankArgs ra;                               // geometry, text, column maxima (cand / ties of it unused)
-    uint32_t *ties, *cand, *defer;             // [nsub][MSD_TCAP], [nsub][MSD_CCAP], [nsub][MSD_DCAP] slots
-    uint32_t *cnt_t, *cnt_c, *cnt_d;           // [nsub] entries of the regions
-    unsigned long long *fcnt;                  // [1] slots that tie on the key, [2] != 0: a region overflowed
-    // x = fract(position / row length) in single precision is off by less than eps / 2, whatever the position: two slots of one
-    // column differ by less than eps (or by more than 1 - eps), a slot in the 64 columns nearest its row's end has x >= near_end
-    float inv_row_len, eps, near_end;
-};
-
-// lane l gets lane l + 1's / lane l - 1's value (beyond the wave: 0)
-__device__ __forceinline__ uint32_t msd_from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t msd_from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ uint64_t msd_from_next(uint64_t v) { return ((uint64_t)msd_from_next((uint32_t)(v >> 32)) << 32) | msd_from_next((uint32_t)v); }
-__device__ __forceinline__ uint64_t msd_from_prev(uint64_t v) { return ((uint64_t)msd_from_prev((uint32_t)(v >> 32)) << 32) | msd_from_prev((uint32_t)v); }
-
-// entries of the lanes in `mask` (wave-uniform) -> a staging list in LDS of capacity cap; *over = 1 when it is full
-__device__ __forceinline__ void msd_stage(unsigned long long mask, uint32_t *counter, uint16_t *list, uint32_t cap, uint32_t value,
-                                          uint32_t *over)
-{
-    if (!mask) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if ((mask >> lane) & 1ull) {
-        const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-        if (at < cap) list[at] = (uint16_t)value;
-        else *over = 1;
-    }
-}
-
-#define MSD_ST_Q 4064                          // queue for rank_scan_slow: room for every slot of a sub-bucket
-#define MSD_W_LIST 256                         // noted per wave: first members of tie groups (expected: 15), slots that may share a column with a neighbour
-#define MSD_EV 62                              // lanes 1 .. 62 of a wave are settled by it
-
-__global__ __launch_bounds__(MSD_FN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_msd_finish_fused(MsdArgs a, int fshift, uint32_t fmask, FuseArgs f)
-{
-    constexpr int WAVES = MSD_FN_THREADS / 64;
-    __shared__ uint64_t buf[MSD_FN_CAP];
-    __shared__ uint32_t cls[2 * MSD_FN_BINS];                   // bin counts | bin offsets; afterwards the queue and the deferred slots
-    __shared__ uint32_t sub[1 << MSD_LOW_BITS];                 // counts of a crowded bin; afterwards what the waves noted
-    static_assert(WAVES * MSD_W_LIST * 2 <= (1 << MSD_LOW_BITS) * 4 && (MSD_ST_Q + MSD_DCAP) * 2 <= 2 * MSD_FN_BINS * 4, "the lists fit the tables of the sort");
-    __shared__ uint32_t wsum[MSD_FN_THREADS / 64];
-    __shared__ uint16_t biglist[MSD_FN_CAP / MSD_BIG_BIN + 1];
-    __shared__ uint32_t nbig_lds;
-    __shared__ uint32_t s_n[4], s_ties, s_over;                 // entries: ties, candidates, deferred, queue
-    __shared__ uint32_t s_wl[WAVES];                            // entries noted by every wave
-    __shared__ uint32_t seen[MSD_FN_CAP / 32];                  // slots that have been in the queue
-    uint32_t *cnt = cls, *loff = cls + MSD_FN_BINS;
-    uint16_t *sq = reinterpret_cast<uint16_t *>(cls), *st_d = sq + MSD_ST_Q, *w_list = reinterpret_cast<uint16_t *>(sub);
-    constexpr int ITEMS = MSD_FN_ITEMS;
-    const uint32_t sb = blockIdx.x;
-    const uint32_t have = a.count2[sb];
-    if (have == 0 || have > MSD_FN_CAP) {                       // the larger ones: k_msd_finish_big, k_msd_defer_big
-        if (threadIdx.x == 0) { f.cnt_t[sb] = 0; f.cnt_c[sb] = 0; f.cnt_d[sb] = 0; }
-        return;
-    }
-    const uint64_t *in = a.buf2 + (uint64_t)sb * MSD_FN_CAP;
-    uint64_t w[ITEMS];
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
-        w[r] = j < have ? in[j] : ~0ull;
-    }
-    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
-    if (threadIdx.x == 4) { s_ties = 0; s_over = 0; }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + MSD_FN_CAP / 32) seen[threadIdx.x - 64] = 0;
-    msd_finish_sort<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
-    const uint64_t o = a.off[sb];
-    uint64_t *out = a.out + o;
-#pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * MSD_FN_THREADS;
-        if (j < have) out[j] = buf[j];
-    }
-    if (a.probe & 64) return;                                   // timing probes (option msd_probe = 2): sort and store only, ...
-    const RankArgs &ra = f.ra;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ihave = (int)have;
-    const uint32_t o32 = (uint32_t)o;
-    uint32_t *ties = f.ties + (size_t)sb * MSD_TCAP, *cand = f.cand + (size_t)sb * MSD_CCAP;
-    uint32_t over = 0;
-    auto enqueue = [&](bool want, uint32_t i) {                // (all lanes of the wave call)
-        bool fresh = false;
-        if (want) fresh = ((atomicOr(&seen[i >> 5], 1u << (i & 31)) >> (i & 31)) & 1u) == 0;
-        msd_stage(__ballot(fresh), &s_n[3], sq, MSD_ST_Q, i, &over);
-    };
-    // ---- every slot: a dozen instructions.  Does it tie with the next one; may it share its column with it, or lie near a row end:
-    //      (position / row length) in single precision says no for all but a few in a thousand, never wrongly (f.eps) ----
-    {
-        uint16_t *my_list = w_list + wv * MSD_W_LIST;
-        const int rounds = (ihave + MSD_EV * WAVES - 1) / (MSD_EV * WAVES);
-        uint32_t nl = 0, nties = 0;                             // (wave-uniform)
-        for (int q = 0; q < rounds; q++) {
-            const int j = (q * WAVES + wv) * MSD_EV - 1 + lane;
-            const bool inr = j >= 0 && j < ihave;
-            const uint64_t x = inr ? buf[j] : 0ull;
-            const uint64_t xn = (j + 1 >= 0 && j + 1 < ihave) ? buf[j + 1] : ~0ull;
-            const float fr = __builtin_amdgcn_fractf((float)((uint32_t)x & (uint32_t)ra.pmask) * f.inv_row_len);
-            const float d = fr - __uint_as_float(msd_from_next(__float_as_uint(fr)));
-            // bit l of a mask speaks of the slot of lane l (and the one after it)
-            const unsigned long long E = __ballot(((x ^ xn) >> ra.pb) == 0);               // ties with the next slot
-            const unsigned long long R1 = __ballot(fabsf(d) < f.eps || fabsf(d) > 1.0f - f.eps) & ~(1ull << 63);   // may share the next slot's column
-            // may lie in the 64 columns nearest the row end, or be a '#' (a fraction just below 1 may have been rounded up to 0)
-            const unsigned long long NE = __ballot(fr >= f.near_end || fr < f.eps);
-            const bool mine = inr && lane >= 1 && lane <= MSD_EV;
-            const unsigned long long D = __ballot(mine && (j < 3 || j + 3 >= ihave));      // a neighbour within 3 lies in another sub-bucket
-            const unsigned long long EV = __ballot(mine) & ~D;
-            const unsigned long long TIE = E | (E << 1);
-            // first member of its group -- or the first one this workgroup may look at (slot 3), when the group begins in the three
-            // slots that are left to k_rank_scan_list
-            const unsigned long long H = EV & ((E & ~(E << 1)) | ((E << 1) & __ballot(j == 3)));
-            const unsigned long long O = EV & ~TIE & (R1 | (R1 << 1) | NE);
-            const unsigned long long L = H | O;
-            nties += (uint32_t)__popcll(TIE & EV);
-            if ((L >> lane) & 1ull) {
-                const uint32_t at = nl + (uint32_t)__popcll(L & ((1ull << lane) - 1));
-                if (at < MSD_W_LIST) my_list[at] = (uint16_t)((uint32_t)j | (((O >> lane) & 1ull) ? 0x8000u : 0u)); else over = 1;
-            }
-            nl += (uint32_t)__popcll(L);
-            msd_stage(D, &s_n[2], st_d, MSD_DCAP, (uint32_t)j, &over);
-        }
-        if (lane == 0) {
-            s_wl[wv] = min(nl, (uint32_t)MSD_W_LIST);
-            if (nties) atomicAdd(&s_ties, nties);
-        }
-    }
-    __syncthreads();
-    if (a.probe & 128) return;                                  // ... the pass over all slots as well
-    // ---- the noted slots, a lane each ----
-    {
-        uint32_t wl[WAVES], tot = 0;
-#pragma unroll
-        for (int q = 0; q < WAVES; q++) { wl[q] = s_wl[q]; tot += wl[q]; }
-        for (uint32_t e0 = 0; e0 < tot; e0 += MSD_FN_THREADS) {
-            if (e0 + (threadIdx.x & ~63u) >= tot) break;       // wave-uniform
-            uint32_t e = e0 + threadIdx.x;
-            const bool on = e < tot;
-            uint32_t src = 0;
-#pragma unroll
-            for (int q = 0; q < WAVES; q++) { if (on && e >= wl[q] && src == (uint32_t)q) { e -= wl[q]; src = q + 1; } }
-            const uint32_t v = on ? w_list[src * MSD_W_LIST + e] : 3u;
-            const int i = (int)(v & 0xfffu);
-            const bool is_odd = on && (v & 0x8000u);
-            // slots i - 2 .. i + 3 (3 <= i, i + 3 < have): keys k[0..5], symbols left r[0..5]; slot i is k[2]
-            uint64_t k[6];
-            uint32_t r[6];
-#pragma unroll
-            for (int dd = 0; dd < 6; dd++) {
-                const uint64_t x = buf[i - 2 + dd];
-                k[dd] = x >> ra.pb;
-                r[dd] = rs_rem<FBG_SLOTS_PACKED>(ra, x & ra.pmask);
-            }
-            // a slot that does not tie: the general code if it does share its column with a neighbour or lies near a row end
-            enqueue(is_odd && r[2] != 0 && (r[2] == r[1] || r[2] == r[3] || r[2] <= 64), (uint32_t)i);
-            const bool head = on && !is_odd;
-            // a group of two, both members this workgroup's to settle (a group that reaches into the first or last three slots
-            // of the sub-bucket is classified slot by slot instead, like those)
-            const bool pair = head && k[1] != k[2] && k[2] == k[3] && k[3] != k[4] && i + 4 < ihave;
-            bool t_simple = false, c_pair = false, q_b = false, q_a = false;
-            if (pair) {
-                t_simple = r[2] >= (uint32_t)ra.K && r[3] >= (uint32_t)ra.K && r[2] != r[3] && k[0] != k[1] && r[1] != r[2] && r[1] != r[3] &&
-                           k[4] != k[5] && r[4] != r[2] && r[4] != r[3];
-                c_pair = !t_simple;
-                // a slot next to the pair that shares its column with the pair's far member may end up next to it (a run); with the
-                // near member: the pass over all slots has noted it
-                q_b = k[0] != k[1] && r[1] != 0 && r[1] == r[3] && i - 1 >= 3;
-                q_a = k[4] != k[5] && r[4] != 0 && r[4] == r[2] && i + 2 + 3 < ihave;
-            }
-            if (t_simple) { const uint32_t at = atomicAdd(&s_n[0], 1u); if (at < MSD_TCAP) ties[at] = o32 + (uint32_t)i; else over = 1; }
-            if (c_pair) {
-                const uint32_t at = atomicAdd(&s_n[1], 2u);
-                if (at + 1 < MSD_CCAP) { cand[at] = o32 + (uint32_t)i; cand[at + 1] = o32 + (uint32_t)i + 1; } else over = 1;
-            }
-            if (__ballot(q_b || q_a)) { enqueue(q_b, (uint32_t)(i - 1)); enqueue(q_a, (uint32_t)(i + 2)); }
-            const bool lng = head && !pair;
-            if (__ballot(lng)) {
-                // a longer group: every member and the slots on either side take the general code
-                int m = i, end = i;
-                if (lng) { while (end + 1 < ihave && (buf[end + 1] >> ra.pb) == k[2]) end++; }
-                enqueue(lng && k[1] != k[2] && k[0] != k[1] && i - 1 >= 3, (uint32_t)(i - 1));
-                enqueue(lng && end + 1 + 3 < ihave && (buf[end + 2] >> ra.pb) != (buf[end + 1] >> ra.pb), (uint32_t)(end + 1));
-                for (;;) {
-                    const bool more = lng && m <= end && m + 3 < ihave;   // (the last three slots of the sub-bucket are deferred already)
-                    if (!__ballot(more)) break;
-                    enqueue(more, (uint32_t)m);
-                    m++;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- the queue: rank_scan_slow on the sorted sub-bucket; slots within RS_HALO of its ends are left to k_rank_scan_list ----
-    {
-        const uint32_t qn = min(s_n[3], (uint32_t)MSD_ST_Q);
-        const RsWordView view{buf, &ra, 0, ihave};
-        for (uint32_t q0 = 0; q0 < qn; q0 += MSD_FN_THREADS) {
-            if (q0 + (threadIdx.x & ~63u) >= qn) break;        // wave-uniform
-            const uint32_t e = q0 + threadIdx.x;
-            bool want_cand = false, want_tie = false, far = false;
-            uint32_t i = 0;
-            if (e < qn) {
-                i = sq[e];
-                far = (int)i < RS_HALO || (int)i + RS_HALO >= ihave;
-                if (!far) rank_scan_slow(ra, view, (int)i, 0, ihave, o + i, want_cand, want_tie);
-            }
-            if (want_tie) { const uint32_t at = atomicAdd(&s_n[0], 1u); if (at < MSD_TCAP) ties[at] = o32 + i; else over = 1; }
-            if (want_cand) { const uint32_t at = atomicAdd(&s_n[1], 1u); if (at < MSD_CCAP) cand[at] = o32 + i; else over = 1; }
-            msd_stage(__ballot(far), &s_n[2], st_d, MSD_DCAP, i, &over);
-        }
-        if (qn) __syncthreads();                                // (uniform)
-    }
-    if (over) s_over = 1;
-    {
-        const uint32_t nd = min(s_n[2], (uint32_t)MSD_DCAP);
-        if (threadIdx.x < nd) f.defer[(size_t)sb * MSD_DCAP + threadIdx.x] = o32 + st_d[threadIdx.x];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        f.cnt_t[sb] = min(s_n[0], (uint32_t)MSD_TCAP); f.cnt_c[sb] = min(s_n[1], (uint32_t)MSD_CCAP); f.cnt_d[sb] = min(s_n[2], (uint32_t)MSD_DCAP);
-        if (s_ties) atomicAdd(f.fcnt + 1, (unsigned long long)s_ties);
-        if (s_over || s_n[0] > MSD_TCAP || s_n[1] > MSD_CCAP || s_n[2] > MSD_DCAP || s_n[3] > MSD_ST_Q) f.fcnt[2] = 1;
-    }
-}
-
 // sub-buckets whose stretch overflowed: the arena (sorted by sub-bucket) holds the slots beyond MSD_FN_CAP.  One
 // workgroup per arena entry; the first entry of a sub-bucket's run does the work.
 __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, const uint32_t *__restrict__ sb_sorted,
@@ -682,27 +450,12 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
                                                   a.out + a.off[sb], fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
 }
 
-// FUSED: the slots of the sub-buckets k_msd_finish_big sorted go to k_rank_scan_list, all of them: as (first slot, count) ranges
-// (same grid; ranges[0] counts them, ranges[2 + 2 e], ranges[3 + 2 e] = range e)
-__global__ void k_msd_defer_big(MsdArgs a, const uint32_t *__restrict__ sb_sorted, uint32_t entries, unsigned long long *__restrict__ ranges,
-                                uint32_t max_ranges, unsigned long long *__restrict__ fcnt)
-{
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= entries) return;
-    const uint32_t sb = sb_sorted[e];
-    if (e > 0 && sb_sorted[e - 1] == sb) return;
-    const unsigned long long at = atomicAdd(ranges, 1ull);
-    if (at < max_ranges) { ranges[2 + 2 * at] = a.off[sb]; ranges[3 + 2 * at] = a.count2[sb]; }
-    else fcnt[2] = 1;
-}
-
 // Sorts the packed slots of the current text by their key bits.  *ok = 0: a capacity was exceeded (keys spread
 // unevenly) or the geometry does not suit this sort -- nothing usable was produced.  On success *sorted points at
 // the N sorted words (inside ctx->keysA).
-int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches, bool want_fused)
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches)
 {
     *ok = 0;
-    ctx->fz_valid = false;
     const uint64_t N = ctx->N;
     const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
     const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);   // tests lower it
@@ -744,8 +497,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
     a.probe = 0;
-    const bool probing = ctx->opt.msd_probe == 1;              // every kernel runs its probe variants first (a profiler reads their times)
-    const bool fprobing = ctx->opt.msd_probe == 2;             // ... the fused pass 3 does (its lists are reset afterwards)
+    const bool probing = ctx->opt.msd_probe != 0;              // every kernel runs its probe variants first (a profiler reads their times)
     if (probing)
         for (int v : {1, 16}) {
             a.probe = v;
@@ -793,36 +545,9 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
             hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
             a.probe = 0;
         }
-    // pass 3, with the scan's classification fused in (option msd_fuse, default on) when the caller can use it
-    const int fuse = ctx->opt.msd_fuse < 0 ? 0 : (int)ctx->opt.msd_fuse;
-    // (fractions of the row length in single precision must tell columns apart: rows of a thousand columns and more)
-    const double row_len = (double)(ctx->n + 1);
-    const double fz_delta = (ldexp(1.0, g.pb - 24) + 2.0) / row_len + ldexp(1.0, g.pb - 21) / row_len + 1e-6;
-    const bool fused = fuse != 0 && want_fused && !probing && 2.0 * fz_delta < 0.01 && g.pb <= 32;
-    FuseArgs fz;
-    memset(&fz, 0, sizeof(fz));
-    if (fused) {
-        FBG_TRY(fbg_rank_fuse_prepare(ctx, g, a.out, (uint32_t)nsub, MSD_TCAP, MSD_CCAP, MSD_DCAP, &fz.ra, &fz.ties, &fz.cand, &fz.defer, &fz.cnt_t,
-                                      &fz.cnt_c, &fz.cnt_d, &fz.fcnt));
-        fz.inv_row_len = (float)(1.0 / row_len);
-        fz.eps = (float)(2.0 * fz_delta);
-        fz.near_end = (float)(1.0 - 65.0 / row_len - fz_delta);
-        if (fprobing) {
-            for (int v : {64, 128}) {
-                a.probe = v;
-                hipLaunchKernelGGL(k_msd_finish_fused, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
-                a.probe = 0;
-            }
-            FBG_HIP_TRY(ctx, hipMemsetAsync(fz.fcnt, 0, 3 * sizeof(unsigned long long), st));
-        }
-        hipLaunchKernelGGL(k_msd_finish_fused, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask, fz);
-    } else {
-        hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
-    }
+    hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
     unsigned long long h2[2] = {0, 0};
-    unsigned long long hf[3] = {0, 0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
-    if (fused) FBG_HIP_TRY(ctx, hipMemcpyAsync(hf, fz.fcnt, 24, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 4;
     if (h2[0] != 0) return FBG_OK;
@@ -840,10 +565,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
         e = rocprim::radix_sort_pairs(ctx->tmp.p, have, a.arena_sb, sb_sorted, a.arena_w, w_sorted, (size_t)entries, 0u, 32u, st);
         if (e != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim radix_sort_pairs: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(k_msd_finish_big, dim3(entries), dim3(MSD_BIG_THREADS), 0, st, a, sb_sorted, w_sorted, entries, fshift, fmask);
-        if (fused) hipLaunchKernelGGL(k_msd_defer_big, dim3(fbg_blocks(entries, 256)), dim3(256), 0, st, a, sb_sorted, entries, ctx->ps_d.as<unsigned long long>(),
-                                      (uint32_t)FBG_FUSE_MAX_RANGES, fz.fcnt);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
-        if (fused) FBG_HIP_TRY(ctx, hipMemcpyAsync(hf, fz.fcnt, 24, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 2;
         if (h2[0] != 0) return FBG_OK;
@@ -851,10 +573,5 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipGetLastError());
     *sorted = ctx->keysA.as<uint64_t>();
     *ok = 1;
-    if (fused && hf[2] == 0) {
-        // the scan's lists are made (rank_scan.hip takes it from here); hf[1]: the slots that tie on the key
-        ctx->fz_valid = true;
-        ctx->fz_ties = hf[1];
-    }
     return FBG_OK;
 }

@@ -436,89 +436,15 @@ static bool rs_lean_setup(const RankArgs &a, int pb, unsigned blocks, LeanArgs *
     return 2.0 * delta < 0.01 && pb <= 31 && a.own_hi < (1ull << 31);
 }
 
-// The slots the fused pass 3 of the MSD sort (msd_sort.hip, k_msd_finish_fused) could not classify from its sub-bucket
-// alone -- up to dcap of every sub-bucket (regions of `defer`, counts in cnt_d), and the sub-buckets too large for that
-// kernel in full (ranges[0] ranges: first slot ranges[2 + 2 e], slots ranges[3 + 2 e]) --: rank_scan_slow on the RS_HALO
-// slots either side of each, read from global memory.  What it finds goes to lists of MSD_SHARDS chunks with a cursor
-// each (cur[(list * MSD_SHARDS + shard) * 16]: 0 ties, 1 candidates), a reservation per wave.
-#define RS_LIST_BLOCKS 2048
-__device__ __forceinline__ void rs_append_chunk(bool want, unsigned long long *cursor, uint32_t *chunk, uint32_t cap, uint32_t value,
-                                                unsigned long long *over)
-{
-    const unsigned long long mask = __ballot(want);
-    if (!mask) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (want) {
-        const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1));
-        if (at < cap) chunk[at] = value;
-        else *over = 1;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_rank_scan_list(RankArgs a, const uint32_t *__restrict__ defer, const uint32_t *__restrict__ cnt_d,
-                                                        uint32_t nsub, uint32_t dcap, const unsigned long long *__restrict__ ranges,
-                                                        uint32_t max_ranges, unsigned long long *__restrict__ cur,
-                                                        unsigned long long *__restrict__ over)
-{
-    const uint32_t shard = blockIdx.x & (MSD_SHARDS - 1);
-    uint32_t *cand = a.cand + (size_t)shard * a.region, *ties = a.ties + (size_t)shard * a.tie_region;
-    unsigned long long *cur_t = cur + ((size_t)0 * MSD_SHARDS + shard) * 16, *cur_c = cur + ((size_t)1 * MSD_SHARDS + shard) * 16;
-    auto look = [&](bool on, uint64_t k) {                     // (all lanes of the wave call)
-        bool want_cand = false, want_tie = false;
-        if (on) {
-            const int64_t base = (int64_t)k - RS_HALO;                     // slot of window index 0
-            const int lo_i = (int)max((int64_t)0, (int64_t)a.own_lo - base);
-            const int hi_i = (int)min((int64_t)(2 * RS_HALO + 1), (int64_t)a.own_hi - base);
-            const RsWordView view{a.keys + base, &a, lo_i, hi_i};
-            rank_scan_slow(a, view, RS_HALO, lo_i, hi_i, k, want_cand, want_tie);
-        }
-        rs_append_chunk(want_cand, cur_c, cand, a.region, (uint32_t)k, over);
-        rs_append_chunk(want_tie, cur_t, ties, a.tie_region, (uint32_t)k, over);
-    };
-    const uint64_t virt = (uint64_t)nsub * dcap;               // entry e of sub-bucket sb: sb * dcap + e
-    for (uint64_t v0 = (uint64_t)blockIdx.x * 256; v0 < virt; v0 += (uint64_t)gridDim.x * 256) {
-        const uint64_t v = v0 + threadIdx.x;
-        const bool on = v < virt && (uint32_t)(v % dcap) < cnt_d[v / dcap];
-        look(on, on ? defer[v] : 0u);
-    }
-    const uint32_t nr = (uint32_t)min(ranges[0], (unsigned long long)max_ranges);
-    for (uint32_t r = 0; r < nr; r++) {
-        const uint64_t first = ranges[2 + 2 * r], n = ranges[3 + 2 * r];
-        for (uint64_t e0 = (uint64_t)blockIdx.x * 256; e0 < n; e0 += (uint64_t)gridDim.x * 256) {
-            const uint64_t e = e0 + threadIdx.x;
-            look(e < n, first + e);
-        }
-    }
-}
-
-// cursors of the chunks -> the per-region counts the kernels below read (a chunk is a region)
-__global__ void k_fuse_counts(const unsigned long long *__restrict__ cur, uint32_t *__restrict__ tie_count, uint32_t *__restrict__ blk_count)
-{
-    const uint32_t s = threadIdx.x;
-    if (s < MSD_SHARDS) {
-        tie_count[s] = (uint32_t)min(cur[((size_t)0 * MSD_SHARDS + s) * 16], 0xffffffffull);
-        blk_count[s] = (uint32_t)min(cur[((size_t)1 * MSD_SHARDS + s) * 16], 0xffffffffull);
-    }
-    if (s == MSD_SHARDS) { tie_count[s] = 0; blk_count[s] = 0; }
-}
-
 // the small tie groups k_rank_scan set aside (same grid: every workgroup works off its own region).  No member
 // shares a column with a neighbour, so each is a run of its own and its extension is 1 + its longest match with
 // any other suffix -- which is another member of the group (they agree on K symbols, nobody else does).
-template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a, uint32_t split, uint32_t regions)
+template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a)
 {
-    // `split` workgroups share a region; split = 0: small regions (those of the fused pass 3 of the MSD sort), a wave each
-    const uint32_t reg = split ? blockIdx.x / split : blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
-    if (reg >= regions) return;
-    const uint32_t have = a.tie_count[reg];
-    if (have > a.tie_region) { if ((threadIdx.x & 63) == 0) a.counters[1] = 1; return; }
-    const uint32_t first = split ? (blockIdx.x % split) * blockDim.x + threadIdx.x : (threadIdx.x & 63), step = split ? split * blockDim.x : 64u;
-    for (uint32_t e = first; e < have; e += step) {
-        const uint64_t h = a.ties[(size_t)reg * a.tie_region + e];
+    const uint32_t have = a.tie_count[blockIdx.x];
+    if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
+    for (uint32_t e = threadIdx.x; e < have; e += blockDim.x) {
+        const uint64_t h = a.ties[(size_t)blockIdx.x * a.tie_region + e];
         // the RS_TG slots from the head on, all loads at once; the group ends where the key changes
         uint64_t key[RS_TG], pos[RS_TG];
         uint32_t best[RS_TG];
@@ -613,14 +539,10 @@ __global__ void k_count_unfilled(const uint32_t *__restrict__ gmax, uint64_t n, 
 
 // candidate regions of the workgroups -> one contiguous list (offsets = exclusive scan of the counts)
 __global__ void k_cand_compact(const uint32_t *__restrict__ regions, const uint32_t *__restrict__ counts,
-                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out, uint32_t split, uint32_t nreg)
+                               const uint32_t *__restrict__ offsets, uint32_t region, uint32_t *__restrict__ out)
 {
-    // `split` workgroups share a region; split = 0: small regions, a wave each
-    const uint32_t reg = split ? blockIdx.x / split : blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
-    if (reg >= nreg) return;
-    const uint32_t c = counts[reg] < region ? counts[reg] : region, o = offsets[reg];
-    const uint32_t first = split ? (blockIdx.x % split) * blockDim.x + threadIdx.x : (threadIdx.x & 63), step = split ? split * blockDim.x : 64u;
-    for (uint32_t i = first; i < c; i += step) out[o + i] = regions[(size_t)reg * region + i];
+    const uint32_t c = counts[blockIdx.x] < region ? counts[blockIdx.x] : region, o = offsets[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) out[o + i] = regions[(size_t)blockIdx.x * region + i];
 }
 
 // a slot whose key equals its successor's but not its predecessor's heads a tie group: put the group in text
@@ -941,10 +863,10 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
         RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
     if (ctx->opt.no_aux_stream) {
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a, 1u, rs_blocks);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
     } else {
         FBG_TRY(rs_fork(ctx));
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a, 1u, rs_blocks);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a);
     }
     *launches += 2;
     // from here on k_tie_simple may be running on the aux stream: an error return joins it first, so that no caller
@@ -970,69 +892,7 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
             // regions are in SA order already (workgroup b owns chunks b, b+G, ...: not contiguous) -> compact, then sort
             FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
             uint32_t *flat = ctx->dp_e.as<uint32_t>();
-            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat, 1u, rs_blocks);
-            FBG_TRY(rs_order_candidates(ctx, a, layout, T, launches));
-        }
-        return FBG_OK;
-    }();
-    if (rc_rest != FBG_OK) { (void)rs_join(ctx); return rc_rest; }
-    return FBG_OK;
-}
-
-// The same when pass 3 of the MSD sort has made the lists (msd_sort.hip, k_msd_finish_fused; fbg_rank_fuse_prepare set the
-// buffers up): a region of tie heads and one of candidates per sub-bucket.  The slots that kernel left over are classified now,
-// into lists of MSD_SHARDS chunks; then both pairs of lists are worked off as above.
-static int rs_classify_premade(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, int *launches)
-{
-    hipStream_t st = ctx->stream;
-    const uint32_t nsub = ctx->fz_nsub;
-    RankArgs a1 = a, a2 = a;                                    // the lists of pass 3 / of k_rank_scan_list
-    a1.cand = ctx->list.as<uint32_t>(); a1.blk_count = ctx->ps_b.as<uint32_t>(); a1.region = ctx->fz_ccap;
-    a1.ties = ctx->tie_list.as<uint32_t>(); a1.tie_count = ctx->ps_a.as<uint32_t>(); a1.tie_region = ctx->fz_tcap;
-    const uint32_t cap2 = ctx->fz_cap2;
-    a2.cand = ctx->ps_h.as<uint32_t>(); a2.region = cap2;
-    a2.ties = ctx->ps_g.as<uint32_t>(); a2.tie_region = cap2;
-    uint32_t *counts2 = ctx->dp_c.as<uint32_t>();              // [0, 65) candidates, [80, 145) ties of the chunks
-    a2.blk_count = counts2; a2.tie_count = counts2 + 80;
-    unsigned long long *cur = ctx->ps_f.as<unsigned long long>();
-    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
-    hipLaunchKernelGGL(k_rank_scan_list, dim3(RS_LIST_BLOCKS), dim3(256), 0, st, a2, ctx->ps_c.as<uint32_t>(), ctx->ps_e.as<uint32_t>(), nsub, ctx->fz_dcap,
-                       ctx->ps_d.as<unsigned long long>(), (uint32_t)FBG_FUSE_MAX_RANGES, cur, a.counters + 1);
-    hipLaunchKernelGGL(k_fuse_counts, dim3(1), dim3(128), 0, st, cur, a2.tie_count, a2.blk_count);
-    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 2));
-    {
-        hipStream_t ts = st;
-        if (!ctx->opt.no_aux_stream) { FBG_TRY(rs_fork(ctx)); ts = ctx->aux; }
-        RS_LAUNCH(k_tie_simple, layout, dim3(fbg_blocks(nsub, 4)), dim3(256), ts, a1, 0u, nsub);
-        RS_LAUNCH(k_tie_simple, layout, dim3(MSD_SHARDS * 4), dim3(256), ts, a2, 4u, (uint32_t)MSD_SHARDS);
-    }
-    *launches += 2;
-    const int rc_rest = [&]() -> int {
-        uint32_t *offs1 = ctx->dp_d.as<uint32_t>(), *offs2 = counts2 + 160;
-        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::exclusive_scan(tmp, bytes, a1.blk_count, offs1, 0u, (size_t)(nsub + 1), rocprim::plus<uint32_t>(), st);
-        }));
-        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::exclusive_scan(tmp, bytes, a2.blk_count, offs2, 0u, (size_t)(MSD_SHARDS + 1), rocprim::plus<uint32_t>(), st);
-        }));
-        uint32_t *d_max = reinterpret_cast<uint32_t *>(a.counters + 6);
-        FBG_TRY(rs_with_tmp(ctx, [&](void *tmp, size_t &bytes) {
-            return rocprim::reduce(tmp, bytes, a2.blk_count, d_max, 0u, (size_t)MSD_SHARDS, rocprim::maximum<uint32_t>(), st);
-        }));
-        uint32_t tot1 = 0, tot2 = 0, mx = 0;
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot1, offs1 + nsub, 4, hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(&tot2, offs2 + MSD_SHARDS, 4, hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        const uint64_t T = (uint64_t)tot1 + tot2;
-        *T_out = T;
-        if (mx > cap2 || T >= (1ull << 32)) { *T_out = ~0ull; return rs_join(ctx); }
-        if (T > 0) {
-            FBG_TRY(fbg_reserve(ctx, ctx->dp_e, T * 4));
-            uint32_t *flat = ctx->dp_e.as<uint32_t>();
-            hipLaunchKernelGGL(k_cand_compact, dim3(fbg_blocks(nsub, 4)), dim3(256), 0, st, a1.cand, a1.blk_count, offs1, a1.region, flat, 0u, nsub);
-            hipLaunchKernelGGL(k_cand_compact, dim3(MSD_SHARDS * 4), dim3(256), 0, st, a2.cand, a2.blk_count, offs2, a2.region, flat + tot1, 4u,
-                               (uint32_t)MSD_SHARDS);
+            hipLaunchKernelGGL(k_cand_compact, dim3(rs_blocks), dim3(256), 0, st, a.cand, d_counts, d_offs, region, flat);
             FBG_TRY(rs_order_candidates(ctx, a, layout, T, launches));
         }
         return FBG_OK;
@@ -1077,50 +937,6 @@ static int rs_pick_threshold(fbg_ctx *ctx, RankArgs &a, const uint64_t *keys, ui
     return FBG_OK;
 }
 
-// Everything k_msd_finish_fused (msd_sort.hip) needs to make the lists of the scan while it sorts: the arguments of the scan
-// for the packed slots at `keys` with the threshold above K, column maxima and counters zeroed, a region of tcap tie heads,
-// ccap candidates and dcap left-over slots for each of the nsub sub-buckets with their counts, and what k_rank_scan_list
-// needs afterwards (cursors and chunks of its own lists, the ranges of the oversized sub-buckets).
-int fbg_rank_fuse_prepare(fbg_ctx *ctx, const KeyGeom &g, uint64_t *keys, uint32_t nsub, uint32_t tcap, uint32_t ccap, uint32_t dcap,
-                          RankArgs *out, uint32_t **ties, uint32_t **cand, uint32_t **defer, uint32_t **cnt_t, uint32_t **cnt_c,
-                          uint32_t **cnt_d, unsigned long long **fcnt)
-{
-    const uint64_t N = ctx->N, n = ctx->n;
-    hipStream_t st = ctx->stream;
-    FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
-    unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
-    FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
-    FBG_TRY(fbg_reserve(ctx, ctx->big_groups, RS_BIG_GROUPS * 8));
-    RankArgs a;
-    rs_args_init(ctx, a, keys, nullptr, N, FBG_SLOTS_PACKED, g.pb, g.b, g.key_bits, g.K);
-    a.g_min = (uint32_t)g.K + 1;
-    FBG_TRY(fbg_reserve(ctx, ctx->tie_list, (size_t)nsub * tcap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->list, (size_t)nsub * ccap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_c, (size_t)nsub * dcap * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_a, (size_t)(nsub + 1) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_b, (size_t)(nsub + 1) * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_e, (size_t)(nsub + 1) * 4));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_b.as<uint32_t>() + nsub, 0, 4, st));           // (the scan of the counts reads nsub + 1 of them)
-    // k_rank_scan_list: the left-over slots (2 * RS_HALO of every sub-bucket at most, the oversized sub-buckets in full) may all
-    // turn out candidates
-    const uint32_t cap2 = (uint32_t)(((uint64_t)nsub * dcap + (1u << 21)) / MSD_SHARDS + 1024);
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_g, (size_t)MSD_SHARDS * cap2 * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)MSD_SHARDS * cap2 * 4));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_f, (size_t)2 * MSD_SHARDS * 16 * 8));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_f.p, 0, (size_t)2 * MSD_SHARDS * 16 * 8, st));
-    FBG_TRY(fbg_reserve(ctx, ctx->ps_d, (size_t)(2 + 2 * FBG_FUSE_MAX_RANGES) * 8));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->ps_d.p, 0, 16, st));
-    FBG_TRY(fbg_reserve(ctx, ctx->dp_c, 256 * 4));
-    *ties = ctx->tie_list.as<uint32_t>(); *cand = ctx->list.as<uint32_t>(); *defer = ctx->ps_c.as<uint32_t>();
-    *cnt_t = ctx->ps_a.as<uint32_t>(); *cnt_c = ctx->ps_b.as<uint32_t>(); *cnt_d = ctx->ps_e.as<uint32_t>();
-    *fcnt = ctx->scalars.as<unsigned long long>() + 116;
-    FBG_HIP_TRY(ctx, hipMemsetAsync(*fcnt, 0, 3 * sizeof(unsigned long long), st));
-    ctx->fz_nsub = nsub; ctx->fz_tcap = tcap; ctx->fz_ccap = ccap; ctx->fz_dcap = dcap; ctx->fz_cap2 = cap2;
-    *out = a;
-    return FBG_OK;
-}
-
 // Called by fbg_suffix_sort right after the round-0 sort of the compact keys.  *done = 1 when the rank-order scan
 // covered the whole input (ctx->ranked set); 0 = continue with the record path.
 int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &geom, int *done)
@@ -1134,31 +950,16 @@ int fbg_rank_scan_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeo
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANKSCAN));
     unsigned long long *cnt = ctx->scalars.as<unsigned long long>() + 32;
     int launches = 0;
-    // Pass 3 of the MSD sort has classified the slots already (msd_sort.hip, k_msd_finish_p<true>) and counted the slots that
-    // tie on the key -- all of them, where rs_pick_threshold looks at a sample.  Its lists stand if the regime is the one
-    // it assumed: so many ties in every column that nothing else can be a column maximum (g_min = K + 1).
-    bool premade = false;
-    if (ctx->fz_valid) {
-        ctx->fz_valid = false;
-        if (ctx->fz_ties * 4 > N) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);   // similar rows: not for this scan
-        premade = layout == FBG_SLOTS_PACKED && !ctx->opt.rank_no_threshold && N > (1u << 22) &&
-                  (double)ctx->fz_ties / (double)N * (double)ctx->m >= 32.0;
-    }
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));             // (before rs_args_init reads the pointer)
     RankArgs a;
     rs_args_init(ctx, a, keys, vals, N, layout, geom.pb, geom.b, geom.key_bits, geom.K);
     uint64_t T = 0;
-    if (premade) {
-        a.g_min = (uint32_t)geom.K + 1;
-    } else {
-        FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
-        FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
-        int reject = 0;
-        FBG_TRY(rs_pick_threshold(ctx, a, keys, N, geom, &reject, &launches));
-        if (reject) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
-    }
-    if (premade) FBG_TRY(rs_classify_premade(ctx, a, layout, &T, &launches));
-    else FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), st));
+    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->gmax.p, 0, (n + 1) * 4, st));
+    int reject = 0;
+    FBG_TRY(rs_pick_threshold(ctx, a, keys, N, geom, &reject, &launches));
+    if (reject) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);
+    FBG_TRY(rs_classify(ctx, a, layout, &T, &launches));
     if (T == ~0ull) return fbg_stage_end(ctx, FBG_STAGE_RANKSCAN, launches);      // a region overflowed: record path
     if (T > 0) {
         RS_LAUNCH(k_runs, layout, dim3(fbg_blocks(T, 64)), dim3(64), st, a, T);

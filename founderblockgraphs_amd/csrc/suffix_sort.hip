@@ -848,7 +848,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
         // its optimistic bucket capacities do not hold, pack and sort with rocPRIM's onesweep
         uint64_t *sorted = nullptr;
         int msd_ok = 0;
-        FBG_TRY(fbg_msd_sort(ctx, g, &sorted, &msd_ok, &launches, !similar && ctx->opt.pure_scan != 1));
+        FBG_TRY(fbg_msd_sort(ctx, g, &sorted, &msd_ok, &launches));
         if (!msd_ok) {
             FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
             FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));

@@ -91,9 +91,6 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *                      (scripts/gpu_trace_order.sh); results unchanged
  *   rank_no_lean       1: the rank-order scan with k_rank_scan also where its lean form (k_rank_scan_lean: packed slots, threshold
  *                      above the key length) applies; results unchanged
- *   msd_fuse           pass 3 of the MSD sort (-1 = 3): bit 0 workgroups that stay and prefetch the next sub-bucket, bit 1 the
- *                      classification of the rank-order scan done on the sorted sub-bucket in LDS (no pass of its own over
- *                      the sorted slots); 0: one workgroup per sub-bucket and k_rank_scan, as in rounds 1-3; results unchanged
  *   msd_xcd            which passes of the MSD sort place their writes by XCD (-1 = 3): bit 0 pass 2 (the tiles of a bucket
  *                      go to the workgroups of one XCD), bit 1 pass 1 (a stretch per bucket and XCD); 0: neither (the
  *                      layout of rounds 1-3); results unchanged
