@@ -39,6 +39,8 @@ struct RankArgs {
     uint32_t *ties;            // heads of the small tie groups, same per-workgroup regions
     uint32_t *tie_count;
     uint32_t tie_region;
+    uint2 *pairs;              // k_rank_scan_lean: the two text positions of every simple tied pair, same per-workgroup regions (k_tie_pairs)
+    uint32_t *pair_count;
     uint32_t *pm;              // scratch parallel to cand: prefix minima of the forward walk
     uint32_t *big;             // tie groups too long for one thread: (head slot, size) pairs, counters[5] of them
     unsigned long long *counters;   // [1] fallback flag
@@ -262,7 +264,7 @@ static inline void rs_args_init(fbg_ctx *ctx, RankArgs &a, uint64_t *keys, uint3
     a.b = b; a.key_bits = key_bits; a.K = K; a.reversed = ctx->reversed;
     a.gmax = ctx->gmax.as<uint32_t>();
     a.cand = nullptr; a.pm = nullptr; a.blk_count = nullptr; a.region = 0;
-    a.ties = nullptr; a.tie_count = nullptr; a.tie_region = 0;
+    a.ties = nullptr; a.tie_count = nullptr; a.tie_region = 0; a.pairs = nullptr; a.pair_count = nullptr;
     a.big = ctx->big_groups.as<uint32_t>();
     a.counters = ctx->scalars.as<unsigned long long>() + 32;
     a.g_min = 0;

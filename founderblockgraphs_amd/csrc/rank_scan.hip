@@ -300,12 +300,14 @@ __device__ __forceinline__ uint32_t rl_lanes_below(unsigned long long m)      //
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// the noted slots [0, n) of a wave's list (n <= 64): heads of simple pairs, to the tie list
-__device__ __attribute__((noinline)) void rl_noted(const RankArgs &a, const uint32_t *list, uint32_t n, uint32_t *s_tie_n)
+// the noted pairs [0, n) of a wave's list (n <= 64): simple tied pairs, their two text positions, to the workgroup's region of a.pairs
+__device__ __attribute__((noinline)) void rl_noted(const RankArgs &a, const uint2 *list, uint32_t n, uint32_t *s_pair_n)
 {
     const int lane = threadIdx.x & 63;
-    const bool on = (uint32_t)lane < n;
-    rs_append(on, s_tie_n, a.ties, a.tie_region, on ? list[lane] : 0u);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(s_pair_n, n);
+    base = __shfl(base, 0, 64);
+    if ((uint32_t)lane < n && base + (uint32_t)lane < a.tie_region) a.pairs[(size_t)blockIdx.x * a.tie_region + base + lane] = list[lane];
 }
 
 // the queued slots [0, n) of a wave's list (n <= 64): rank_scan_slow on the RS_HALO slots either side, from global memory
@@ -327,12 +329,11 @@ __device__ __attribute__((noinline)) void rl_queued(const RankArgs &a, const uin
 }
 
 // the first 64 entries of a list are done with: the rest moves to the front
-__device__ __forceinline__ void rl_shift(uint32_t *list, uint32_t &n)
+template <class E> __device__ __forceinline__ void rl_shift(E *list, uint32_t &n)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t rest = n - 64;
-    const uint32_t v = (uint32_t)lane < rest ? list[64 + lane] : 0u;
-    if ((uint32_t)lane < rest) list[lane] = v;
+    if ((uint32_t)lane < rest) { const E v = list[64 + lane]; list[lane] = v; }
     n = rest;
 }
 
@@ -340,13 +341,15 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 {
     // (the scan's arguments stay in memory: the rows below need a handful of them, and in scalar registers all of them
     // together crowd out the masks)
-    __shared__ uint32_t s_note[RL_WAVES][RL_LIST], s_queue[RL_WAVES][RL_LIST];
-    __shared__ uint32_t s_cand_n, s_tie_n;
+    __shared__ uint2 s_note[RL_WAVES][RL_LIST];
+    __shared__ uint32_t s_queue[RL_WAVES][RL_LIST];
+    __shared__ uint32_t s_cand_n, s_tie_n, s_pair_n;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // (told to be uniform: the loop below runs on scalar registers)
-    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; }
+    if (threadIdx.x == 0) { s_cand_n = 0; s_tie_n = 0; s_pair_n = 0; }
     __syncthreads();
-    uint32_t *my_note = s_note[wv], *my_queue = s_queue[wv];
+    uint2 *my_note = s_note[wv];
+    uint32_t *my_queue = s_queue[wv];
     uint32_t nn = 0, nq = 0;                                            // (wave-uniform)
     const uint32_t own_lo = (uint32_t)f.own_lo, own_hi = (uint32_t)f.own_hi;   // (below 2^31: rs_lean_setup)
     const uint32_t wlo = own_lo + ((uint32_t)blockIdx.x * RL_WAVES + (uint32_t)wv) * f.per_wave;   // per_wave: a multiple of RL_EV
@@ -372,7 +375,8 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             nq += (uint32_t)__popcll(Q);
         } else {
             const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
-            const uint32_t dh = hi ^ rl_from_next(hi), dl = (lo ^ rl_from_next(lo)) >> f.pb;    // (pb < 32: the position lies in the low word)
+            const uint32_t lo_n = rl_from_next(lo);
+            const uint32_t dh = hi ^ rl_from_next(hi), dl = (lo ^ lo_n) >> f.pb;                // (pb < 32: the position lies in the low word)
             const float fr = __builtin_amdgcn_fractf((float)(lo & f.pmask) * f.inv_row_len);
             const float f1 = __uint_as_float(rl_from_next(__float_as_uint(fr))), f2 = __uint_as_float(rl_from_next(__float_as_uint(f1)));
             const float d1 = fabsf(fr - f1), d2 = fabsf(fr - f2);
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 Q = QP | (QP << 1) | (EVM & (LONG | ADJL | (~TIE & (RUN | NE))));
             }
             if (SS) {
-                if ((SS >> lane) & 1ull) my_note[nn + rl_lanes_below(SS)] = slot;
+                if ((SS >> lane) & 1ull) my_note[nn + rl_lanes_below(SS)] = make_uint2(lo & f.pmask, lo_n & f.pmask);
                 nn += (uint32_t)__popcll(SS);
             }
             if (Q) {
@@ -411,12 +415,12 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             }
         }
         while (nq >= 64) { rl_queued(*ap, my_queue, 64, &s_cand_n, &s_tie_n); rl_shift(my_queue, nq); }
-        if (nn >= 64) { rl_noted(*ap, my_note, 64, &s_tie_n); rl_shift(my_note, nn); }
+        if (nn >= 64) { rl_noted(*ap, my_note, 64, &s_pair_n); rl_shift(my_note, nn); }
     }
-    if (nn) rl_noted(*ap, my_note, nn, &s_tie_n);
+    if (nn) rl_noted(*ap, my_note, nn, &s_pair_n);
     if (nq) rl_queued(*ap, my_queue, nq, &s_cand_n, &s_tie_n);
     __syncthreads();
-    if (threadIdx.x == 0) { ap->blk_count[blockIdx.x] = s_cand_n; ap->tie_count[blockIdx.x] = s_tie_n; }
+    if (threadIdx.x == 0) { ap->blk_count[blockIdx.x] = s_cand_n; ap->tie_count[blockIdx.x] = s_tie_n; ap->pair_count[blockIdx.x] = s_pair_n; }
 }
 
 // Can fractions of the row length in single precision tell the columns apart?  x = fract((float)position * (float)(1 / row length)):
@@ -477,6 +481,22 @@ template <int L> __global__ __launch_bounds__(256) void k_tie_simple(RankArgs a)
 #pragma unroll
         for (int i = 0; i < RS_TG; i++)
             if (i < s) rs_update(a, rs_col_of_rem(a, rs_rem<L>(a, pos[i])), fbg_clamp_lcp(best[i] + (uint32_t)a.K) + 1);
+    }
+}
+
+// the simple tied pairs k_rank_scan_lean set aside with their text positions: the two suffixes agree on K symbols and nobody
+// else does, the extension of either is 1 + their longest common prefix (no slot is read again: two text reads per pair)
+__global__ __launch_bounds__(256) void k_tie_pairs(RankArgs a)
+{
+    const uint32_t have = a.pair_count[blockIdx.x];
+    if (have > a.tie_region) { if (threadIdx.x == 0) a.counters[1] = 1; return; }
+    for (uint32_t e = threadIdx.x; e < have; e += blockDim.x) {
+        const uint2 p = a.pairs[(size_t)blockIdx.x * a.tie_region + e];
+        const uint64_t x = fbg_load8(a.T, (uint64_t)p.x + a.K) ^ fbg_load8(a.T, (uint64_t)p.y + a.K);
+        const uint32_t h = x != 0 ? (uint32_t)(__ffsll((unsigned long long)x) - 1) / 8 : fbg_extend_match(a.T, (uint64_t)p.x + a.K, (uint64_t)p.y + a.K, 8);
+        const uint32_t g = fbg_clamp_lcp(h + (uint32_t)a.K) + 1;
+        rs_update(a, rs_col_of_rem(a, rs_rem<FBG_SLOTS_PACKED>(a, p.x)), g);
+        rs_update(a, rs_col_of_rem(a, rs_rem<FBG_SLOTS_PACKED>(a, p.y)), g);
     }
 }
 
@@ -851,8 +871,13 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     a.tie_count = ctx->dp_f.as<uint32_t>(); a.tie_region = tie_region;
     FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_RANK_KERNEL));
     LeanArgs lf;
-    if (layout == FBG_SLOTS_PACKED && a.g_min > (uint32_t)a.K && !a.values_only && !a.part_mode && !ctx->opt.rank_no_lean && rs_lean_setup(a, a.pb, rs_blocks, &lf))
+    const bool lean = layout == FBG_SLOTS_PACKED && a.g_min > (uint32_t)a.K && !a.values_only && !a.part_mode && !ctx->opt.rank_no_lean &&
+                      rs_lean_setup(a, a.pb, rs_blocks, &lf);
+    if (lean)
     {
+        FBG_TRY(fbg_reserve(ctx, ctx->ps_g, (size_t)rs_blocks * tie_region * 8));
+        FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)rs_blocks * 4));
+        a.pairs = ctx->ps_g.as<uint2>(); a.pair_count = ctx->ps_h.as<uint32_t>();
         // the scan's arguments travel through memory
         FBG_TRY(fbg_reserve(ctx, ctx->kargs, sizeof(RankArgs)));
         FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->kargs.p, &a, sizeof(RankArgs), hipMemcpyHostToDevice, st));
@@ -862,11 +887,11 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
     else
         RS_LAUNCH_SCAN(layout, a.g_min <= (uint32_t)a.K || a.values_only, dim3(rs_blocks), st, a);
     FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_RANK_KERNEL, 1));
-    if (ctx->opt.no_aux_stream) {
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), st, a);
-    } else {
-        FBG_TRY(rs_fork(ctx));
-        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ctx->aux, a);
+    {
+        hipStream_t ts = st;
+        if (!ctx->opt.no_aux_stream) { FBG_TRY(rs_fork(ctx)); ts = ctx->aux; }
+        if (lean) hipLaunchKernelGGL(k_tie_pairs, dim3(rs_blocks), dim3(256), 0, ts, a);
+        RS_LAUNCH(k_tie_simple, layout, dim3(rs_blocks), dim3(256), ts, a);
     }
     *launches += 2;
     // from here on k_tie_simple may be running on the aux stream: an error return joins it first, so that no caller
