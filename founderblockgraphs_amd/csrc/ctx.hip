@@ -211,6 +211,7 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (strcmp(key, "grs_threshold") == 0) { *value = ctx->grs_t; return FBG_OK; }
     if (strcmp(key, "grs_redone") == 0) { *value = (int64_t)ctx->grs_redone; return FBG_OK; }
     if (strcmp(key, "dp_kind") == 0) { *value = ctx->dp_kind; return FBG_OK; }
+    if (strcmp(key, "msd_decline") == 0) { *value = ctx->msd_decline; return FBG_OK; }
     if (strcmp(key, "span_scan_used") == 0) { *value = (ctx->index_valid && ctx->granked && ctx->spanned) ? 1 : 0; return FBG_OK; }
     if (strcmp(key, "span_scan_work") == 0) { *value = (int64_t)ctx->sp_work; return FBG_OK; }
     if (strcmp(key, "span_groups") == 0) { *value = (int64_t)ctx->sp_G; return FBG_OK; }

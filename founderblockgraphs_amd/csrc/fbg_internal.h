@@ -110,6 +110,7 @@ struct fbg_ctx {
     uint64_t sp_G = 0, sp_R = 0, sp_n_irr = 0, sp_work = 0;
     uint32_t sp_n_odd[4] = {0, 0, 0, 0}, sp_odd_cap = 0;
     const uint32_t *sort_payload = nullptr;   // while set: the pack kernels of the (key, value) sorts write payload[p] instead of p | flag
+    int64_t msd_decline = -1;    // the last fbg_msd_sort: 0 sorted; 1 not tried (geometry), 2 / 4 a stretch of pass 1, 8 the arena of pass 2, 16 a sub-bucket too large
     int dp_kind = -1;            // which sweep produced the last fbg_dp_minmax result (fbg_get_option "dp_kind")
     bool cells_built = false;      // prow / igrow hold the current MSA (built on demand: only the record path reads them)
     uint8_t ignore_tab[256] = {0};

@@ -20,7 +20,8 @@ __device__ __forceinline__ void msd_fetch_raw(const uint8_t *__restrict__ T, uin
         raw2 = q < N + 56 ? *reinterpret_cast<const uint64_t *>(T + q) : 0ull;
     }
 }
-template <int TILE>
+// FULL: the tile and its lookahead lie inside the text (base + TILE + 64 <= N): no end-of-text checks
+template <int TILE, bool FULL = false>
 __device__ __forceinline__ void msd_store_tile(uint8_t *tile, const uint8_t *cd, uint64_t N, uint64_t base, uint64_t raw, uint64_t raw2)
 {
     const int k8 = threadIdx.x * 8;
@@ -28,7 +29,7 @@ __device__ __forceinline__ void msd_store_tile(uint8_t *tile, const uint8_t *cd,
     uint64_t codes = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint32_t c = p + j < N ? cd[(raw >> (8 * j)) & 255u] : (uint32_t)MSD_SEP;
+        const uint32_t c = (FULL || p + j < N) ? cd[(raw >> (8 * j)) & 255u] : (uint32_t)MSD_SEP;
         codes |= (uint64_t)c << (8 * j);
     }
     *reinterpret_cast<uint64_t *>(tile + k8) = codes;
@@ -38,18 +39,18 @@ __device__ __forceinline__ void msd_store_tile(uint8_t *tile, const uint8_t *cd,
         uint64_t codes2 = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const uint32_t c = q + j < N ? cd[(raw2 >> (8 * j)) & 255u] : (uint32_t)MSD_SEP;
+            const uint32_t c = (FULL || q + j < N) ? cd[(raw2 >> (8 * j)) & 255u] : (uint32_t)MSD_SEP;
             codes2 |= (uint64_t)c << (8 * j);
         }
         *reinterpret_cast<uint64_t *>(tile + kk) = codes2;
     }
 }
-template <int TILE>
+template <int TILE, bool FULL = false>
 __device__ __forceinline__ void msd_load_tile(uint8_t *tile, const uint8_t *cd, const uint8_t *__restrict__ T, uint64_t N, uint64_t base)
 {
     uint64_t raw, raw2;
     msd_fetch_raw<TILE>(T, N, base, raw, raw2);
-    msd_store_tile<TILE>(tile, cd, N, base, raw, raw2);
+    msd_store_tile<TILE, FULL>(tile, cd, N, base, raw, raw2);
 }
 
 // w[i] = key of position t0 + i of the tile, i < MSD_ITEMS (t0 = 8 * threadIdx.x)

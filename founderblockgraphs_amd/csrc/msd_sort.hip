@@ -59,15 +59,7 @@ struct MsdArgs {
     unsigned long long *arena_count;
     uint32_t arena_cap;
     unsigned long long *flag;                  // != 0: a capacity was exceeded
-    int probe;                                 // timing probes (option msd_probe): 1 no global stores, 2 made-up slots instead of loads, 16 / 32 non-temporal stores / loads
 };
-
-__device__ __forceinline__ uint64_t msd_probe_word(uint32_t j)
-{
-    uint64_t x = ((uint64_t)blockIdx.x * 16384ull + j + 1) * 0x9E3779B97F4A7C15ull;
-    x ^= x >> 29;
-    return (x & ~0x3fffull) | j;
-}
 
 // ranks -> exclusive offsets of the MSD_NB digit counts of a tile; thread d < MSD_NB also reserves the run of digit d
 // behind *cursor (one global atomic per non-empty digit) and leaves its start, relative to the bucket, minus the run's
@@ -94,20 +86,15 @@ __device__ __forceinline__ void msd_scan_and_reserve(uint32_t *cnt, uint32_t *lo
     __syncthreads();
 }
 
-__global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
+// FULL: every position of the tile lies inside the text (all tiles but the last one): none of the per-slot checks
+template <bool FULL>
+__device__ __forceinline__ void msd_pack_split_body(const MsdArgs &a, uint64_t *buf, const uint8_t *cd, uint32_t *cnt, uint32_t *loff, uint32_t *gdelta,
+                                                    uint32_t *wsum)
 {
-    __shared__ uint64_t buf[MSD_TILE];         // first the symbol codes of the tile (bytes), then the regrouped slots
-    __shared__ uint8_t cd[256];
-    __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
-    __shared__ uint32_t gdelta[MSD_NB];
-    __shared__ uint32_t wsum[MSD_THREADS / 64];
     uint8_t *tile = reinterpret_cast<uint8_t *>(buf);          // MSD_TILE + 64 bytes
     const int b = a.b, K = a.K;
-    if (threadIdx.x < 256) cd[threadIdx.x] = a.code[threadIdx.x];
-    if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
-    __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * MSD_TILE;
-    msd_load_tile<MSD_TILE>(tile, cd, a.T, a.N, base);
+    msd_load_tile<MSD_TILE, FULL>(tile, cd, a.T, a.N, base);
     __syncthreads();
     // keys of the thread's MSD_ITEMS consecutive positions
     const int t0 = threadIdx.x * MSD_ITEMS;
@@ -119,7 +106,7 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
 #pragma unroll
     for (int i = 0; i < MSD_ITEMS; i++) {
         const uint64_t p = base + t0 + i;
-        const bool ok = p < a.N;
+        const bool ok = FULL || p < a.N;
         rk[i] = ok ? atomicAdd(&cnt[(uint32_t)(w[i] >> dshift)], 1u) : 0xffffffffu;
         w[i] = (w[i] << a.pb) | p;
     }
@@ -133,23 +120,37 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
     uint64_t *const obase = a.buf1 + xq * a.segcap;
 #pragma unroll
     for (int i = 0; i < MSD_ITEMS; i++)
-        if (rk[i] != 0xffffffffu) buf[loff[(uint32_t)(w[i] >> wshift)] + rk[i]] = w[i];
+        if (FULL || rk[i] != 0xffffffffu) buf[loff[(uint32_t)(w[i] >> wshift)] + rk[i]] = w[i];
     __syncthreads();
-    const uint32_t have = (uint32_t)min((uint64_t)MSD_TILE, a.N - base);
+    const uint32_t have = FULL ? (uint32_t)MSD_TILE : (uint32_t)min((uint64_t)MSD_TILE, a.N - base);
+    bool over = false;
 #pragma unroll
     for (int r = 0; r < MSD_ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        if (j < have) {
+        if (FULL || j < have) {
             const uint64_t x = buf[j];
             const uint32_t d = (uint32_t)(x >> wshift);
             const uint32_t at = j + gdelta[d];                  // below 2^32: the host checks cap1 + N
-            if (a.probe & 1) continue;
-            if (at < a.segcap) {
-                if (a.probe & 16) __builtin_nontemporal_store(x, &obase[(uint64_t)d * a.cap1 + at]);
-                else obase[(uint64_t)d * a.cap1 + at] = x;
-            } else if (!a.probe) *a.flag = 1;
+            if (at < a.segcap) obase[(uint64_t)d * a.cap1 + at] = x;
+            else over = true;
         }
     }
+    if (over) atomicOr(a.flag, 2ull);
+}
+
+__global__ __launch_bounds__(MSD_THREADS) void k_msd_pack_split(MsdArgs a)
+{
+    __shared__ uint64_t buf[MSD_TILE];         // first the symbol codes of the tile (bytes), then the regrouped slots
+    __shared__ uint8_t cd[256];
+    __shared__ uint32_t cnt[MSD_NB], loff[MSD_NB];
+    __shared__ uint32_t gdelta[MSD_NB];
+    __shared__ uint32_t wsum[MSD_THREADS / 64];
+    if (threadIdx.x < 256) cd[threadIdx.x] = a.code[threadIdx.x];
+    if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // (a body without the end-of-text checks for the tiles inside the text is slower here: 3.35 against 3.12 ms, same box,
+    // where the same specialisation takes a sixth off pass 2; not taken)
+    msd_pack_split_body<false>(a, buf, cd, cnt, loff, gdelta, wsum);
 }
 
 // first tile of every stretch of pass 1 (one workgroup of 1024 threads; nseg <= 4096 stretches, four per thread)
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(1024) void k_msd_tiles(const unsigned long long *__
         t[q] = 0;
         if (s < nseg) {
             const unsigned long long c = count1[s] < segcap ? count1[s] : segcap;
-            if (count1[s] > segcap) *flag = 1;
+            if (count1[s] > segcap) atomicOr(flag, 4ull);
             t[q] = (uint32_t)((c + MSD_TILE - 1) / MSD_TILE);
         }
         tot += t[q];
@@ -183,6 +184,51 @@ __global__ __launch_bounds__(1024) void k_msd_tiles(const unsigned long long *__
         if (s < nseg) tile_start[s] = pre;
         pre += t[q];
         if (s + 1 == nseg) tile_start[nseg] = pre;
+    }
+}
+
+// FULL: a whole tile of MSD_TILE slots (all tiles of a stretch but its last one): none of the per-slot checks
+template <bool FULL>
+__device__ __forceinline__ void msd_split_body(const MsdArgs &a, uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *gdelta, uint32_t *wsum,
+                                               const uint64_t *__restrict__ in, uint32_t have, uint32_t seg)
+{
+    const int wshift = a.pb + a.kb - 2 * MSD_DIG;
+    uint64_t w[MSD_ITEMS];
+    uint32_t rk[MSD_ITEMS];
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        w[r] = (FULL || j < have) ? in[j] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        rk[r] = (FULL || j < have) ? atomicAdd(&cnt[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    msd_scan_and_reserve(cnt, loff, gdelta, wsum, nullptr, false,
+                         a.count2 + (size_t)seg * MSD_NB + (threadIdx.x < MSD_NB ? threadIdx.x : 0));
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        if (FULL || j < have) buf[loff[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)] + rk[r]] = w[r];
+    }
+    __syncthreads();
+    uint64_t *const obase = a.buf2 + (uint64_t)seg * MSD_NB * MSD_FN_CAP;
+#pragma unroll
+    for (int r = 0; r < MSD_ITEMS; r++) {
+        const uint32_t j = threadIdx.x + r * MSD_THREADS;
+        if (FULL || j < have) {
+            const uint64_t x = buf[j];
+            const uint32_t d = (uint32_t)(x >> wshift) & (MSD_NB - 1);
+            const uint32_t at = j + gdelta[d];
+            if (at < MSD_FN_CAP) obase[d * MSD_FN_CAP + at] = x;
+            else {
+                const unsigned long long e = atomicAdd(a.arena_count, 1ull);
+                if (e < a.arena_cap) { a.arena_sb[e] = seg * MSD_NB + d; a.arena_w[e] = x; }
+                else atomicOr(a.flag, 8ull);
+            }
+        }
     }
 }
 
@@ -207,47 +253,8 @@ __global__ __launch_bounds__(MSD_THREADS) void k_msd_split(MsdArgs a)
     const uint64_t *in = a.buf1 + (uint64_t)seg * a.cap1 + (uint64_t)(lo % (uint32_t)a.xs) * a.segcap + first;
     if (threadIdx.x < MSD_NB) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int wshift = a.pb + a.kb - 2 * MSD_DIG;
-    uint64_t w[MSD_ITEMS];
-    uint32_t rk[MSD_ITEMS];
-#pragma unroll
-    for (int r = 0; r < MSD_ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        w[r] = j < have ? ((a.probe & 2) ? msd_probe_word(j) : (a.probe & 32) ? __builtin_nontemporal_load(in + j) : in[j]) : 0ull;
-    }
-#pragma unroll
-    for (int r = 0; r < MSD_ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        rk[r] = j < have ? atomicAdd(&cnt[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)], 1u) : 0u;
-    }
-    __syncthreads();
-    msd_scan_and_reserve(cnt, loff, gdelta, wsum, nullptr, false,
-                         a.count2 + (size_t)seg * MSD_NB + (threadIdx.x < MSD_NB ? threadIdx.x : 0));
-#pragma unroll
-    for (int r = 0; r < MSD_ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        if (j < have) buf[loff[(uint32_t)(w[r] >> wshift) & (MSD_NB - 1)] + rk[r]] = w[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < MSD_ITEMS; r++) {
-        const uint32_t j = threadIdx.x + r * MSD_THREADS;
-        if (j < have) {
-            const uint64_t x = buf[j];
-            const uint32_t d = (uint32_t)(x >> wshift) & (MSD_NB - 1);
-            const uint32_t at = j + gdelta[d];
-            if (a.probe & 1) continue;
-            if (at < MSD_FN_CAP) {
-                if (a.probe & 16) __builtin_nontemporal_store(x, &a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at]);
-                else a.buf2[((uint64_t)seg * MSD_NB + d) * MSD_FN_CAP + at] = x;
-            } else if (a.probe) continue;
-            else {
-                const unsigned long long e = atomicAdd(a.arena_count, 1ull);
-                if (e < a.arena_cap) { a.arena_sb[e] = seg * MSD_NB + d; a.arena_w[e] = x; }
-                else *a.flag = 1;
-            }
-        }
-    }
+    if (__builtin_amdgcn_readfirstlane((int)have) == MSD_TILE) msd_split_body<true>(a, buf, cnt, loff, gdelta, wsum, in, have, seg);   // (uniform, and told so: barriers inside)
+    else msd_split_body<false>(a, buf, cnt, loff, gdelta, wsum, in, have, seg);
 }
 
 __global__ void k_msd_widen(const uint32_t *__restrict__ count2, unsigned long long *__restrict__ wide, uint64_t cnt)
@@ -395,21 +402,20 @@ __device__ __forceinline__ void msd_finish_sort(uint64_t *buf, uint32_t *cnt, ui
 template <int CAP, int THREADS>
 __device__ __forceinline__ void msd_finish_body(uint64_t *buf, uint32_t *cnt, uint32_t *loff, uint32_t *wsum, const uint64_t *in_a,
                                                 uint32_t n_a, const uint64_t *in_b, uint32_t have, uint64_t *out, int fshift,
-                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds,
-                                                int probe = 0)
+                                                uint32_t fmask, int lowbits, uint32_t *sub, uint16_t *biglist, uint32_t *nbig_lds)
 {
     constexpr int ITEMS = CAP / THREADS;
     uint64_t w[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
-        w[r] = j < have ? ((probe & 2) ? msd_probe_word(j) : (probe & 32) ? __builtin_nontemporal_load(in_a + j) : j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
+        w[r] = j < have ? (j < n_a ? in_a[j] : in_b[j - n_a]) : ~0ull;
     }
     msd_finish_sort<CAP, THREADS>(buf, cnt, loff, wsum, w, have, fshift, fmask, lowbits, sub, biglist, nbig_lds);
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t j = threadIdx.x + r * THREADS;
-        if (j < have && !(probe & 1)) { if (probe & 16) __builtin_nontemporal_store(buf[j], out + j); else out[j] = buf[j]; }
+        if (j < have) out[j] = buf[j];
     }
 }
 
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(MSD_FN_THREADS) void k_msd_finish(MsdArgs a, int fs
     if (have == 0 || have > MSD_FN_CAP) return;                // the larger ones: k_msd_finish_big
     const uint64_t *in = a.buf2 + (uint64_t)blockIdx.x * MSD_FN_CAP;
     msd_finish_body<MSD_FN_CAP, MSD_FN_THREADS>(buf, cnt, loff, wsum, in, have, in, have, a.out + a.off[blockIdx.x], fshift, fmask,
-                                                fshift - a.pb, sub, biglist, &nbig_lds, a.probe);
+                                                fshift - a.pb, sub, biglist, &nbig_lds);
 }
 
 // sub-buckets whose stretch overflowed: the arena (sorted by sub-bucket) holds the slots beyond MSD_FN_CAP.  One
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
     const uint32_t sb = sb_sorted[e];
     if (e > 0 && sb_sorted[e - 1] == sb) return;
     const uint32_t have = a.count2[sb];
-    if (have > MSD_BIG_CAP || have <= MSD_FN_CAP) { if (threadIdx.x == 0) *a.flag = 1; return; }
+    if (have > MSD_BIG_CAP || have <= MSD_FN_CAP) { if (threadIdx.x == 0) atomicOr(a.flag, 16ull); return; }
     msd_finish_body<MSD_BIG_CAP, MSD_BIG_THREADS>(buf, cnt, loff, wsum, a.buf2 + (uint64_t)sb * MSD_FN_CAP, MSD_FN_CAP, w_sorted + e, have,
                                                   a.out + a.off[sb], fshift, fmask, fshift - a.pb, sub, biglist, &nbig_lds);
 }
@@ -456,6 +462,7 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
 int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches)
 {
     *ok = 0;
+    ctx->msd_decline = 1;                                       // the geometry does not suit this sort
     const uint64_t N = ctx->N;
     const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
     const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);   // tests lower it
@@ -496,15 +503,6 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 16, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
-    a.probe = 0;
-    const bool probing = ctx->opt.msd_probe != 0;              // every kernel runs its probe variants first (a profiler reads their times)
-    if (probing)
-        for (int v : {1, 16}) {
-            a.probe = v;
-            hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
-            FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
-            a.probe = 0;
-        }
     hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, st, a.count1, a.segcap, nseg, tile_start, flag);
     uint32_t tiles2 = 0;
@@ -513,17 +511,11 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemcpyAsync(&h_flag, flag, 8, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 2;
+    ctx->msd_decline = (int64_t)h_flag;                         // (fbg_get_option "msd_decline": which capacity did not hold)
     if (h_flag != 0 || tiles2 == 0) return FBG_OK;
     a.tiles2 = tiles2;
     a.tiles2_x = (xcd & 1) ? (tiles2 + 7) / 8 : 0;
     const unsigned grid2 = a.tiles2_x ? 8 * a.tiles2_x : tiles2;
-    if (probing)
-        for (int v : {1, 16, 32, 48}) {
-            a.probe = v;
-            hipLaunchKernelGGL(k_msd_split, dim3(grid2), dim3(MSD_THREADS), 0, st, a);
-            FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
-            a.probe = 0;
-        }
     hipLaunchKernelGGL(k_msd_split, dim3(grid2), dim3(MSD_THREADS), 0, st, a);
     // offsets of the sub-buckets in the sorted array: exclusive scan of their sizes
     unsigned long long *wide = reinterpret_cast<unsigned long long *>(ctx->keysA.p);   // scratch: pass 1's slots are dead
@@ -539,17 +531,12 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     }
     const int fshift = g.pb + rest - fbits;
     const uint32_t fmask = (uint32_t)((1u << fbits) - 1);
-    if (probing)
-        for (int v : {1, 3, 16, 32, 48}) {
-            a.probe = v;
-            hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
-            a.probe = 0;
-        }
     hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
     unsigned long long h2[2] = {0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 4;
+    ctx->msd_decline = (int64_t)h2[0];
     if (h2[0] != 0) return FBG_OK;
     if (h2[1] > 0) {
         // a few sub-buckets were larger than their stretch (row ends pile up on keys that end in zeros): their
@@ -568,6 +555,7 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         *launches += 2;
+        ctx->msd_decline = (int64_t)h2[0];
         if (h2[0] != 0) return FBG_OK;
     }
     FBG_HIP_TRY(ctx, hipGetLastError());

@@ -86,9 +86,9 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   msd_min_force      1: the sample sort of (key, position) pairs also for rows that resemble each other (tests)
  *   msd_sample_bins    1: the finish of the sample sort bins by sampled keys instead of symbol ranks (the earlier method, kept for tests)
  *   gapped_rank also takes 2 (no flag bits in the sort's values), 3 (flag bits, no threshold), 4 (threshold forced: tests)
- *   msd_probe          1: the kernels of the MSD sort and the finish of the sample sort also run in timing variants (no stores,
- *                      made-up slots, single phases) before the real launch -- for a kernel trace read in launch order
- *                      (scripts/gpu_trace_order.sh); results unchanged
+ *   msd_probe          1: the finish of the sample sort (k_pp_finish) also runs in timing variants (copy only, single phases) before
+ *                      the real launch -- for a kernel trace read in launch order (scripts/gpu_trace_order.sh); results
+ *                      unchanged.  (The three-pass MSD sort had such variants in round 3: profiles/r03_msd_probe_order.txt)
  *   rank_no_lean       1: the rank-order scan with k_rank_scan also where its lean form (k_rank_scan_lean: packed slots, threshold
  *                      above the key length) applies; results unchanged
  *   msd_xcd            which passes of the MSD sort place their writes by XCD (-1 = 3): bit 0 pass 2 (the tiles of a bucket
@@ -105,6 +105,9 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  * "dp_kind" (read-only): the sweep that produced the last fbg_minmax_dp result: -1 none yet, 0 statement by statement,
  * 1 matrix chain with byte entries (windows up to 256 columns), 2 wave-parallel sweep, 3 .. 7 matrix chain with 16-bit
  * entries over windows of 1024 / 2048 / 4096 / 8192 / 16384 columns.
+ * "msd_decline" (read-only): the three-pass MSD sort of the last index build: -1 not reached, 0 it sorted the slots, 1 the
+ * geometry did not suit it (rocPRIM sorted), else the capacity that did not hold (2 / 4 a stretch of pass 1, 8 the arena
+ * of pass 2, 16 a sub-bucket beyond the largest finish).
  * Unknown key: FBG_ERR_INVALID.
  */
 int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value);

@@ -26,5 +26,5 @@ with F.Engine(0) as eng:
         eng.index_build()
         eng.scan_f(0, n, d_f.data_ptr())
         eng.sync()
-        print(json.dumps({"ms": round(1e3 * (time.perf_counter() - t0), 2), "index_kind": eng.get_option("index_kind"),
+        print(json.dumps({"ms": round(1e3 * (time.perf_counter() - t0), 2), "index_kind": eng.get_option("index_kind"), "msd_decline": eng.get_option("msd_decline"),
                           "stages": {k: round(v[0], 2) for k, v in eng.stage_ms().items()}, "f_sum": int(d_f.sum())}), flush=True)
