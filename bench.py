@@ -18,9 +18,10 @@ The sweep of step i runs on a context and stream of its own on rank 0, beside th
 step i+1 (it is a chain of small launches that would leave the GPU -- at N>1 all GPUs -- idle); all
 of it is joined before the closing barrier, inside the timed region.  --serial-sweep switches that off.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the extension-scan kernel (k_rank_scan; k_scan_stream
-when the MSA has gaps): algorithmic bytes = (13*m + 8) per column over its HIP-event
-duration.  `cpu_baseline` times the CPU restatement (oracle/, kind "port") on a bounded column prefix
+Prints ONE JSON line on rank 0.  `roofline` prices the kernel of the step that takes longest among those
+with HIP-event brackets of their own: the extension scan (k_rank_scan_lean / k_rank_scan; k_scan_stream when
+the MSA has gaps) with (13*m + 8) bytes per column, the three passes of the MSD sort with
+the bytes a pass must move (9 / 16 / 16 per suffix); `roofline.kernels` lists all of them.  `cpu_baseline` times the CPU restatement (oracle/, kind "port") on a bounded column prefix
 of the same MSA.
 """
 import argparse
@@ -257,7 +258,7 @@ def measured_traffic(m, n, kernel):
     """HBM bytes per launch of the scan kernel from the committed rocprofv3 PMC passes (profiles/, collected as
     MI355X_MICROARCH.md prescribes: separate --pmc passes, KiB units, FETCH_SIZE doubled on gfx950); None when no pass
     exists for this workload / kernel."""
-    for name in ("r03_pmc_kernels.json", "r02_pmc_kernels.json", "r01_pmc_scan_kernels.json"):
+    for name in ("r04_pmc_kernels.json", "r03_pmc_kernels.json", "r02_pmc_kernels.json", "r01_pmc_scan_kernels.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 d = json.load(fh)
@@ -472,8 +473,27 @@ def main():
             scan_cols, scan_rows = n, rows_pair
             mode_used = f"row-group pairs (G={G}, {len(D.group_pairs(G))} pairs), all-reduce(max)"
         scan_bytes = (13 * scan_rows + 8) * scan_cols / launches_per_step    # algorithmic bytes one launch covers
-        traffic, traffic_src = measured_traffic(scan_rows, scan_cols, "k_rank_scan" if ranked else "k_scan_stream")
+        scan_kernel = "k_scan_stream" if not ranked else ("k_rank_scan_lean" if (world == 1 and eng.get_option("rank_no_lean") == 0) else "k_rank_scan")
+        traffic, traffic_src = measured_traffic(scan_rows, scan_cols, scan_kernel)
         achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        # The kernels with HIP-event brackets of their own: the extension scan, priced with SURVEY.md 8(d)'s
+        # (13 m + 8) bytes per column, and the three passes of the MSD sort, priced with the bytes a sort pass cannot avoid
+        # (pass 1: 1 text byte read + 8 written per suffix; passes 2 and 3: 8 read + 8 written).  `roofline` is the one
+        # that takes longest; `roofline.kernels` has them all.
+        slots = scan_rows * (scan_cols + 1) + 1
+        priced = {scan_kernel: {"avg_launch_ms": scan_ms, "algorithmic_bytes_per_launch": scan_bytes,
+                                "bytes_per_unit": f"(13 * {scan_rows} + 8) B per column (SURVEY.md 8d)"}}
+        for stage, kname, per_slot in (("sort_pass1", "k_msd_pack_split", 9), ("sort_pass2", "k_msd_split", 16), ("sort_pass3", "k_msd_finish", 16)):
+            tot, ln = stage_acc.get(stage, [0.0, 0])
+            if ln > 0:
+                priced[kname] = {"avg_launch_ms": tot / ln, "algorithmic_bytes_per_launch": per_slot * slots,
+                                 "bytes_per_unit": f"{per_slot} B per suffix (DESIGN.md 5)"}
+        for v in priced.values():
+            v["achieved"] = v["algorithmic_bytes_per_launch"] / (v["avg_launch_ms"] * 1e-3) / 1e9 if v["avg_launch_ms"] > 0 else 0.0
+            v["frac"] = v["achieved"] / HBM_PEAK_GBPS
+        dominant = max(priced, key=lambda k: priced[k]["avg_launch_ms"])
+        dom = priced[dominant]
+        dom_traffic, dom_src = (traffic, traffic_src) if dominant == scan_kernel else measured_traffic(scan_rows, scan_cols, dominant)
         out = {
             "metric": "MSA columns segmented/sec", "value": n * args.steps / dt, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -485,12 +505,15 @@ def main():
                                    "device, the sweep of a step running beside the next step's index build; T_seg of SURVEY.md 8(d) "
                                    "(host RAM to host RAM) is `t_seg`, one job alone is `latency_ms`",
                        "rows": m, "cols": n, "text_length": m * (n + 1) + 1, "blocks": state.get("blocks")},
-            "roofline": {"bound": "hbm", "kernel": "k_rank_scan" if ranked else "k_scan_stream", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic if world == 1 else None,
-                         "traffic_source": (f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled "
-                                            "as the guide prescribes for gfx950: equals one read of every slot)") if traffic_src else None,
-                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches_per_step": launches_per_step},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": dom["frac"],
+                         "traffic": dom_traffic if world == 1 else None,
+                         "traffic_source": (f"{dom_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled for "
+                                            "the wide coalesced streams, as the guide prescribes for gfx950)") if dom_src else None,
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+                         "bytes_per_unit": dom["bytes_per_unit"],
+                         "note": "the kernel of the step that takes longest; the extension scan and every sort pass are in `kernels`",
+                         "kernels": priced, "scan_kernel": scan_kernel, "scan_launches_per_step": launches_per_step},
             "stages_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stage_acc.items()},
             "sweep": ("serial" if sweeper is None else
                       {"overlapped_with": "the next step's index build (own context and stream on rank 0)",

@@ -15,7 +15,7 @@ FBG_OK, FBG_ERR_INVALID, FBG_ERR_NO_SEGMENTATION, FBG_ERR_OOM, FBG_ERR_HIP, FBG_
     FBG_ERR_NO_DEVICE, FBG_ERR_HASH_COLLISION = range(8)
 PART_HALO = 64                               # FBG_PART_HALO (include/fbg_hip.h)
 PART_HALO_BYTES = 2 * PART_HALO * 12 + 16    # FBG_PART_HALO_BYTES
-STAGES = ("text", "suffix_sort", "lcp", "rank_scan", "scan", "dp", "rank_kernel")
+STAGES = ("text", "suffix_sort", "lcp", "rank_scan", "scan", "dp", "rank_kernel", "sort_pass1", "sort_pass2", "sort_pass3")
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
 vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)

@@ -390,6 +390,10 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     if (!ctx) return FBG_ERR_INVALID;
     if (!ctx->d_msa) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_index_build: no MSA set");
     FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int st : {FBG_STAGE_SORT_PASS1, FBG_STAGE_SORT_PASS2, FBG_STAGE_SORT_PASS3, FBG_STAGE_RANK_KERNEL}) {   // (stages only some paths reach)
+        ctx->timers[st].recorded = false;
+        ctx->timers[st].launches = 0;
+    }
     ctx->index_valid = false;
     ctx->granked = false;
     ctx->spanned = false;

@@ -126,7 +126,8 @@ struct fbg_ctx {
 
     // scratch
     DevBuf keysA, keysB, valsA, valsB, grp, flags, list, tie_list, big_groups, tmp, small, scalars;
-    DevBuf kargs;              // arguments a kernel reads from memory (k_rank_scan_lean)
+    DevBuf kargs;              // arguments a kernel reads from memory (k_rank_scan_lean) ...
+    alignas(16) unsigned char kargs_host[512];   // ... and the host copy they are sent from
     DevBuf msd_w, msd_v;       // sub-bucket stretches of the MSD sort of 12-byte slots (msd_sort_pairs.hip)
     DevBuf dp_a, dp_b, dp_c, dp_d, dp_e, dp_f, dp_g, dp_h, io_a, io_b, io_c, io_d;
     DevBuf bt_up, bt_dep;      // binary-lifting tables of the parallel backtrack

@@ -503,7 +503,9 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 16, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SORT_PASS1));
     hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SORT_PASS1, 1));
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, st, a.count1, a.segcap, nseg, tile_start, flag);
     uint32_t tiles2 = 0;
     unsigned long long h_flag = 0;
@@ -516,7 +518,9 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     a.tiles2 = tiles2;
     a.tiles2_x = (xcd & 1) ? (tiles2 + 7) / 8 : 0;
     const unsigned grid2 = a.tiles2_x ? 8 * a.tiles2_x : tiles2;
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SORT_PASS2));
     hipLaunchKernelGGL(k_msd_split, dim3(grid2), dim3(MSD_THREADS), 0, st, a);
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SORT_PASS2, 1));
     // offsets of the sub-buckets in the sorted array: exclusive scan of their sizes
     unsigned long long *wide = reinterpret_cast<unsigned long long *>(ctx->keysA.p);   // scratch: pass 1's slots are dead
     hipLaunchKernelGGL(k_msd_widen, dim3(fbg_blocks(nsub, 256)), dim3(256), 0, st, a.count2, wide, nsub);
@@ -531,7 +535,9 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     }
     const int fshift = g.pb + rest - fbits;
     const uint32_t fmask = (uint32_t)((1u << fbits) - 1);
+    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SORT_PASS3));
     hipLaunchKernelGGL(k_msd_finish, dim3((unsigned)nsub), dim3(MSD_FN_THREADS), 0, st, a, fshift, fmask);
+    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SORT_PASS3, 1));
     unsigned long long h2[2] = {0, 0};
     FBG_HIP_TRY(ctx, hipMemcpyAsync(h2, flag, 16, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));

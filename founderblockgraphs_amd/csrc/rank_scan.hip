@@ -878,10 +878,11 @@ static int rs_classify(fbg_ctx *ctx, RankArgs &a, int layout, uint64_t *T_out, i
         FBG_TRY(fbg_reserve(ctx, ctx->ps_g, (size_t)rs_blocks * tie_region * 8));
         FBG_TRY(fbg_reserve(ctx, ctx->ps_h, (size_t)rs_blocks * 4));
         a.pairs = ctx->ps_g.as<uint2>(); a.pair_count = ctx->ps_h.as<uint32_t>();
-        // the scan's arguments travel through memory
+        // the scan's arguments travel through memory (the host copy lives in the context: nothing to wait for)
+        static_assert(sizeof(RankArgs) <= sizeof(ctx->kargs_host), "room for the scan's arguments");
         FBG_TRY(fbg_reserve(ctx, ctx->kargs, sizeof(RankArgs)));
-        FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->kargs.p, &a, sizeof(RankArgs), hipMemcpyHostToDevice, st));
-        FBG_HIP_TRY(ctx, hipStreamSynchronize(st));             // (a lives on this stack frame)
+        memcpy(ctx->kargs_host, &a, sizeof(RankArgs));
+        FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->kargs.p, ctx->kargs_host, sizeof(RankArgs), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_rank_scan_lean, dim3(rs_blocks), dim3(RL_THREADS), 0, st, (const RankArgs *)ctx->kargs.p, lf);
     }
     else

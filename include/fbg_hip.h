@@ -57,7 +57,10 @@ enum {
                                 is also contained in FBG_STAGE_SUFFIX_SORT) */
     FBG_STAGE_SCAN,          /* compute_f / v[] column scan (fbg.cpp:1579-1695, 552-611) */
     FBG_STAGE_DP,            /* bucket pass + DP sweep + backtrack (fbg.cpp:1940-2039, 616-664) */
-    FBG_STAGE_RANK_KERNEL,   /* the k_rank_scan launch alone (1 launch), for roofline accounting */
+    FBG_STAGE_RANK_KERNEL,   /* the k_rank_scan / k_rank_scan_lean launch alone (1 launch), for roofline accounting */
+    FBG_STAGE_SORT_PASS1,    /* the three kernels of the MSD sort alone, one launch each (k_msd_pack_split, k_msd_split, */
+    FBG_STAGE_SORT_PASS2,    /* k_msd_finish), for roofline accounting; 0 launches when another sort ran                */
+    FBG_STAGE_SORT_PASS3,
     FBG_STAGE_COUNT
 };
 
