@@ -1360,7 +1360,6 @@ def test_span_scan_leaves_many_large_slow_groups_to_the_record_path(engine):
     rows' first symbols) and its chains give up -- thousands of list entries for a few hundred groups, each a second of
     all-pairs comparisons.  By its own choice the library hands such an input to the record path (span_scan_used 0);
     with span_scan = 1 it insists, takes every listed group once, and is still exact (fbg.cpp:1579-1695)."""
-    import time
     import founderblockgraphs_amd as F
     rng = np.random.default_rng(424243)
     m, n = 1030, 1200
@@ -1372,7 +1371,6 @@ def test_span_scan_leaves_many_large_slow_groups_to_the_record_path(engine):
     f_on, f_off = O.compute_f(msa), O.compute_f(msa, disable_tricks=True)
     for forced in (0, 1):
         with fbg_options(engine, {"span_scan": forced}):
-            t0 = time.time()
             for tricks_off, ref in ((False, f_on), (True, f_off)):
                 try:
                     got = engine.elastic_f(msa, disable_efg_tricks=tricks_off)
@@ -1382,8 +1380,10 @@ def test_span_scan_leaves_many_large_slow_groups_to_the_record_path(engine):
             if forced:
                 assert engine.get_option("span_scan_used") == 1
             else:
+                # by its own choice: the record path (no wall-clock bound here -- a busy box would make it flake; what is
+                # asserted is the path taken)
+                assert engine.get_option("span_scan_used") == 0
                 assert engine.get_option("span_slow_groups") <= engine.get_option("span_groups")
-                assert time.time() - t0 < 5.0, time.time() - t0
 
 
 def test_span_scan_through_a_group_and_at_scale():
