@@ -175,7 +175,7 @@ static const OptKey g_opt_keys[] = {
     {"bp_min", &FbgOptions::bp_min}, {"record_scatter", &FbgOptions::record_scatter}, {"lcp_text", &FbgOptions::lcp_text},
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
-    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force}, {"msd_probe", &FbgOptions::msd_probe}, {"msd_xcd", &FbgOptions::msd_xcd}, {"rank_no_lean", &FbgOptions::rank_no_lean},
+    {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force}, {"msd_probe", &FbgOptions::msd_probe}, {"msd_xcd", &FbgOptions::msd_xcd}, {"rank_no_lean", &FbgOptions::rank_no_lean}, {"no_stream_upload", &FbgOptions::no_stream_upload},
     {"span_scan", &FbgOptions::span_scan},
 };
 
@@ -212,6 +212,7 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (strcmp(key, "grs_redone") == 0) { *value = (int64_t)ctx->grs_redone; return FBG_OK; }
     if (strcmp(key, "dp_kind") == 0) { *value = ctx->dp_kind; return FBG_OK; }
     if (strcmp(key, "msd_decline") == 0) { *value = ctx->msd_decline; return FBG_OK; }
+    if (strcmp(key, "pass1_ahead") == 0) { *value = ctx->pass1_ahead; return FBG_OK; }
     if (strcmp(key, "span_scan_used") == 0) { *value = (ctx->index_valid && ctx->granked && ctx->spanned) ? 1 : 0; return FBG_OK; }
     if (strcmp(key, "span_scan_work") == 0) { *value = (int64_t)ctx->sp_work; return FBG_OK; }
     if (strcmp(key, "span_groups") == 0) { *value = (int64_t)ctx->sp_G; return FBG_OK; }
@@ -282,6 +283,11 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
                       &ctx->sp_cells, &ctx->sp_cwin, &ctx->sp_tiles, &ctx->sp_gstart, &ctx->sp_gcol, &ctx->sp_gflags, &ctx->sp_rstart, &ctx->sp_rid,
                       &ctx->sp_gplo, &ctx->sp_gphi, &ctx->sp_gval, &ctx->sp_odd, &ctx->sp_irr, &ctx->sp_chain, &ctx->sp_slow, &ctx->sp_mins};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
+    if (ctx->up_stream) {
+        (void)hipStreamSynchronize(ctx->up_stream);
+        for (auto &e : ctx->up_ev) if (e) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(ctx->up_stream);
+    }
     for (auto &t : ctx->timers) {
         if (t.start) (void)hipEventDestroy(t.start);
         if (t.stop) (void)hipEventDestroy(t.stop);
@@ -555,8 +561,21 @@ int fbg_elastic_f(fbg_ctx *ctx, const uint8_t *msa, uint64_t m, uint64_t n, cons
 {
     if (!ctx) return FBG_ERR_INVALID;
     if (!f) return fbg_fail(ctx, FBG_ERR_INVALID, "fbg_elastic_f: null f");
-    FBG_TRY(fbg_msa_load_host(ctx, msa, m, n));
-    FBG_TRY(fbg_index_build(ctx, 0, ignore_chars, ignore_len));
+    if (msa && ignore_len == 0 && !ctx->opt.no_stream_upload && m * n >= FBG_STAGE_MIN && host_pointer_is_pinned(msa) && check_dims(ctx, m, n) == FBG_OK) {
+        // the rows go up in chunks while the index build starts on those that are there (text_build.hip)
+        FBG_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        FBG_TRY(fbg_reserve(ctx, ctx->msa_own, m * n));
+        ctx->d_msa = ctx->msa_own.as<uint8_t>(); ctx->m = m; ctx->n = n; ctx->index_valid = false;
+        ctx->up_host = msa;
+        const int rc = fbg_index_build(ctx, 0, ignore_chars, ignore_len);
+        ctx->up_host = nullptr;
+        if (ctx->up_stream) (void)hipStreamSynchronize(ctx->up_stream);   // (the caller's memory is free again whatever happened)
+        if (rc != FBG_OK) return rc;
+    } else {
+        FBG_TRY(fbg_msa_load_host(ctx, msa, m, n));
+        FBG_TRY(fbg_index_build(ctx, 0, ignore_chars, ignore_len));
+    }
     FBG_TRY(fbg_reserve(ctx, ctx->io_a, n * sizeof(uint64_t)));
     FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->io_a.p, f, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     FBG_TRY(fbg_scan_f(ctx, 0, n, disable_tricks, ctx->io_a.as<uint64_t>()));

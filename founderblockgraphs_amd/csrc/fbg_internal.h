@@ -37,7 +37,7 @@ struct StageTimer {
 struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
-            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0, msd_probe = 0, msd_xcd = -1, rank_no_lean = 0,
+            dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0, msd_probe = 0, msd_xcd = -1, rank_no_lean = 0, no_stream_upload = 0,
             span_scan = 0;
 };
 
@@ -58,6 +58,17 @@ struct fbg_ctx {
     const uint8_t *d_msa = nullptr;
     DevBuf msa_own;
     uint64_t m = 0, n = 0;
+
+    // a streamed upload (fbg_elastic_f from pinned host memory; text_build.hip): the MSA still on the host while the index build
+    // starts, pass 1 of the MSD sort done ahead on the alphabet the first chunk of rows promised (msd_sort.hip fbg_msd_pre_*)
+    const uint8_t *up_host = nullptr;
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_ev[9] = {};
+    bool pre_pass1 = false;
+    uint64_t pre_symbols[4] = {0, 0, 0, 0};   // the symbols (bytes of the text) the speculative keys were set up for
+    alignas(16) unsigned char pre_state[768]; // KeyGeom + the sort's arguments between fbg_msd_pre_begin and fbg_msd_sort
+    uint64_t pre_tiles = 0;                    // tiles of pass 1 launched so far
+    int pass1_ahead = 0;                       // the last MSD sort found its pass 1 done (fbg_get_option "pass1_ahead")
 
     // index state
     bool index_valid = false;
@@ -206,6 +217,9 @@ int fbg_rank_part_unfilled(fbg_ctx *ctx, uint64_t *unfilled);
 int fbg_rank_part_rescan(fbg_ctx *ctx);
 int fbg_part_sort(fbg_ctx *ctx, int part, int nparts, uint8_t *d_blob, int *ok);
 int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches);         // msd_sort.hip
+int fbg_msd_pre_begin(fbg_ctx *ctx, int *ok);                     // pass 1 ahead of the rest, on a text that is still arriving
+int fbg_msd_pre_pass1(fbg_ctx *ctx, uint64_t avail);              // ... over the tiles whose positions (and 64 beyond) are below avail
+bool fbg_msd_pre_geom(fbg_ctx *ctx, KeyGeom *g);                  // the key geometry it used, if pass 1 was done ahead
 int fbg_msd_sort_part(fbg_ctx *ctx, const KeyGeom &g, uint64_t lo, uint64_t hi, int nohi, int nparts, uint64_t out_offset,
                       uint64_t *count, int *ok, int *launches);                                       // msd_sort_pairs.hip                        // suffix_sort.hip
 int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches);                      // msd_sort_pairs.hip

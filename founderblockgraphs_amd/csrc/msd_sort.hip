@@ -49,6 +49,7 @@ struct MsdArgs {
     uint64_t segcap;
     unsigned long long *count1;                // [MSD_NB * xs]
     const uint32_t *tile_start;                // [MSD_NB * xs + 1]: first tile of every stretch (pass 2)
+    uint64_t tile0;                            // pass 1: the first tile of this launch
     uint32_t tiles2, tiles2_x;                 // pass 2: tiles in all; tiles per XCD when the tiles are dealt to the XCDs in ranges (0: in launch order)
     uint64_t *buf2;                            // pass 2 output: MSD_NB^2 stretches of MSD_FN_CAP slots
     uint32_t *count2;                          // [MSD_NB^2]
@@ -93,7 +94,7 @@ __device__ __forceinline__ void msd_pack_split_body(const MsdArgs &a, uint64_t *
 {
     uint8_t *tile = reinterpret_cast<uint8_t *>(buf);          // MSD_TILE + 64 bytes
     const int b = a.b, K = a.K;
-    const uint64_t base = (uint64_t)blockIdx.x * MSD_TILE;
+    const uint64_t base = ((uint64_t)blockIdx.x + a.tile0) * MSD_TILE;     // (tile0: pass 1 may come in pieces, fbg_msd_pre_pass1)
     msd_load_tile<MSD_TILE, FULL>(tile, cd, a.T, a.N, base);
     __syncthreads();
     // keys of the thread's MSD_ITEMS consecutive positions
@@ -459,15 +460,30 @@ __global__ __launch_bounds__(MSD_BIG_THREADS) void k_msd_finish_big(MsdArgs a, c
 // Sorts the packed slots of the current text by their key bits.  *ok = 0: a capacity was exceeded (keys spread
 // unevenly) or the geometry does not suit this sort -- nothing usable was produced.  On success *sorted points at
 // the N sorted words (inside ctx->keysA).
-int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches)
+// What the three passes work with, worked out from the key geometry and the text length; buffers reserved, counters zeroed
+struct MsdPlan {
+    KeyGeom g;
+    MsdArgs a;
+    uint64_t nsub;
+    uint32_t nseg;
+    int rest, fbits, xcd;
+    uint32_t *tile_start;
+    unsigned long long *off, *flag;
+};
+static_assert(sizeof(MsdPlan) <= sizeof(((fbg_ctx *)nullptr)->pre_state), "room for the plan of a sort begun ahead");
+
+// *ok = 0: the geometry does not suit this sort
+static int msd_plan(fbg_ctx *ctx, const KeyGeom &g, MsdPlan *p, int *ok)
 {
     *ok = 0;
-    ctx->msd_decline = 1;                                       // the geometry does not suit this sort
     const uint64_t N = ctx->N;
     const int rest = g.key_bits - 2 * MSD_DIG;                 // key bits left for the finish
     const uint64_t min_n = ctx->opt.msd_min >= 0 ? (uint64_t)ctx->opt.msd_min : (1ull << 24);   // tests lower it
     if (!g.packed || !g.compact || N < min_n || rest < 1 || ctx->opt.no_msd_sort) return FBG_OK;
-    if (N >= (1ull << 31)) return FBG_OK;                      // places inside a bucket are 32-bit (k_msd_pack_split)
+    // places inside a stretch are kept in 32 bits with wrap-around arithmetic (k_msd_pack_split: j + gdelta[d]), slot numbers of the
+    // scan behind it too: texts of 2^31 symbols and more go to rocPRIM's sort (what the arithmetic itself needs is
+    // cap1 + MSD_TILE < 2^32 -- the round limit is the documented one)
+    if (N >= (1ull << 31)) return FBG_OK;
     const int fbits = rest < MSD_FN_BITS ? rest : MSD_FN_BITS;
     // without enough bits for the bins the counting in the finish turns quadratic: leave those to rocPRIM
     if (fbits < 6) return FBG_OK;
@@ -486,26 +502,100 @@ int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int
     FBG_TRY(fbg_reserve(ctx, ctx->dp_d, (size_t)MSD_ARENA * 4 * 2));
     FBG_TRY(fbg_reserve(ctx, ctx->dp_e, (size_t)MSD_ARENA * 8 * 2));
     unsigned long long *flag = ctx->scalars.as<unsigned long long>() + 100;
-    MsdArgs a;
+    MsdArgs &a = p->a;
     a.T = ctx->text.as<uint8_t>(); a.N = N; a.code = g.d_code; a.b = g.b; a.K = g.K; a.pb = g.pb; a.kb = g.key_bits;
     a.buf1 = ctx->keysA.as<uint64_t>(); a.cap1 = cap1; a.xs = xs; a.segcap = cap1 / xs;
-    a.tiles2 = 0; a.tiles2_x = 0;
+    a.tile0 = 0; a.tiles2 = 0; a.tiles2_x = 0;
     a.count1 = ctx->dp_a.as<unsigned long long>();
-    uint32_t *tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + (size_t)nseg * 8);
-    a.tile_start = tile_start;
+    p->tile_start = reinterpret_cast<uint32_t *>(ctx->dp_a.as<uint8_t>() + (size_t)nseg * 8);
+    a.tile_start = p->tile_start;
     a.buf2 = ctx->keysB.as<uint64_t>();
     a.count2 = ctx->dp_b.as<uint32_t>();
-    unsigned long long *off = ctx->dp_c.as<unsigned long long>();
-    a.off = off;
+    p->off = ctx->dp_c.as<unsigned long long>();
+    a.off = p->off;
     a.out = ctx->keysA.as<uint64_t>();         // pass 1's slots are dead by then
     a.flag = flag;
     a.arena_sb = ctx->dp_d.as<uint32_t>(); a.arena_w = ctx->dp_e.as<uint64_t>(); a.arena_count = flag + 1; a.arena_cap = MSD_ARENA;
+    p->g = g; p->nsub = nsub; p->nseg = nseg; p->rest = rest; p->fbits = fbits; p->xcd = xcd; p->flag = flag;
     FBG_HIP_TRY(ctx, hipMemsetAsync(flag, 0, 16, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count1, 0, (size_t)nseg * 8, st));
     FBG_HIP_TRY(ctx, hipMemsetAsync(a.count2, 0, nsub * 4, st));
-    FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SORT_PASS1));
-    hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
-    FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SORT_PASS1, 1));
+    *ok = 1;
+    return FBG_OK;
+}
+
+// Pass 1 ahead of the rest of the index build, while the MSA is still arriving (text_build.hip, streamed upload): the keys are set
+// up for the alphabet ctx->byte_hist promises (the first chunk of rows, scaled); fbg_build_text checks the promise at the end
+// (ctx->pre_pass1) and fbg_msd_sort picks the plan up from ctx->pre_state.
+int fbg_msd_pre_begin(fbg_ctx *ctx, int *ok)
+{
+    *ok = 0;
+    if (ctx->have_ignore || ctx->reversed || ctx->opt.no_ranked) return FBG_OK;
+    int launches = 0;
+    KeyGeom g;
+    FBG_TRY(fbg_key_setup(ctx, true, &g, &launches));
+    MsdPlan plan;
+    int good = 0;
+    FBG_TRY(msd_plan(ctx, g, &plan, &good));
+    if (!good) return FBG_OK;
+    for (int w = 0; w < 4; w++) ctx->pre_symbols[w] = 0;
+    for (int b = 0; b < 256; b++) if (ctx->byte_hist[b]) ctx->pre_symbols[b >> 6] |= 1ull << (b & 63);
+    memcpy(ctx->pre_state, &plan, sizeof(plan));
+    ctx->pre_tiles = 0;
+    *ok = 1;
+    return FBG_OK;
+}
+
+int fbg_msd_pre_pass1(fbg_ctx *ctx, uint64_t avail)
+{
+    MsdPlan plan;
+    memcpy(&plan, ctx->pre_state, sizeof(plan));
+    const uint64_t N = plan.a.N;
+    // a tile reads MSD_TILE + 64 text positions
+    const uint64_t upto = avail >= N ? (N + MSD_TILE - 1) / MSD_TILE : (avail >= 64 ? (avail - 64) / MSD_TILE : 0);
+    if (upto <= ctx->pre_tiles) return FBG_OK;
+    plan.a.tile0 = ctx->pre_tiles;
+    hipLaunchKernelGGL(k_msd_pack_split, dim3((unsigned)(upto - ctx->pre_tiles)), dim3(MSD_THREADS), 0, ctx->stream, plan.a);
+    ctx->pre_tiles = upto;
+    return FBG_OK;
+}
+
+bool fbg_msd_pre_geom(fbg_ctx *ctx, KeyGeom *g)
+{
+    if (!ctx->pre_pass1) return false;
+    MsdPlan plan;
+    memcpy(&plan, ctx->pre_state, sizeof(plan));
+    *g = plan.g;
+    return true;
+}
+
+int fbg_msd_sort(fbg_ctx *ctx, const KeyGeom &g, uint64_t **sorted, int *ok, int *launches)
+{
+    *ok = 0;
+    ctx->msd_decline = 1;                                       // the geometry does not suit this sort
+    const uint64_t N = ctx->N;
+    hipStream_t st = ctx->stream;
+    MsdPlan plan;
+    const bool ahead = ctx->pre_pass1;                          // pass 1 ran while the MSA was uploaded (same g: fbg_msd_pre_geom)
+    ctx->pre_pass1 = false;
+    ctx->pass1_ahead = ahead ? 1 : 0;
+    if (ahead) memcpy(&plan, ctx->pre_state, sizeof(plan));
+    else {
+        int good = 0;
+        FBG_TRY(msd_plan(ctx, g, &plan, &good));
+        if (!good) return FBG_OK;
+    }
+    MsdArgs &a = plan.a;
+    const uint64_t nsub = plan.nsub;
+    const uint32_t nseg = plan.nseg;
+    const int rest = plan.rest, fbits = plan.fbits, xcd = plan.xcd;
+    uint32_t *tile_start = plan.tile_start;
+    unsigned long long *off = plan.off, *flag = plan.flag;
+    if (!ahead) {
+        FBG_TRY(fbg_stage_begin(ctx, FBG_STAGE_SORT_PASS1));
+        hipLaunchKernelGGL(k_msd_pack_split, dim3(fbg_blocks(N, MSD_TILE)), dim3(MSD_THREADS), 0, st, a);
+        FBG_TRY(fbg_stage_end(ctx, FBG_STAGE_SORT_PASS1, 1));
+    }
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, st, a.count1, a.segcap, nseg, tile_start, flag);
     uint32_t tiles2 = 0;
     unsigned long long h_flag = 0;

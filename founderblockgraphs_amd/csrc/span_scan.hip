@@ -1475,8 +1475,8 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
         }
         *launches += 4;
     }
+    const unsigned long long none = n;                          // (function scope: the copy below may read it until the stream is synchronised further down)
     if (disable_tricks) {
-        const unsigned long long none = n;
         FBG_HIP_TRY(ctx, hipMemcpyAsync(a.counters + 4, &none, 8, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_sp_row_ends, dim3(fbg_blocks(ctx->m, 256)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_sp_fill_ends, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, a);

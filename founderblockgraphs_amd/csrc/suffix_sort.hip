@@ -841,7 +841,8 @@ int fbg_suffix_sort(fbg_ctx *ctx)
 
     // ---- gap-free MSAs: compact keys, sort, and the whole extension scan in rank order (rank_scan.hip) -------
     if (ctx->gapfree && !ctx->have_ignore && !ctx->opt.no_ranked) {
-        FBG_TRY(fbg_key_setup(ctx, true, &g, &launches));
+        // (a streamed upload has set the keys up and run pass 1 of the sort already: same geometry)
+        if (!fbg_msd_pre_geom(ctx, &g)) FBG_TRY(fbg_key_setup(ctx, true, &g, &launches));
         bool similar = false;
         FBG_TRY(sample_says_similar(ctx, g, &similar, &launches));
         // packed slots of a large text: three-pass MSD sort fused with the key packing (msd_sort.hip); else, or when

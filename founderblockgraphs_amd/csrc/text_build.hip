@@ -57,7 +57,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
                                                           uint32_t *__restrict__ tot,
                                                           unsigned long long *__restrict__ scalars,
                                                           unsigned long long *__restrict__ hist,
-                                                          uint32_t *__restrict__ segcnt, uint8_t *__restrict__ T_copy)
+                                                          uint32_t *__restrict__ segcnt, uint8_t *__restrict__ T_copy, uint32_t row0 = 0)
 {
     // T_copy (optional; only when every row takes the 8-byte path: n and the MSA's address multiples of 8): the text of a
     // gap-free MSA -- row i at T + i * (n + 1), a '#' behind it -- is written along the way, from the very words the
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_row_count(const uint8_t *__restr
     typedef uint64_t u64_unaligned __attribute__((aligned(1)));
     __shared__ uint32_t red[2][TB_THREADS / 64];
     __shared__ uint32_t sh[256];
-    const uint64_t i = blockIdx.y;
+    const uint64_t i = (uint64_t)blockIdx.y + row0;           // (row0: the rows of one chunk of a streamed upload, fbg_build_text)
     const uint8_t *row = msa + i * n;
     const uint64_t x_lo = (uint64_t)blockIdx.x * RC_SEG, x_hi = min(n, x_lo + RC_SEG);
     const int lane = threadIdx.x & 63;
@@ -420,8 +420,59 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     // written by the counting pass itself from the words it loads (one read of the MSA instead of two)
     const bool fused = !ctx->reversed && n % 8 == 0 && ((uintptr_t)ctx->d_msa & 7) == 0 && m * (n + 1) + 1 < (1ull << 40);
     if (fused) FBG_TRY(fbg_reserve(ctx, ctx->text, m * (n + 1) + 1 + 64));
-    hipLaunchKernelGGL(k_row_count, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
-                       n, (const uint8_t *)nullptr, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt, fused ? ctx->text.as<uint8_t>() : (uint8_t *)nullptr);
+    const uint8_t *up = ctx->up_host;                           // fbg_elastic_f: the MSA is still in (pinned) host memory
+    ctx->up_host = nullptr;
+    ctx->pre_pass1 = false;
+    if (up && fused && m >= 16) {
+        // Streamed upload: the rows arrive in chunks on a copy stream of their own, and what needs nothing but the rows that are
+        // there runs behind every chunk -- the counting pass that also writes the text, and (speculatively: the alphabet and
+        // "no gaps" are taken from the first chunk and checked at the end, fbg_msd_pre_*) pass 1 of the MSD sort over the text
+        // positions that are complete.  The 1 GB upload of BASELINE config 3 takes 18 ms; 4 ms of the build hide behind it.
+        constexpr int CHUNKS = 8;
+        if (!ctx->up_stream) {
+            FBG_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+            for (auto &e : ctx->up_ev) FBG_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        uint8_t *d_msa = ctx->msa_own.as<uint8_t>();
+        FBG_HIP_TRY(ctx, hipEventRecord(ctx->up_ev[CHUNKS], st));                 // (the copies start after what the stream holds: memsets above)
+        FBG_HIP_TRY(ctx, hipStreamWaitEvent(ctx->up_stream, ctx->up_ev[CHUNKS], 0));
+        uint64_t r0s[CHUNKS + 1];
+        for (int c = 0; c <= CHUNKS; c++) r0s[c] = m * c / CHUNKS;
+        for (int c = 0; c < CHUNKS; c++) {
+            FBG_HIP_TRY(ctx, hipMemcpyAsync(d_msa + r0s[c] * n, up + r0s[c] * n, (r0s[c + 1] - r0s[c]) * n, hipMemcpyHostToDevice, ctx->up_stream));
+            FBG_HIP_TRY(ctx, hipEventRecord(ctx->up_ev[c], ctx->up_stream));
+        }
+        bool pre = false;
+        for (int c = 0; c < CHUNKS; c++) {
+            FBG_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->up_ev[c], 0));
+            hipLaunchKernelGGL(k_row_count, dim3(nseg, (unsigned)(r0s[c + 1] - r0s[c])), dim3(TB_THREADS), 0, st, ctx->d_msa,
+                               n, (const uint8_t *)nullptr, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt, ctx->text.as<uint8_t>(), (uint32_t)r0s[c]);
+            if (c == 0) {
+                unsigned long long h0[1];
+                FBG_HIP_TRY(ctx, hipMemcpyAsync(h0, sc, sizeof(h0), hipMemcpyDeviceToHost, st));
+                FBG_HIP_TRY(ctx, hipMemcpyAsync(ctx->byte_hist, d_hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+                FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+                if (h0[0] == 0) {
+                    // the whole MSA as the first chunk promises it: no gaps, these symbols in these proportions
+                    for (int b = 0; b < 256; b++) ctx->byte_hist[b] = ctx->byte_hist[b] * m / r0s[1];
+                    ctx->byte_hist['-'] = 0; ctx->byte_hist['#'] += m; ctx->byte_hist[0] += 1;
+                    ctx->N = m * (n + 1) + 1;
+                    ctx->gapfree = true;
+                    FBG_HIP_TRY(ctx, hipMemsetAsync(ctx->text.as<uint8_t>() + ctx->N - 1, 0, 65, st));
+                    int ok = 0;
+                    FBG_TRY(fbg_msd_pre_begin(ctx, &ok));
+                    pre = ok != 0;
+                }
+            }
+            if (pre) FBG_TRY(fbg_msd_pre_pass1(ctx, c + 1 < CHUNKS ? r0s[c + 1] * (n + 1) : ctx->N));
+        }
+        ctx->pre_pass1 = pre;
+        launches += CHUNKS - 1;
+    } else {
+        if (up) FBG_TRY(fbg_upload(ctx, ctx->msa_own.p, up, m * n));
+        hipLaunchKernelGGL(k_row_count, dim3(nseg, (unsigned)m), dim3(TB_THREADS), 0, st, ctx->d_msa,
+                           n, (const uint8_t *)nullptr, ctx->tot.as<uint32_t>(), sc, d_hist, segcnt, fused ? ctx->text.as<uint8_t>() : (uint8_t *)nullptr);
+    }
     hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(64), 0, st, ctx->tot.as<uint32_t>(), m,
                        ctx->pos.as<uint32_t>(), sc);
     launches += 2;
@@ -435,6 +486,12 @@ int fbg_build_text(fbg_ctx *ctx, const uint8_t *ignore, uint64_t ignore_len)
     ctx->byte_hist[0] += 1;
     ctx->gapfree = h[0] == 0;
     ctx->N = h[2];
+    if (ctx->pre_pass1) {
+        // what the first chunk promised: no gaps, and exactly the symbols the keys were set up for
+        bool same = ctx->gapfree && ctx->N == m * (n + 1) + 1;
+        for (int b = 0; b < 256 && same; b++) same = (ctx->byte_hist[b] != 0) == ((ctx->pre_symbols[b >> 6] >> (b & 63)) & 1ull);
+        ctx->pre_pass1 = same;
+    }
     if (ctx->N >= (1ull << 32) && !(ctx->allow_wide && ctx->gapfree && !ctx->reversed && !ctx->have_ignore && ctx->N < (1ull << 40)))
         return fbg_fail(ctx, FBG_ERR_TOO_LARGE, "text length %llu needs >32-bit positions (only the partitioned index of a "
                         "gap-free MSA, elastic scan, goes beyond)", h[2]);

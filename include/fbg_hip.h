@@ -44,9 +44,10 @@ enum {
     FBG_ERR_HASH_COLLISION = 7   /* fbg_block_graph only: use the caller's own label numbering instead */
 };
 
-#define FBG_MAX_ROWS 262144 /* fbg_block_graph only: a workgroup groups the labels of a block -- in LDS up to 4096 rows, in a
-                               stretch of device memory of its own beyond (more rows than this: FBG_ERR_TOO_LARGE, number the
-                               labels on the host).  The segmentation itself has no row limit. */
+#define FBG_MAX_ROWS 32768  /* fbg_block_graph only: a workgroup groups the labels of a block -- in LDS up to 4096 rows, in a
+                               stretch of device memory of its own beyond (exercised at 5000 rows; at this limit 512 workgroups
+                               hold 0.4 GB of such stretches and sort 32768 pairs each per block in device memory).  More rows:
+                               FBG_ERR_TOO_LARGE, number the labels on the host.  The segmentation itself has no row limit. */
 
 /* stage ids for fbg_stage_ms() */
 enum {
@@ -92,6 +93,9 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   msd_probe          1: the finish of the sample sort (k_pp_finish) also runs in timing variants (copy only, single phases) before
  *                      the real launch -- for a kernel trace read in launch order (scripts/gpu_trace_order.sh); results
  *                      unchanged.  (The three-pass MSD sort had such variants in round 3: profiles/r03_msd_probe_order.txt)
+ *   no_stream_upload   1: fbg_elastic_f copies the whole MSA to the device before the index build starts, also from memory of
+ *                      fbg_host_alloc (default: the rows go up in eight chunks while the text is written and pass 1 of the MSD sort
+ *                      runs on the rows that are there; results unchanged)
  *   rank_no_lean       1: the rank-order scan with k_rank_scan also where its lean form (k_rank_scan_lean: packed slots, threshold
  *                      above the key length) applies; results unchanged
  *   msd_xcd            which passes of the MSD sort place their writes by XCD (-1 = 3): bit 0 pass 2 (the tiles of a bucket
@@ -110,7 +114,8 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  * entries over windows of 1024 / 2048 / 4096 / 8192 / 16384 columns.
  * "msd_decline" (read-only): the three-pass MSD sort of the last index build: -1 not reached, 0 it sorted the slots, 1 the
  * geometry did not suit it (rocPRIM sorted), else the capacity that did not hold (2 / 4 a stretch of pass 1, 8 the arena
- * of pass 2, 16 a sub-bucket beyond the largest finish).
+ * of pass 2, 16 a sub-bucket beyond the largest finish).  "pass1_ahead" (read-only): 1 when that sort found its pass 1 done
+ * during a streamed upload (fbg_elastic_f from memory of fbg_host_alloc).
  * Unknown key: FBG_ERR_INVALID.
  */
 int fbg_set_option(fbg_ctx *ctx, const char *key, int64_t value);

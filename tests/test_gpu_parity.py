@@ -862,6 +862,38 @@ def test_msd_sort_gives_the_suffix_array(engine):
     assert torch.equal(fs[0], fs[1])
 
 
+def test_streamed_upload_equals_plain_upload(engine):
+    """fbg_elastic_f from memory of fbg_host_alloc sends the rows up in chunks and starts the build on those that are there
+    (text, pass 1 of the MSD sort on the alphabet the first chunk promises): same f as with the whole MSA uploaded first --
+    also when a later chunk breaks the promise (a new symbol, a gap) and the build starts over."""
+    import ctypes as C
+    from founderblockgraphs_amd import _lib
+    m, n = 64, 600_000
+    rng = np.random.default_rng(99)
+    L = _lib.lib()
+    p = L.fbg_host_alloc(m * n)
+    assert p
+    try:
+        pinned = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(m, n))
+        base = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (m, n))]
+        for variant in ("plain", "late_symbol", "late_gap"):
+            np.copyto(pinned, base)
+            if variant == "late_symbol":
+                pinned[m - 1, 12345] = ord("N")
+            if variant == "late_gap":
+                pinned[m - 2, 777:790] = ord("-")
+            with fbg_options(engine, {"no_stream_upload": 1}):
+                ref = engine.elastic_f(pinned)
+                assert engine.get_option("pass1_ahead") == 0
+            got = engine.elastic_f(pinned)
+            assert np.array_equal(got, ref), variant
+            assert engine.get_option("pass1_ahead") == (1 if variant == "plain" else 0), variant
+            if variant == "plain":
+                assert engine.get_option("msd_decline") == 0
+    finally:
+        L.fbg_host_free(C.c_void_p(p))
+
+
 def _block_graph_reference(msa, boundaries):
     """output_efg's numbering (fbg.cpp:1224-1260) with plain Python dicts: node_of, first_node, rep_row, edges."""
     m, n = msa.shape
