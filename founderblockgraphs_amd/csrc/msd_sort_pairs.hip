@@ -453,6 +453,11 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         return pp_t28(a, word) & (PP_FBINS - 1);
     };
     uint32_t bn[ITEMS];
+    // SIMPLE: the variants without a second look at crowded bins (the one most sub-buckets of a large text go through, and the
+    // partitions' sort): the counting runs in binned order, as in msd_sort.hip -- the bins' first slots are marked in a bitmap
+    constexpr bool SIMPLE = !(MODE == 1 && (ANY || CAP > PP_FN_SMALL));
+    __shared__ uint32_t bm[SIMPLE ? CAP / 32 + 2 : 1];
+    if (SIMPLE) for (uint32_t i = threadIdx.x; i < CAP / 32 + 2; i += PP_THREADS) bm[i] = 0;
     cnt[2 * threadIdx.x] = 0; cnt[2 * threadIdx.x + 1] = 0;    // PP_FBINS bins, two per thread
     __syncthreads();
     uint64_t w[ITEMS];
@@ -521,7 +526,52 @@ __device__ __forceinline__ void pp_finish_body(const PpArgs &a, uint64_t *sw, ui
         const uint32_t j = threadIdx.x + r * PP_THREADS;
         if (j < have) { const uint32_t at = loff[bn[r]] + rk[r]; sw[at] = w[r]; sv[at] = v[r]; }
     }
+    if (SIMPLE) {
+        // the first slot of every bin that has one, and the end of the slots
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t b = 2 * threadIdx.x + q;
+            if (cnt[b]) atomicOr(&bm[loff[b] >> 5], 1u << (loff[b] & 31));
+        }
+        if (threadIdx.x == 0) atomicOr(&bm[have >> 5], 1u << (have & 31));
+    }
     __syncthreads();
+    if (SIMPLE) {
+        // Every slot counts the smaller slots of its bin, taken in the order in which they lie in sw now: the lanes of a wave
+        // sit in the same few bins (the same words for all of them: no bank conflicts) and loop as often as the largest of
+        // those has slots.  (key, value) pairs compare as one 96-bit number: no branch for equal keys.
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * PP_THREADS;
+            if (j < have) {
+                const uint64_t y = sw[j];
+                const uint32_t yv = sv[j];
+                uint32_t wi = j >> 5, m = bm[wi] & (0xffffffffu >> (31 - (j & 31)));
+                while (!m) m = bm[--wi];                        // (slot 0 starts a bin: the walk ends)
+                const uint32_t b0 = wi * 32 + 31 - (uint32_t)__clz((int)m);
+                wi = (j + 1) >> 5; m = bm[wi] & (0xffffffffu << ((j + 1) & 31));
+                while (!m) m = bm[++wi];                        // (the end of the slots is marked: the walk ends)
+                const uint32_t e = wi * 32 + (uint32_t)__ffs((int)m) - 1;
+                const unsigned __int128 Y = ((unsigned __int128)y << 32) | yv;
+                uint32_t smaller = 0;
+                for (uint32_t q = b0; q < e; q++) smaller += ((((unsigned __int128)sw[q]) << 32) | sv[q]) < Y ? 1u : 0u;
+                w[r] = y; v[r] = yv; rk[r] = b0 + smaller;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * PP_THREADS;
+            if (j < have) { sw[rk[r]] = w[r]; sv[rk[r]] = v[r]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t j = threadIdx.x + r * PP_THREADS;
+            if (j < have) { wout[j] = sw[j]; if (!a.packed) vout[j] = sv[j]; }
+        }
+        return;
+    }
     // where every slot counts the smaller slots of its bin a bin of thousands is quadratic work -- MODE 1: the keys with a
     // rare symbol at the edge of a sub-bucket share one number.  Such a bin is split once more, on the 8 key bits from the
     // highest bit in which its smallest and largest key differ (monotone; even enough for a few hundred to a few thousand keys)
