@@ -222,7 +222,8 @@ def other_workloads(F, torch, dev):
                     best, stages = dt, {k: round(v[0], 3) for k, v in eng.stage_ms().items()}
             res.append({"workload": name, "rows": m, "cols": n, "ms_per_step": 1e3 * best, "columns_per_s": n / best,
                         "blocks": blocks, "stages_ms": stages, "index_kind": eng.get_option("index_kind"),
-                        "span_scan_used": eng.get_option("span_scan_used"), "dp_kind": eng.get_option("dp_kind")})
+                        "span_scan_used": eng.get_option("span_scan_used"), "span_key_flags_used": eng.get_option("span_key_flags_used"),
+                        "dp_kind": eng.get_option("dp_kind")})
 
     m, n = 1000, 200_000
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -251,6 +252,24 @@ def other_workloads(F, torch, dev):
         eng.msa_synthetic(d.data_ptr(), m, n, gap_fraction=0.05, gap_run=16, n_fraction=0.001)
         eng.sync()
     run("BASELINE config 5: synthetic 256 x 2000000, 5% gap runs of 16 + 0.1% N, --elastic --ignore-chars=N", m, n, d, ignore="N")
+    del d
+    # similar rows with gaps beyond 2^30 cells (2 * 10^9): the group-level scan with the slots' flags in the key word
+    # (span_key_flags_used; rounds 1-3: the record path, seconds)
+    m, n = 1000, 2_000_000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    anc = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.uint8)
+    d = torch.empty((m, n), dtype=torch.uint8, device="cuda")
+    for i0 in range(0, m, 5):
+        i1 = min(m, i0 + 5)
+        mut = torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.01
+        sub = torch.randint(0, 4, (i1 - i0, n), device="cuda", generator=g, dtype=torch.uint8)
+        d[i0:i1] = lut[torch.where(mut, sub, anc.expand(i1 - i0, n)).long()]
+        start = (torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.02 / 8).float().unsqueeze(1)
+        gap = torch.nn.functional.max_pool1d(torch.nn.functional.pad(start, (7, 0)), 8, 1).squeeze(1) > 0
+        d[i0:i1][gap] = ord("-")
+        del mut, sub, start, gap
+    torch.cuda.empty_cache()
+    run("star phylogeny 1000 x 2000000, p = 0.01, 2 % gap cells in runs of 8 (similar rows WITH gaps, 2 * 10^9 cells), --elastic", m, n, d.reshape(-1))
     return res
 
 

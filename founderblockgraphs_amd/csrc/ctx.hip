@@ -1,5 +1,6 @@
 // ctx.hip -- context, error plumbing, workspaces and the C-ABI entry points of include/fbg_hip.h.
 #include "fbg_internal.h"
+#include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
 #include <ctype.h>
@@ -26,6 +27,7 @@ int fbg_reserve(fbg_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 256;
     if (b.cap >= bytes) return FBG_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
     if (b.p) {
         FBG_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         FBG_HIP_TRY(ctx, hipFree(b.p));
@@ -41,6 +43,10 @@ int fbg_reserve(fbg_ctx *ctx, DevBuf &b, size_t bytes)
     }
     b.cap = want;
     ctx->held_bytes += want;
+    ctx->alloc_calls++;
+    ctx->alloc_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
+    // (debugging aid: fresh buffers full of a byte pattern instead of whatever the allocator hands out -- zeros, in a new process)
+    if (ctx->opt.poison) FBG_HIP_TRY(ctx, hipMemsetAsync(b.p, (int)(ctx->opt.poison & 255), want, ctx->stream));
     return FBG_OK;
 }
 
@@ -176,7 +182,7 @@ static const OptKey g_opt_keys[] = {
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
     {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force}, {"msd_probe", &FbgOptions::msd_probe}, {"msd_xcd", &FbgOptions::msd_xcd}, {"rank_no_lean", &FbgOptions::rank_no_lean}, {"no_stream_upload", &FbgOptions::no_stream_upload},
-    {"span_scan", &FbgOptions::span_scan},
+    {"span_scan", &FbgOptions::span_scan}, {"span_key_flags", &FbgOptions::span_key_flags}, {"span_slow_split", &FbgOptions::span_slow_split}, {"poison", &FbgOptions::poison},
 };
 
 // The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of
@@ -213,6 +219,10 @@ int fbg_get_option(const fbg_ctx *ctx, const char *key, int64_t *value)
     if (strcmp(key, "dp_kind") == 0) { *value = ctx->dp_kind; return FBG_OK; }
     if (strcmp(key, "msd_decline") == 0) { *value = ctx->msd_decline; return FBG_OK; }
     if (strcmp(key, "pass1_ahead") == 0) { *value = ctx->pass1_ahead; return FBG_OK; }
+    if (strcmp(key, "alloc_calls") == 0) { *value = (int64_t)ctx->alloc_calls; return FBG_OK; }
+    if (strcmp(key, "alloc_us") == 0) { *value = (int64_t)ctx->alloc_us; return FBG_OK; }
+    if (strcmp(key, "span_decline") == 0) { *value = ctx->sp_decline; return FBG_OK; }
+    if (strcmp(key, "span_key_flags_used") == 0) { *value = (ctx->index_valid && ctx->granked && ctx->spanned && ctx->sp_key_flags_sorted) ? 1 : 0; return FBG_OK; }
     if (strcmp(key, "span_scan_used") == 0) { *value = (ctx->index_valid && ctx->granked && ctx->spanned) ? 1 : 0; return FBG_OK; }
     if (strcmp(key, "span_scan_work") == 0) { *value = (int64_t)ctx->sp_work; return FBG_OK; }
     if (strcmp(key, "span_groups") == 0) { *value = (int64_t)ctx->sp_G; return FBG_OK; }
@@ -280,7 +290,7 @@ void fbg_ctx_destroy(fbg_ctx *ctx)
                       &ctx->dp_d, &ctx->dp_e, &ctx->dp_f, &ctx->dp_g, &ctx->dp_h, &ctx->io_a, &ctx->io_b,
                       &ctx->io_c, &ctx->io_d, &ctx->bt_up, &ctx->bt_dep, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d,
                       &ctx->ps_e, &ctx->ps_f, &ctx->ps_g, &ctx->ps_h, &ctx->gwin, &ctx->gbits, &ctx->gwin_rows,
-                      &ctx->sp_cells, &ctx->sp_cwin, &ctx->sp_tiles, &ctx->sp_gstart, &ctx->sp_gcol, &ctx->sp_gflags, &ctx->sp_rstart, &ctx->sp_rid,
+                      &ctx->sp_cells, &ctx->sp_flagT, &ctx->sp_cwin, &ctx->sp_tiles, &ctx->sp_gstart, &ctx->sp_gcol, &ctx->sp_gflags, &ctx->sp_rstart, &ctx->sp_rid,
                       &ctx->sp_gplo, &ctx->sp_gphi, &ctx->sp_gval, &ctx->sp_odd, &ctx->sp_irr, &ctx->sp_chain, &ctx->sp_slow, &ctx->sp_mins};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     if (ctx->up_stream) {
@@ -348,7 +358,7 @@ int fbg_release_scratch(fbg_ctx *ctx)
     DevBuf *bufs[] = {sorted_in_A ? &ctx->keysB : &ctx->keysA, &ctx->valsA, &ctx->grp, &ctx->flags, &ctx->list, &ctx->tie_list, &ctx->msd_w, &ctx->msd_v,
                       &ctx->tmp, &ctx->dp_a, &ctx->dp_b, &ctx->dp_c, &ctx->dp_d, &ctx->dp_e, &ctx->dp_f,
                       &ctx->dp_g, &ctx->dp_h, &ctx->ps_a, &ctx->ps_b, &ctx->ps_c, &ctx->ps_d, &ctx->ps_e, &ctx->ps_f,
-                      &ctx->ps_g, &ctx->ps_h, &ctx->sp_cells, &ctx->sp_tiles};
+                      &ctx->ps_g, &ctx->ps_h, &ctx->sp_cells, &ctx->sp_flagT, &ctx->sp_tiles};
     for (DevBuf *b : bufs) fbg_release(ctx, *b);
     return FBG_OK;
 }
@@ -408,7 +418,13 @@ int fbg_index_build(fbg_ctx *ctx, int reversed, const uint8_t *ignore_chars, uin
     FBG_TRY(fbg_build_text(ctx, reversed ? nullptr : ignore_chars, reversed ? 0 : ignore_len));
     FBG_TRY(fbg_suffix_sort(ctx));
     FBG_TRY(fbg_neighbour_lcp(ctx));
-    if (ctx->N > 1500000000ull) FBG_TRY(fbg_release_scratch(ctx));   // keep the footprint of huge indexes down
+    if (ctx->N > 1500000000ull) {
+        // keep the footprint of huge indexes down -- where the device is filling up: giving 50 GB back and taking them again costs
+        // the next build seconds of hipFree / hipMalloc (4.2 s measured for 2 * 10^9 symbols, ten times the build itself)
+        size_t free_b = 0, total_b = 0;
+        FBG_HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+        if (free_b < total_b / 2) FBG_TRY(fbg_release_scratch(ctx));
+    }
     ctx->index_valid = true;
     return FBG_OK;
 }

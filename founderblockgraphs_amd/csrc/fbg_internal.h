@@ -38,7 +38,7 @@ struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
             dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0, msd_probe = 0, msd_xcd = -1, rank_no_lean = 0, no_stream_upload = 0,
-            span_scan = 0;
+            span_scan = 0, span_key_flags = 0, span_slow_split = 0, poison = 0;
 };
 
 struct fbg_ctx {
@@ -115,6 +115,11 @@ struct fbg_ctx {
     // group-level scan on column spans for similar rows with gaps / ignore characters (span_scan.hip): `granked` and `spanned`
     bool spanned = false;
     DevBuf sp_cells;               // u32[N]: cell | flags of every text position, the payload of the sort
+    DevBuf sp_flagT;               // u8[N]: the flags alone where the cells take all 32 bits (sp_key_flags)
+    bool sp_key_flags = false;     // span scan: the flags W / I are the key words' two lowest bits (2^30 cells and more): the sort ahead
+    uint64_t alloc_calls = 0, alloc_us = 0;   // device allocations of the context so far and the host time they took (free + malloc)
+    int sp_decline = 0;            // why the group-level scan handed the slots back (0: it did not; include/fbg_hip.h "span_decline")
+    bool sp_key_flags_sorted = false;   // ... the sorted slots at hand
     DevBuf sp_cwin;                // 20 bytes per 128 cells of a row: text position of a cell
     DevBuf sp_tiles, sp_gstart, sp_gcol, sp_gflags, sp_rstart, sp_rid, sp_gplo, sp_gphi, sp_gval, sp_odd, sp_irr, sp_chain, sp_slow, sp_mins;
     uint32_t sp_chain_n = 0, sp_slow_n = 0;
@@ -204,7 +209,8 @@ int fbg_grs_strip(fbg_ctx *ctx, uint32_t *vals);
 int fbg_grs_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);             // gapped_rank.hip
 int fbg_grs_finish(fbg_ctx *ctx, uint64_t x0, uint64_t x1, int disable_tricks, uint64_t *d_out, int *ok);
 int fbg_grs_materialize(fbg_ctx *ctx, uint32_t *d_sa, uint32_t *d_isa, uint32_t *d_pl, uint32_t *d_pr);
-bool fbg_span_eligible(fbg_ctx *ctx, const KeyGeom &g);                                                 // span_scan.hip
+bool fbg_span_eligible(fbg_ctx *ctx, const KeyGeom &g);
+bool fbg_span_key_flags(fbg_ctx *ctx, KeyGeom &g);                                                 // span_scan.hip
 int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches);
 int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g, int *done);
 int fbg_span_rescan(fbg_ctx *ctx, int disable_tricks, int *ok);

@@ -1012,6 +1012,7 @@ int fbg_sample_sort_pairs(fbg_ctx *ctx, const KeyGeom &g, int *ok, int *launches
     const uint64_t nsub = (uint64_t)PP_NB * PP_NB;
     // sub-bucket sizes follow the sample (2^22 keys, 16 per sub-bucket: +-25 %): they must fit their stretches twice over
     if (g.compact || g.packed || g.wide || N < min_n || N >= (1ull << 32) || ctx->opt.no_msd_sort || g.key_bits >= 64) return FBG_OK;
+    if (ctx->sp_key_flags) return FBG_OK;                  // (span_scan.hip beyond 2^30 cells: flag bits below the key; such texts are beyond the next line anyway)
     if (2 * (N / nsub) + 64 > PP_FN_CAP) return FBG_OK;
     hipStream_t st = ctx->stream;
     uint64_t S = 1ull << 22;

@@ -59,6 +59,7 @@ struct SpArgs {
     uint64_t N;
     uint32_t n, m, row_len, magic;   // row_len = n + 1; magic = floor(2^32 / row_len)
     int b, K, key_bits, disable_tricks;
+    int ksh;                         // 0: the flags W / I in the values' top bits; 2: in the key words' low bits (2^30 cells and more)
     const uint8_t *T;
     const uint32_t *colT, *pos, *tot;   // colT = nullptr: rows without gaps (cell == text position)
     const CWin *cwin;
@@ -103,9 +104,17 @@ __device__ __forceinline__ uint32_t sp_key_lcp(uint64_t a, uint64_t c, int b, in
     return (bits * ((65536u + (uint32_t)b - 1) / (uint32_t)b)) >> 16;
 }
 
+// The flags of a slot.  (m + 1) * (n + 1) < 2^30: bits 30 and 31 of its value.  Beyond that the value is the cell alone and the
+// flags are the two lowest bits of the key word, below the K symbols (ksh = 2: fbg_span_prepare).
+__device__ __forceinline__ uint64_t sp_key(const SpArgs &a, uint64_t slot) { return a.keys[slot] >> a.ksh; }
+__device__ __forceinline__ uint32_t sp_fl(const SpArgs &a, uint64_t slot, uint32_t v)
+{
+    return a.ksh ? (uint32_t)(a.keys[slot] & 3ull) << 30 : v & ~SP_CELL;
+}
+
 __device__ __forceinline__ void sp_decode(const SpArgs &a, uint32_t v, uint32_t &row, uint32_t &col)
 {
-    const uint32_t c = v & SP_CELL;
+    const uint32_t c = a.ksh ? v : v & SP_CELL;
     row = __umulhi(c, a.magic);
     col = c - row * a.row_len;
     if (col >= a.row_len) { col -= a.row_len; row++; }
@@ -235,7 +244,8 @@ __global__ __launch_bounds__(64) void k_sp_cwin_scan(uint32_t wpr, CWin *__restr
 // separators passed.
 #define SPC_CHUNKS 8
 __global__ __launch_bounds__(256) void k_sp_cells(const uint32_t *__restrict__ colT, const uint32_t *__restrict__ pos, uint64_t N, uint32_t n, uint32_t m,
-                                                  int K, const unsigned long long *__restrict__ ebits, uint32_t *__restrict__ cellT)
+                                                  int K, const unsigned long long *__restrict__ ebits, uint32_t *__restrict__ cellT,
+                                                  uint8_t *__restrict__ flagT)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -274,22 +284,24 @@ __global__ __launch_bounds__(256) void k_sp_cells(const uint32_t *__restrict__ c
         uint32_t w = (bits & 1ull) ? SP_W : 0u;
         uint32_t i = ((bits >> 1) & ((1ull << (K - 1)) - 1)) ? SP_I : 0u;
         if (col >= n) w = i = 0;                               // '#' / sentinel: no flags (the column says what they are)
-        cellT[p] = (row * (n + 1) + col) | w | i;
+        if (flagT) { cellT[p] = row * (n + 1) + col; flagT[p] = (uint8_t)((w | i) >> 30); }    // (2^30 cells and more: the flags join the key word)
+        else cellT[p] = (row * (n + 1) + col) | w | i;
     }
 }
 
 // the values back to text positions (the record path reads them as the suffix array)
-__global__ void k_sp_to_positions(SpArgs a, uint32_t *__restrict__ vals)
+__global__ void k_sp_to_positions(SpArgs a, uint32_t *__restrict__ vals, uint64_t *__restrict__ keys)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.N) return;
     uint32_t row, col;
     sp_decode(a, vals[k], row, col);
     vals[k] = sp_pos(a, row, col);
+    if (a.ksh) keys[k] >>= a.ksh;                              // (and the key words without the flags)
 }
 
 __global__ void k_sp_check(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ cells, uint64_t N,
-                           unsigned long long *__restrict__ out)
+                           unsigned long long *__restrict__ out, int ksh)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
@@ -297,7 +309,7 @@ __global__ void k_sp_check(const uint64_t *__restrict__ keys, const uint32_t *__
     atomicAdd(&out[1], (unsigned long long)cells[k]);
     atomicXor(&out[2], (unsigned long long)vals[k] * 0x9E3779B97F4A7C15ull);
     atomicXor(&out[3], (unsigned long long)cells[k] * 0x9E3779B97F4A7C15ull);
-    if (k > 0 && keys[k] < keys[k - 1]) atomicAdd(&out[4], 1ull);
+    if (k > 0 && (keys[k] >> ksh) < (keys[k - 1] >> ksh)) atomicAdd(&out[4], 1ull);
 }
 
 // ---- groups: maximal stretches of equal keys --------------------------------------------------------------------
@@ -327,18 +339,21 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_groups(S
     uint32_t v[SP_ITEMS + 1];
     {
         const bool ok = k0 > 0 && k0 - 1 < N;
-        key[0] = ok ? a.keys[k0 - 1] : 0ull;
+        key[0] = ok ? a.keys[k0 - 1] >> a.ksh : 0ull;
         v[0] = (FILL && ok) ? a.vals[k0 - 1] : 0u;
     }
-    uint32_t heads = 0, irr = 0;
+    uint32_t heads = 0, irr = 0, wide = 0;
 #pragma unroll
     for (int j = 0; j < SP_ITEMS; j++) {
         const uint64_t k = k0 + j;
         const bool ok = k < N;
-        key[j + 1] = ok ? a.keys[k] : 0ull;
+        const uint64_t word = ok ? a.keys[k] : 0ull;
+        key[j + 1] = word >> a.ksh;
         v[j + 1] = ok ? a.vals[k] : 0u;
+        const uint32_t fl = a.ksh ? (uint32_t)(word & 3ull) << 30 : v[j + 1] & ~SP_CELL;
         if (ok && (k == 0 || key[j + 1] != key[j])) heads |= 1u << j;
-        if (ok && (v[j + 1] & SP_I)) irr |= 1u << j;
+        if (ok && (fl & SP_I)) irr |= 1u << j;
+        if (ok && (fl & SP_W)) wide |= 1u << j;
     }
     unsigned long long total;
     const unsigned long long before = sp_block_excl((unsigned long long)__popc(heads) | ((unsigned long long)__popc(irr) << 32), &total, lds);
@@ -374,8 +389,8 @@ template <bool FILL> __global__ __launch_bounds__(SP_THREADS) void k_sp_groups(S
         } else if (col != pcol) acc |= SPG_ODD;
         if (sep) acc |= SPG_SEP;
         else {
-            if (v[j + 1] & SP_W) acc |= SPG_ODD;
-            acc |= (v[j + 1] & SP_I) ? SPG_IRR : SPG_REG;
+            if ((wide >> j) & 1u) acc |= SPG_ODD;
+            acc |= ((irr >> j) & 1u) ? SPG_IRR : SPG_REG;
             if ((irr >> j) & 1u) a.irr[iat++] = make_uint2((uint32_t)k, gid);
         }
         pcol = col;
@@ -477,8 +492,9 @@ __global__ __launch_bounds__(256) void k_sp_odd_spans(SpArgs a, const uint32_t *
             uint32_t row, col, lo, hi;
             sp_decode(a, v, row, col);
             lo = hi = col;
-            if (v & SP_W) sp_wide_span(a, row, col, sp_pos(a, row, col), lo, hi);
-            if ((v & SP_W) || col != c0) nodd++;
+            const bool wide = sp_fl(a, s0 + i, v) & SP_W;
+            if (wide) sp_wide_span(a, row, col, sp_pos(a, row, col), lo, hi);
+            if (wide || col != c0) nodd++;
             if (lo > hi) { lo_max = SP_NONE; hi_min = 0; }       // a member that is never coloured
             lo_max = max(lo_max, lo); hi_min = min(hi_min, hi);
         }
@@ -517,7 +533,7 @@ __device__ uint32_t sp_outside(const SpArgs &a, uint64_t g, uint64_t key, uint32
             h = dir < 0 ? a.rstart[run] : a.rstart[run + 1] - 1;
             continue;
         }
-        return sp_key_lcp(key, a.keys[a.gstart[h]], a.b, a.key_bits);
+        return sp_key_lcp(key, sp_key(a, a.gstart[h]), a.b, a.key_bits);
     }
 }
 
@@ -532,11 +548,11 @@ __global__ void k_sp_values(SpArgs a)
         // an odd group whose pure interval is one column: g there, for its workgroup to pick up (the walk is a chain of
         // dependent reads that one thread of a workgroup would make with the other 255 waiting)
         const uint32_t x = a.gplo[g];
-        if (x == a.gphi[g]) { const uint64_t key = a.keys[a.gstart[g]]; a.gval[g] = 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1)); }
+        if (x == a.gphi[g]) { const uint64_t key = sp_key(a, a.gstart[g]); a.gval[g] = 1 + max(sp_outside(a, g, key, x, -1), sp_outside(a, g, key, x, +1)); }
         return;
     }
     const uint32_t x = a.gcol[g];
-    const uint64_t key = a.keys[a.gstart[g]];
+    const uint64_t key = sp_key(a, a.gstart[g]);
     const uint32_t run = a.rid[g];
     // (the groups of the run are coloured along: start beyond it)
     const uint32_t gv = 1 + max(sp_outside(a, a.rstart[run], key, x, -1), sp_outside(a, (uint64_t)a.rstart[run + 1] - 1, key, x, +1));   // 1656
@@ -558,7 +574,7 @@ __global__ void k_sp_irr(SpArgs a)
     uint32_t row, col;
     sp_decode(a, a.vals[sg.x], row, col);
     const uint32_t p = sp_pos(a, row, col);
-    sp_update(a, col, sp_extent(a, p, row, gv, sp_key_first_ignore(a, a.keys[sg.x], gv)));
+    sp_update(a, col, sp_extent(a, p, row, gv, sp_key_first_ignore(a, sp_key(a, sg.x), gv)));
 }
 
 // ---- the odd groups: one workgroup each ---------------------------------------------------------------------------
@@ -624,12 +640,12 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd(SpArgs
         for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
             uint32_t row, col;
             sp_decode(a, sv[i], row, col);
-            if ((sv[i] & SP_W) || col != major) {
+            if ((sp_fl(a, s0 + i, sv[i]) & SP_W) || col != major) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
                 if (o < SP_MAX_ODD) {
                     const uint32_t p = sp_pos(a, row, col);
                     uint32_t lo = col, hi = col;
-                    if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+                    if (sp_fl(a, s0 + i, sv[i]) & SP_W) sp_wide_span(a, row, col, p, lo, hi);
                     oidx[o] = (uint16_t)i; olo[o] = lo; ohi[o] = hi; opos[o] = p;
                 }
             }
@@ -638,7 +654,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd(SpArgs
         const uint32_t no = n_odd;
         if (no > SP_MAX_ODD) { if (threadIdx.x == 0) a.counters[3] = 1; continue; }
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
-        const uint64_t key = a.keys[s0];
+        const uint64_t key = sp_key(a, s0);
         const bool has_narrow = no < s;
         // -- the pure interval (usually one column, the majority's): every member is coloured, keys decide
         for (uint32_t x = plo; x <= phi && plo <= phi; x++) {
@@ -650,7 +666,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd(SpArgs
             for (uint32_t i = threadIdx.x; i < s; i += SP_THREADS) {
                 uint32_t row, col;
                 sp_decode(a, sv[i], row, col);
-                const uint32_t fi = (sv[i] & SP_I) ? sp_extent(a, sp_pos(a, row, col), row, gv, kign) : col + (kign < gv ? kign : gv - 1);
+                const uint32_t fi = (sp_fl(a, s0 + i, sv[i]) & SP_I) ? sp_extent(a, sp_pos(a, row, col), row, gv, kign) : col + (kign < gv ? kign : gv - 1);
                 sp_update(a, x, fi);
             }
         }
@@ -725,11 +741,11 @@ __device__ uint32_t sp_chain_max(const SpArgs &a, uint32_t pq, const uint32_t *e
             for (int k = k0; k < a.K && k < k0 + 8; k++) key = (key << a.b) | (t + k < a.N ? (uint64_t)a.code[(x >> (8 * (k - k0))) & 255u] : 0ull);
         }
         uint64_t lo = 0, hi = a.N;                             // first slot whose key is not below
-        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a.keys[mid] < key) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (sp_key(a, mid) < key) lo = mid + 1; else hi = mid; }
         uint32_t best = L;
         bool all = true;
         for (uint64_t k = lo; k < a.N; k++) {
-            if (a.keys[k] != key) break;
+            if (sp_key(a, k) != key) break;
             if (k - lo >= SP_CHAIN_SCAN) { all = false; break; }
             uint32_t row, col;
             sp_decode(a, a.vals[k], row, col);
@@ -791,7 +807,11 @@ __global__ void k_sp_chain(SpArgs a, uint32_t count, int pass)
 
 #define SP_WIN 128u
 
-template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t min_size)
+// (split: a group's odd members are dealt to that many workgroups -- two columns of a long MSA whose K symbols agree make a
+// group of twice the rows with half of them odd, 125 ms for one workgroup; what the members of the majority column get from
+// the odd members is a maximum, which the column maxima take from the parts as well)
+template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(SpArgs a, const uint32_t *__restrict__ list, uint32_t count, uint32_t min_size,
+                                                                                uint32_t split)
 {
     __shared__ uint32_t sv[CAP], sp[CAP], nbest[CAP];
     __shared__ uint16_t omap[CAP];                             // member -> its place in the odd list (0xffff: a member of the majority)
@@ -800,7 +820,8 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
     __shared__ uint32_t n_odd, n_col, s_mn, s_any, s_gmax, s_ign, votes[8];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t sub = lane >> 4, sl = lane & 15;            // mate of the wave's four, place in its 128-byte window
-    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+    for (uint64_t item = blockIdx.x; item < (uint64_t)count * split; item += gridDim.x) {
+        const uint32_t e = (uint32_t)(item / split), part = (uint32_t)(item % split);
         const uint32_t g = list[e];
         if (e > 0 && list[e - 1] == g) continue;               // (the big groups' list is sorted: a group that several chains gave up on is in it once per chain)
         const uint32_t s0 = a.gstart[g], s = a.gstart[g + 1] - s0;
@@ -816,7 +837,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
             const uint32_t p = sp_pos(a, row, col);
             sp[i] = p;
             uint32_t lo = col, hi = col;                        // (odd: as in k_sp_odd_pairs)
-            if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+            if (sp_fl(a, s0 + i, sv[i]) & SP_W) sp_wide_span(a, row, col, p, lo, hi);
             if (col != major || lo != col || hi != col) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
                 if (lo <= hi) atomicAdd(&n_col, 1u);
@@ -836,6 +857,7 @@ template <int CAP> __global__ __launch_bounds__(SP_THREADS) void k_sp_odd_slow(S
         // -- the other columns of the odd members, one odd member after the other
         for (uint32_t o = 0; o < no; o++) {
             const uint32_t q = oidx[o], pq = sp[q], lo = olo[o], hi = ohi[o];
+            if (q % split != part) continue;                   // (by the member's place in the group: the odd list's order differs from workgroup to workgroup)
             const bool at_major = lo <= major && major <= hi;  // coloured at the majority column: no partner for its members there
             const bool own = lo <= hi && (plo > phi || lo < plo || hi > phi);   // has columns outside the pure interval
             if (!own && (at_major || !has_narrow)) continue;   // (uniform over the workgroup)
@@ -1006,7 +1028,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
             // odd: another column than the majority's, or a span that is not just its column (a W member whose span
             // IS its column -- a row's first symbol at column 0 with the tricks off -- is a member like any other)
             uint32_t lo = col, hi = col;
-            if (sv[i] & SP_W) sp_wide_span(a, row, col, p, lo, hi);
+            if (sp_fl(a, s0 + i, sv[i]) & SP_W) sp_wide_span(a, row, col, p, lo, hi);
             if (col != major || lo != col || hi != col) {
                 const uint32_t o = atomicAdd(&n_odd, 1u);
                 if (lo <= hi) atomicAdd(&n_col, 1u);
@@ -1022,7 +1044,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
         const uint32_t no = n_odd;
         if (no == s && n_col == 0) continue;                   // nobody is ever coloured (the first symbols of more than MAXO rows, tricks on): nothing to say
         const uint32_t plo = a.gplo[g], phi = a.gphi[g];
-        const uint64_t key = a.keys[s0];
+        const uint64_t key = sp_key(a, s0);
         const bool has_narrow = no < s;
         // -- the pure interval (usually one column, the majority's): every member is coloured, keys decide
         for (uint32_t x = plo; x <= phi && plo <= phi; x++) {
@@ -1038,8 +1060,8 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
             for (uint32_t i = threadIdx.x; i < s; i += NT) {
                 uint32_t row, col;
                 sp_decode(a, sv[i], row, col);
-                if (!(sv[i] & SP_I) && col == major) { reg_major = true; continue; }
-                const uint32_t fi = (sv[i] & SP_I) ? sp_extent(a, sp[i], row, gv, kign) : col + step;
+                if (!(sp_fl(a, s0 + i, sv[i]) & SP_I) && col == major) { reg_major = true; continue; }
+                const uint32_t fi = (sp_fl(a, s0 + i, sv[i]) & SP_I) ? sp_extent(a, sp[i], row, gv, kign) : col + step;
                 sp_update(a, x, fi);
             }
             if (__ballot(reg_major) && (threadIdx.x & 63) == 0) sp_update(a, x, major + step);
@@ -1051,7 +1073,7 @@ void sp_odd_pairs_body(const SpArgs a, const uint32_t *__restrict__ list, uint32
                 if (at < a.slow_cap) a.slow[at] = g; else a.counters[3] = 1;
                 if (CAP > 1024) {                              // what the slow kernel has ahead in the large groups (the host decides)
                     atomicAdd(&a.counters[32], (unsigned long long)no * s);
-                    if (no > 256) a.counters[33] = 1;
+                    if (no > 256) atomicAdd(&a.counters[33], 1ull);
                 }
             }
             continue;
@@ -1303,6 +1325,7 @@ static void sp_args(fbg_ctx *ctx, SpArgs &a, int disable_tricks)
     a.n = (uint32_t)ctx->n; a.m = (uint32_t)ctx->m; a.row_len = (uint32_t)(ctx->n + 1);
     a.magic = (uint32_t)((1ull << 32) / (ctx->n + 1));
     a.b = ctx->rk_b; a.K = ctx->rk_K; a.key_bits = ctx->rk_key_bits; a.disable_tricks = disable_tricks;
+    a.ksh = ctx->sp_key_flags_sorted ? 2 : 0;
     a.T = ctx->text.as<uint8_t>();
     a.colT = ctx->gapfree ? nullptr : ctx->colT.as<uint32_t>();
     a.pos = ctx->pos.as<uint32_t>(); a.tot = ctx->tot.as<uint32_t>();
@@ -1331,18 +1354,30 @@ bool fbg_span_eligible(fbg_ctx *ctx, const KeyGeom &g)
     if (ctx->opt.span_scan == -1 || ctx->grs_skip || ctx->reversed) return false;   // (span_scan = 2: as 0, plus a check of the sort)
     if (ctx->gapfree && !ctx->have_ignore) return false;
     if (g.compact || g.packed || g.wide || g.K > 32 || g.K < 2) return false;
-    if ((ctx->m + 1) * (ctx->n + 1) >= (1ull << 30) || ctx->m >= 65535) return false;
+    // the cell is the sort's 32-bit value; from 2^30 cells on its two flags move into the key word (fbg_span_key_flags)
+    if ((ctx->m + 1) * (ctx->n + 1) >= (1ull << 32) || ctx->m >= 65535) return false;
     if (ctx->have_ignore && ctx->ignore_tab[(unsigned char)'-']) return false;          // gap cells that clamp: the record path's per-cell table
     return true;
 }
 
+// 2^30 cells and more: the flags W / I do not fit beside the cell.  They become the two lowest bits of the key word, below
+// the symbols (a key of more than 62 bits gives up its last symbol for them: the caller's geometry changes).  The sort
+// orders by the symbols alone; the scan shifts them away (SpArgs::ksh).
+bool fbg_span_key_flags(fbg_ctx *ctx, KeyGeom &g)
+{
+    const bool want = (ctx->m + 1) * (ctx->n + 1) >= (1ull << 30) || ctx->opt.span_key_flags;
+    if (want && g.key_bits > 62) { g.K -= 1; g.key_bits -= g.b; }
+    return want;
+}
+
 // Before the sort (fbg_grs_prepare has made the bitmap of irregular positions): the payload of every text position ->
-// ctx->sp_cells, the window table of the cells.
+// ctx->sp_cells (and ctx->sp_flagT), the window table of the cells.
 int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches)
 {
     const uint64_t N = ctx->N, n = ctx->n, m = ctx->m;
     hipStream_t st = ctx->stream;
     FBG_TRY(fbg_reserve(ctx, ctx->sp_cells, N * 4));
+    if (ctx->sp_key_flags) FBG_TRY(fbg_reserve(ctx, ctx->sp_flagT, N));
     if (!ctx->gapfree) {
         const uint32_t wpr = (uint32_t)((n + 127) / 128);
         FBG_TRY(fbg_reserve(ctx, ctx->sp_cwin, (size_t)m * wpr * sizeof(CWin)));
@@ -1353,7 +1388,8 @@ int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches)
         *launches += 2;
     }
     hipLaunchKernelGGL(k_sp_cells, dim3(fbg_blocks(N, 256 * SPC_CHUNKS)), dim3(256), 0, st, ctx->gapfree ? (const uint32_t *)nullptr : ctx->colT.as<uint32_t>(),
-                       ctx->pos.as<uint32_t>(), N, (uint32_t)n, (uint32_t)m, g.K, ctx->gbits.as<unsigned long long>(), ctx->sp_cells.as<uint32_t>());
+                       ctx->pos.as<uint32_t>(), N, (uint32_t)n, (uint32_t)m, g.K, ctx->gbits.as<unsigned long long>(), ctx->sp_cells.as<uint32_t>(),
+                       ctx->sp_key_flags ? ctx->sp_flagT.as<uint8_t>() : (uint8_t *)nullptr);
     *launches += 1;
     FBG_HIP_TRY(ctx, hipGetLastError());
     return FBG_OK;
@@ -1363,6 +1399,7 @@ int fbg_span_prepare(fbg_ctx *ctx, const KeyGeom &g, int *launches)
 static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
 {
     *ok = 0;
+    ctx->sp_decline = 0;
     hipStream_t st = ctx->stream;
     const uint64_t n = ctx->n, G = ctx->sp_G;
     SpArgs a;
@@ -1382,7 +1419,8 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     *launches += 2;
     ctx->sp_work = h[0];
     // text comparisons ahead (odd members x group size): beyond a few dozen per suffix of the text the record path is cheaper
-    if (h[1] != 0 || h[0] > std::max<unsigned long long>(32 * ctx->N, 1ull << 26)) return FBG_OK;
+    if (h[1] != 0) { ctx->sp_decline = 1; return FBG_OK; }
+    if (h[0] > std::max<unsigned long long>(32 * ctx->N, 1ull << 26)) { ctx->sp_decline = 2; return FBG_OK; }
     // the larger groups' odd members: a list for those that are coloured alone, a list of the groups that need every pair compared
     const uint64_t members = h[3];
     FBG_TRY(fbg_reserve(ctx, ctx->sp_chain, (members + 1) * sizeof(SpChain)));
@@ -1417,7 +1455,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
         // the groups with more odd members than that kernel takes: every pair the slow way
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (h[1] != 0) return FBG_OK;
+        if (h[1] != 0) { ctx->sp_decline = 3; return FBG_OK; }
         const uint32_t n_slow = (uint32_t)h[5];
         ctx->sp_slow_n = n_slow;
         // (a large group on the slow list has more odd members than the kernel above takes -- a deletion in dozens of a few
@@ -1429,12 +1467,18 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
             unsigned long long ahead[2] = {0, 0};
             FBG_HIP_TRY(ctx, hipMemcpyAsync(ahead, a.counters + 32, sizeof(ahead), hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-            if (ahead[1] != 0 || ahead[0] > 64 * ctx->N) return FBG_OK;
+            // (ahead[1]: the large groups with more than 256 odd members.  A long MSA has some by chance -- two columns whose K
+            // symbols agree make one group of twice the rows, half of them "odd"; their number grows with the square of the
+            // columns -- and they run side by side, a workgroup each: up to one per 2^22 suffixes is accepted)
+            if (ahead[1] > (ctx->N >> 22) || ahead[0] > 64 * ctx->N) { ctx->sp_decline = 4; return FBG_OK; }
         }
         if (n_slow) {
-            hipLaunchKernelGGL((k_sp_odd_slow<1024>), dim3(std::min<uint32_t>(n_slow, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow, 0u);
-            if (n_big && !big_chains)
-                hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow, 1024u);
+            hipLaunchKernelGGL((k_sp_odd_slow<1024>), dim3(std::min<uint32_t>(n_slow, 1u << 20)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow, n_slow, 0u, 1u);
+            if (n_big && !big_chains) {
+                const uint32_t split = ctx->opt.span_slow_split > 0 ? (uint32_t)ctx->opt.span_slow_split : 32u;
+                hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3((unsigned)std::min<uint64_t>((uint64_t)n_slow * split, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)a.slow,
+                                   n_slow, 1024u, split);
+            }
             *launches += 2;
         }
         FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 7, 0, 8, st));
@@ -1443,7 +1487,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
         hipLaunchKernelGGL((k_sp_odd<8192>), dim3(std::min<uint32_t>(n_big, 1u << 16)), dim3(SP_THREADS), 0, st, a, lists[3], n_big);
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (h[1] != 0) return FBG_OK;
+        if (h[1] != 0) { ctx->sp_decline = 5; return FBG_OK; }
         const uint32_t n_chain = (uint32_t)h[4];
         if (n_chain) {
             hipLaunchKernelGGL(k_sp_chain, dim3(fbg_blocks(n_chain, 64)), dim3(64), 0, st, a, n_chain, 0);
@@ -1451,7 +1495,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
         }
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
-        if (h[1] != 0) return FBG_OK;
+        if (h[1] != 0) { ctx->sp_decline = 6; return FBG_OK; }
         const uint32_t n_slow = (uint32_t)h[5];
         ctx->sp_chain_n = n_chain; ctx->sp_slow_n = n_slow;
         if (n_slow) {
@@ -1469,8 +1513,8 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
             FBG_HIP_TRY(ctx, hipMemcpyAsync(&uniq, a.counters + 15, 8, hipMemcpyDeviceToHost, st));
             FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
             ctx->sp_slow_n = (uint32_t)uniq;
-            if (ctx->opt.span_scan != 1 && ctx->opt.span_scan != 3 && uniq > ctx->N / (1ull << 20) + 4) return FBG_OK;
-            hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)sorted, n_slow, 0u);
+            if (ctx->opt.span_scan != 1 && ctx->opt.span_scan != 3 && uniq > ctx->N / (1ull << 20) + 4) { ctx->sp_decline = 7; return FBG_OK; }
+            hipLaunchKernelGGL((k_sp_odd_slow<8192>), dim3(std::min<uint32_t>(n_slow, 1u << 16)), dim3(SP_THREADS), 0, st, a, (const uint32_t *)sorted, n_slow, 0u, 1u);
             *launches += 3;
         }
         *launches += 4;
@@ -1486,7 +1530,7 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     FBG_HIP_TRY(ctx, hipMemcpyAsync(&flag, a.counters + 3, 8, hipMemcpyDeviceToHost, st));
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     FBG_HIP_TRY(ctx, hipGetLastError());
-    if (flag != 0) return FBG_OK;
+    if (flag != 0) { ctx->sp_decline = 8; return FBG_OK; }
     ctx->grs_tricks_off = disable_tricks;
     *ok = 1;
     return FBG_OK;
@@ -1518,6 +1562,7 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
     int launches = 0;
     uint64_t by_code = 0;
     bool good = sp_ignore_mask(ctx, &by_code);
+    ctx->sp_decline = good ? 0 : 10;
     FBG_TRY(fbg_reserve(ctx, ctx->gmax, (n + 1) * 4));
     ctx->rk_keys = keys; ctx->sa_ptr = vals;
     ctx->rk_layout = FBG_SLOTS_PAIRS; ctx->rk_pb = 0; ctx->rk_b = g.b; ctx->rk_key_bits = g.key_bits; ctx->rk_K = g.K;
@@ -1528,7 +1573,7 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
         // debugging aid: the sorted values are a permutation of the cells (sum and xor agree), the keys ascend
         sp_args(ctx, a, 0);
         FBG_HIP_TRY(ctx, hipMemsetAsync(a.counters + 16, 0, 8 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sp_check, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keys, (const uint32_t *)vals, ctx->sp_cells.as<uint32_t>(), N, a.counters + 16);
+        hipLaunchKernelGGL(k_sp_check, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, keys, (const uint32_t *)vals, ctx->sp_cells.as<uint32_t>(), N, a.counters + 16, a.ksh);
         unsigned long long c[5];
         FBG_HIP_TRY(ctx, hipMemcpyAsync(c, a.counters + 16, sizeof(c), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1589,7 +1634,7 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
         FBG_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
         FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
         launches += 2;
-        if (h[3] != 0) good = false;
+        if (h[3] != 0) { good = false; ctx->sp_decline = 9; }
         for (int c = 0; c < 4; c++) ctx->sp_n_odd[c] = (uint32_t)std::min<unsigned long long>(h[8 + c], cap);
         // The lists in COLUMN order: the workgroups of an odd group read the texts of all its members -- hundreds of rows at
         // one column, two memory lines each -- and so do the groups of the columns next to it.  In key order those meet at
@@ -1619,7 +1664,7 @@ int fbg_span_try(fbg_ctx *ctx, uint64_t *keys, uint32_t *vals, const KeyGeom &g,
         *done = 1;
     } else {
         sp_args(ctx, a, 0);
-        hipLaunchKernelGGL(k_sp_to_positions, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a, vals);
+        hipLaunchKernelGGL(k_sp_to_positions, dim3(fbg_blocks(N, 256)), dim3(256), 0, st, a, vals, keys);
         launches++;
         FBG_HIP_TRY(ctx, hipGetLastError());
     }

@@ -59,6 +59,7 @@ struct PackArgs {
     unsigned long long *counter;
     const uint64_t *ebits = nullptr;   // PAIRS: bit 31 of the value = an irregular position among the K from p on (gapped_rank.hip)
     const uint32_t *payload = nullptr; // PAIRS: the value of position p is payload[p] (span_scan.hip: cell | flags)
+    const uint8_t *key_flags = nullptr; // PAIRS: two bits per position that go below the key (span_scan.hip, 2^30 cells and more)
 };
 
 // any irregular position among [p, p + K)?  (K <= 32; the bitmap is padded beyond the text)
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
             if (p < a.N) {
                 if (LAYOUT == FBG_SLOTS_PACKED) a.keys[p] = (skeys[j] << a.pb) | p;
                 else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[p] = (skeys[j] << a.pb) | (p >> 32); a.vals[p] = (uint32_t)p; }
-                else { a.keys[p] = skeys[j]; a.vals[p] = a.payload ? a.payload[p] : (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
+                else { a.keys[p] = a.key_flags ? (skeys[j] << 2) | a.key_flags[p] : skeys[j]; a.vals[p] = a.payload ? a.payload[p] : (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
             }
         }
         return;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_pack(PackArgs a)
                 const uint64_t p = base + j;
                 if (LAYOUT == FBG_SLOTS_PACKED) a.keys[o] = (skeys[j] << a.pb) | p;
                 else if (LAYOUT == FBG_SLOTS_WIDE) { a.keys[o] = (skeys[j] << a.pb) | (p >> 32); a.vals[o] = (uint32_t)p; }
-                else { a.keys[o] = skeys[j]; a.vals[o] = a.payload ? a.payload[p] : (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
+                else { a.keys[o] = a.key_flags ? (skeys[j] << 2) | a.key_flags[p] : skeys[j]; a.vals[o] = a.payload ? a.payload[p] : (uint32_t)p | (a.ebits ? pack_flag(a.ebits, p, K) : 0u); }
             }
         }
         off += (uint64_t)__popcll(keep[i]);
@@ -787,7 +788,7 @@ static int sort_slots(fbg_ctx *ctx, const KeyGeom &g, uint64_t count, uint64_t o
         });
     }
     uint32_t *va = ctx->valsA.as<uint32_t>(), *vb = ctx->valsB.as<uint32_t>() + out_offset;
-    unsigned lo = g.wide ? (unsigned)g.pb : 0u;
+    unsigned lo = g.wide ? (unsigned)g.pb : ctx->sp_key_flags ? 2u : 0u;     // (span_scan.hip: two flag bits below the key)
     const unsigned hi = lo + (unsigned)g.key_bits;
     if (hi == 64 && count < (1u << 23)) lo = 0;        // same caution as above
     return with_tmp(ctx, [&](void *tmp, size_t &bytes) {
@@ -880,7 +881,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
 
     // ---- round 0: sort all suffixes by their first K symbols -------------------------------
     FBG_TRY(fbg_key_setup(ctx, false, &g, &launches));
-    const int b = g.b, K = g.K, key_bits = g.key_bits;
+    int b = g.b, K = g.K, key_bits = g.key_bits;
     FBG_TRY(fbg_reserve(ctx, ctx->keysA, N * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->keysB, N * 8));
     FBG_TRY(fbg_reserve(ctx, ctx->valsA, N * 4));
@@ -902,6 +903,7 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     ctx->pairs_similar = false;
     ctx->spanned = false;
     ctx->sort_payload = nullptr;
+    ctx->sp_key_flags = false;
     // rows that resemble each other (twins among the keys of a sample; option span_scan = 1: whatever the rows): the
     // group-level scan on column spans (span_scan.hip), whose sort carries cells instead of positions
     bool try_span = fbg_span_eligible(ctx, g);
@@ -914,6 +916,8 @@ int fbg_suffix_sort(fbg_ctx *ctx)
     if (try_grs || try_span) FBG_TRY(fbg_grs_prepare(ctx, &launches));
     if (try_span) {
         ctx->grs_ebits = nullptr; ctx->grs_flagged = false;           // (the bitmap goes into the cells' flags instead)
+        ctx->sp_key_flags = fbg_span_key_flags(ctx, g);               // (2^30 cells and more: may shorten the key by a symbol)
+        K = g.K; key_bits = g.key_bits;
         FBG_TRY(fbg_span_prepare(ctx, g, &launches));
         ctx->sort_payload = ctx->sp_cells.as<uint32_t>();
     }
@@ -930,11 +934,14 @@ int fbg_suffix_sort(fbg_ctx *ctx)
             pa.lo = pa.hi = pa.cap = 0; pa.nohi = 1; pa.counter = nullptr;
             pa.ebits = ctx->grs_ebits;
             pa.payload = ctx->sort_payload;
+            pa.key_flags = ctx->sp_key_flags ? ctx->sp_flagT.as<uint8_t>() : nullptr;
             launch_pack(ctx, g, false, pa);
             launches++;
             FBG_TRY(sort_slots(ctx, g, N, 0));
         }
         ctx->sort_payload = nullptr;
+        ctx->sp_key_flags_sorted = ctx->sp_key_flags;
+        ctx->sp_key_flags = false;                                    // (sort_slots serves the later rounds too)
         // the sample sort sizes its buffers itself: take the pointers again
         keysA = ctx->keysA.as<uint64_t>(); keysB = ctx->keysB.as<uint64_t>();
         valsA = ctx->valsA.as<uint32_t>(); valsB = ctx->valsB.as<uint32_t>();

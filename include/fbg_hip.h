@@ -105,10 +105,22 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *                      column spans (span_scan.hip); 1: every such MSA takes it, -1: none, 2: as 0, and the sorted slots
  *                      are checked to be the cells in key order (debugging), 3: as 1, with the groups of more than 1024
  *                      members worked off by chains along the later keys' groups (the earlier method, kept for tests)
+ *   span_key_flags     1: that scan's slot layout for MSAs of 2^30 cells and more (the two flags of a slot in the key word,
+ *                      the cell alone in the value) whatever the size (tests); results unchanged
+ *   poison             1 .. 255: every device buffer the context allocates from now on is filled with that byte first
+ *                      (debugging aid: reads of memory nobody wrote show up in a fresh process too); results unchanged
+ *   span_slow_split    workgroups that share the odd members of one large group whose pairs are all compared (0 = 32);
+ *                      results unchanged
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
  * gap-free MSA, 2 scan in suffix order of an MSA with gaps / ignore characters (slot by slot, or -- "span_scan_used" = 1 --
  * group by group), 3 one partition of a partitioned index.  "span_groups", "span_odd_groups", "span_irregular",
- * "span_scan_work" (read-only): the group-level scan's table sizes and the text comparisons it expected.
+ * "span_scan_work" (read-only): the group-level scan's table sizes and the text comparisons it expected;
+ * "alloc_calls", "alloc_us" (read-only): device buffers the context has allocated or enlarged so far, and the host time
+ * that took in microseconds (hipFree + hipMalloc).
+ * "span_decline" (read-only): why the group-level scan handed the last build to the record path: 0 it did not, 1 / 3 / 5 /
+ * 6 / 8 / 9 a list or table of its kernels was full, 2 more than 32 text comparisons per suffix ahead, 4 / 7 too many groups
+ * that need every pair of members compared, 10 an ignore character it cannot express;
+ * "span_key_flags_used" (read-only): 1 when the slots at hand have that scan's layout for 2^30 cells and more.
  * "dp_kind" (read-only): the sweep that produced the last fbg_minmax_dp result: -1 none yet, 0 statement by statement,
  * 1 matrix chain with byte entries (windows up to 256 columns), 2 wave-parallel sweep, 3 .. 7 matrix chain with 16-bit
  * entries over windows of 1024 / 2048 / 4096 / 8192 / 16384 columns.

@@ -1342,17 +1342,19 @@ SPAN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("key_flags", [0, 1])
 @pytest.mark.parametrize("case", range(len(SPAN_CASES)))
-def test_span_scan_matches_oracle(engine, case):
+def test_span_scan_matches_oracle(engine, case, key_flags):
     """Star-phylogeny rows with gap runs -- the shape of a pangenome MSA -- through the group-level scan on column spans
     (option span_scan = 1 takes it whatever the size; at scale the sample of the sort decides): f with and without
     --ignore-chars, with the elastic tricks on and off, in 3 column shards; against the oracle (fbg.cpp:1579-1695,
-    esp. 1687-1691: the pointer that waits through a gap run)."""
+    esp. 1687-1691: the pointer that waits through a gap run).  key_flags = 1: in the slot layout of MSAs with 2^30
+    cells and more (the reference's size_type is 64 bits wide, fbg.cpp:47: no limit of that kind there)."""
     import torch
     kw = dict(SPAN_CASES[case])
     m, n = kw.pop("m"), kw.pop("n")
     msa = star_msa(np.random.default_rng(9000 + case), m, n, **kw)
-    with fbg_options(engine, {"span_scan": 1}):
+    with fbg_options(engine, {"span_scan": 1, "span_key_flags": key_flags}):
         for ignore in ("", "N"):
             if ignore == "" and ord("N") in msa and case != 3:
                 continue
@@ -1361,6 +1363,7 @@ def test_span_scan_matches_oracle(engine, case):
             engine.index_build(ignorechars=ignore)
             if ord("-") in msa or ignore:
                 assert engine.get_option("span_scan_used") == 1 and engine.get_option("index_kind") == 2, (case, ignore)
+                assert engine.get_option("span_key_flags_used") == key_flags
             for tricks_off, ref in ((False, f_on), (True, f_off), (False, f_on)):
                 d = torch.zeros(n, dtype=torch.int64, device="cuda")
                 torch.cuda.synchronize()
@@ -1451,6 +1454,54 @@ def test_span_scan_through_a_group_and_at_scale():
             assert np.array_equal(a, b), tricks_off
 
 
+def test_span_scan_beyond_2_30_cells_equals_the_record_path():
+    """1000 x 1 100 000 star phylogeny with gaps: 1.1 * 10^9 cells, more than a 30-bit cell number holds.  The reference
+    has no limit of that kind (size_type is 64 bits wide, fbg.cpp:47; the pointer that waits through a gap run,
+    fbg.cpp:1687-1691, at any size): the group-level scan carries the cell in all 32 bits of the slot's value and the two
+    flags in the key word (span_key_flags_used), and gives the f of the record path (option span_scan = -1).  Two columns of
+    so long an MSA whose K symbols agree make groups of 2000 members, half of them odd: the slow groups' odd members are
+    shared out over 32 workgroups (span_slow_split) -- with 1 the same f."""
+    import torch
+    import founderblockgraphs_amd as F
+    m, n = 1000, 1_100_000
+    g = torch.Generator(device="cuda").manual_seed(11)
+    anc = torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.uint8)
+    d = torch.empty((m, n), dtype=torch.uint8, device="cuda")
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    for i0 in range(0, m, 10):
+        i1 = min(m, i0 + 10)
+        mut = torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.01
+        sub = torch.randint(0, 4, (i1 - i0, n), device="cuda", generator=g, dtype=torch.uint8)
+        d[i0:i1] = lut[torch.where(mut, sub, anc.expand(i1 - i0, n)).long()]
+        start = (torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.02 / 8).float().unsqueeze(1)
+        gap = torch.nn.functional.max_pool1d(torch.nn.functional.pad(start, (7, 0)), 8, 1).squeeze(1) > 0
+        d[i0:i1][gap] = ord("-")
+        del mut, sub, start, gap
+    assert (m + 1) * (n + 1) >= 1 << 30
+    d = d.reshape(-1)
+    got = {}
+    with F.Engine(0) as e:
+        e.msa_set_device(d.data_ptr(), m, n)
+        d_f = torch.zeros(n, dtype=torch.int64, device="cuda")
+        for name, opts in (("span", {}), ("span, one workgroup per slow group", {"span_slow_split": 1}), ("record path", {"span_scan": -1})):
+            with e.options(**opts):
+                d_f.zero_()
+                torch.cuda.synchronize()
+                e.index_build()
+                e.scan_f(0, n, d_f.data_ptr())
+                e.sync()
+                spanned = name != "record path"
+                assert e.get_option("span_scan_used") == int(spanned), (name, e.get_option("span_decline"))
+                assert e.get_option("span_key_flags_used") == int(spanned), name
+                got[name] = d_f.clone()
+    for name in got:
+        bad = torch.nonzero(got[name] != got["record path"]).flatten()
+        assert bad.numel() == 0, (name, bad[:8].tolist())
+    assert int(got["span"].max()) > 0
+    del d, got
+    torch.cuda.empty_cache()
+
+
 def test_span_scan_decline_hands_the_record_path_a_suffix_array(engine):
     """The group-level scan declines (here: a gap of 5000 columns common to all rows makes a group whose members are coloured
     together over more columns than it walks) AFTER the sort: the cells go back to text positions and the record path goes
@@ -1463,7 +1514,8 @@ def test_span_scan_decline_hands_the_record_path_a_suffix_array(engine):
     msa[:, :10] = row[:10]
     msa[:, 5010:] = row[10:]
     assert (3 * (63 + 1) + 1) % 64 == 1
-    with fbg_options(engine, {"span_scan": 1}):
-        for tricks_off in (False, True):
-            assert np.array_equal(engine.elastic_f(msa, disable_efg_tricks=tricks_off), O.compute_f(msa, disable_tricks=tricks_off))
-        assert engine.get_option("span_scan_used") == 0
+    for key_flags in (0, 1):           # (1: the declined sort hands back key words without the flag bits, too)
+        with fbg_options(engine, {"span_scan": 1, "span_key_flags": key_flags}):
+            for tricks_off in (False, True):
+                assert np.array_equal(engine.elastic_f(msa, disable_efg_tricks=tricks_off), O.compute_f(msa, disable_tricks=tricks_off))
+            assert engine.get_option("span_scan_used") == 0
