@@ -10,7 +10,7 @@ import sys
 
 # kernels whose reads are scattered 8- / 16-byte accesses, not streams: no doubling (round-3 verdict: 17.7 GB "read" by
 # k_tie_simple in 2.6 ms would have been 6.7 TB/s of gathers)
-GATHER = ("k_tie_pairs", "k_tie_simple", "k_tie_groups", "k_tie_big", "k_runs", "k_sp_odd", "k_sp_chain", "k_grs_scan_seg", "k_grs_long", "k_scan_exceptions",
+GATHER = ("k_tie_pairs", "k_tie_simple", "k_tie_groups", "k_tie_big", "k_runs", "k_sp_odd", "k_sp_chain", "k_sp_values", "k_sp_irr", "k_grs_scan_seg", "k_grs_long", "k_scan_exceptions",
           "k_bt_", "k_dp_bt", "k_block_group", "k_block_edges")
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
@@ -26,7 +26,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
        "workload": {"rows": 1000, "cols": 1000000},
        **({"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 scripts/gpu_configs.py c5  (scripts/gpu_round2_extra.sh)",
            "workload": {"rows": 256, "cols": 2000000, "gaps": "5 % in runs of 16", "N": "0.1 %", "ignore": "N", "builds_per_run": 2}} if c5 else {}),
-       **({"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 scripts/gpu_stargaps.py 1 0  (scripts/gpu_round3.sh)",
+       **({"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 scripts/gpu_stargaps.py 1 0  (scripts/gpu_r4_prof.sh)",
            "workload": {"rows": 1000, "cols": 200000, "rows_are": "a star phylogeny, 1 % substitutions", "gaps": "2 % of the cells in runs of 8", "builds_per_run": 1}} if star else {}),
        "correction": "counter unit KiB; FETCH_SIZE doubled for gfx950 (MI355X_MICROARCH.md, HBM section) for the kernels that stream, raw for those that gather (read_correction)", "kernels": {}}
 for name, d in sorted(acc.items()):
