@@ -15,22 +15,38 @@
 
 #define DP_NONE 0xffffffffu
 
-// e[x] = f[x] + 1 ; hist[e]++
-__global__ void k_dp_keys(const uint64_t *__restrict__ f, uint64_t n, uint32_t *__restrict__ e,
-                          uint32_t *__restrict__ hist, unsigned long long *__restrict__ bad)
+// e[x] = f[x] + 1, the count of entries outside [x, n] and the longest minimal extension (one atomic each per workgroup)
+__global__ __launch_bounds__(256) void k_dp_keys(const uint64_t *__restrict__ f, uint64_t n, uint32_t *__restrict__ e,
+                                                 unsigned long long *__restrict__ bad)
 {
-    uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= n) return;
-    uint64_t fx = f[x];
-    if (fx > n || fx < x) { atomicAdd(bad, 1ull); fx = fx > n ? n : x; }   // f[x] in [x, n] by construction
-    e[x] = (uint32_t)(fx + 1);
-    atomicAdd(&hist[fx + 1], 1u);
-    // longest minimal extension f[x]+1-x, reduced per wave then one atomic.  A column with f[x] = n (a row runs out of
-    // symbols; only without the elastic tricks, fbg.cpp:1659-1663) can start no block at all -- its entry would be read
-    // at step n+1 -- and does not count
-    unsigned long long ext = fx < n ? fx + 1 - x : 0;
-    for (int d = 32; d >= 1; d >>= 1) ext = max(ext, (unsigned long long)__shfl_down(ext, d, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(bad + 1, ext);
+    __shared__ unsigned long long s_ext[4], s_bad[4];
+    unsigned long long ext = 0, nbad = 0;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t fx = f[x];
+        if (fx > n || fx < x) { nbad++; fx = fx > n ? n : x; }            // f[x] in [x, n] by construction
+        e[x] = (uint32_t)(fx + 1);
+        // longest minimal extension f[x]+1-x.  A column with f[x] = n (a row runs out of symbols; only without the elastic
+        // tricks, fbg.cpp:1659-1663) can start no block at all -- its entry would be read at step n+1 -- and does not count
+        if (fx < n) ext = max(ext, (unsigned long long)(fx + 1 - x));
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        ext = max(ext, (unsigned long long)__shfl_down(ext, d, 64));
+        nbad += (unsigned long long)__shfl_down(nbad, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_ext[threadIdx.x >> 6] = ext; s_bad[threadIdx.x >> 6] = nbad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long mx = max(max(s_ext[0], s_ext[1]), max(s_ext[2], s_ext[3])), nb = s_bad[0] + s_bad[1] + s_bad[2] + s_bad[3];
+        if (nb) atomicAdd(bad, nb);
+        if (mx) atomicMax(bad + 1, mx);
+    }
+}
+
+// hist[e]++ : the counting sort of fbg.cpp:1941-1953 (only the wave-parallel and the literal sweep read its order)
+__global__ void k_dp_hist(const uint32_t *__restrict__ e, uint64_t n, uint32_t *__restrict__ hist)
+{
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n) atomicAdd(&hist[e[x]], 1u);
 }
 
 __global__ void k_dp_scatter(const uint32_t *__restrict__ e, uint64_t n, uint32_t *__restrict__ cursor,
@@ -629,6 +645,14 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
 #define DPW_INF 0xffffu
 typedef uint16_t __attribute__((may_alias)) dpw_u16;     // the LDS rows are written as 16-bit entries and read as pairs / quads
 typedef uint32_t __attribute__((may_alias)) dpw_u32;
+// A barrier between phases that exchange through LDS only: __syncthreads() also waits for every global load and store in flight
+// (its fence covers global memory), which would put the latency of the rows fetched ahead back on every step of a chain
+__device__ __forceinline__ void dpw_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __global__ void k_dpw_prep(const uint32_t *__restrict__ e, uint32_t n, uint16_t *__restrict__ ext16)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -782,7 +806,7 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
                 fresh[t0 + 1] = w0 >> 16;
             }
         }
-        __syncthreads();
+        dpw_lds_barrier();
         if (threadIdx.x < DPW_B) {
             const uint32_t j = jb + 1 + threadIdx.x;
             const uint32_t v = fresh[threadIdx.x];
@@ -790,9 +814,371 @@ __global__ __launch_bounds__(1024) void k_dpw_chain(const uint16_t *__restrict__
             if (j <= n) { if (j < first_valid) mml[j] = n + j; else { mml[j] = v; if (v >= WS) bad = true; } }
         }
         L = fresh[DPW_B - 1];                                            // stays until the next block's minima are written, after the barrier below
-        __syncthreads();
+        dpw_lds_barrier();
     }
     if (bad) flag[4] = 1;
+}
+
+// ---- round 4: the wide-window chain without the wide matrices ------------------------------------------------------
+//
+// A source that lies more than 128 columns before a block can enter it only by ONE block that is longer than anything that
+// follows inside (the inner blocks are at most 127 long): the cost of reaching target t from such a source x through the
+// inner cut point c is max(minmaxlength[x], c - x) whenever t can be reached from c at all.  So the block has to know two
+// things about its inside -- the 128 x 128 matrix of the 128 sources right before it (k_dpw_blockY, as k_dpw_blockM), and
+// the BIT matrix "t is reachable from c" -- and for the older sources
+//     G[c] = min over the old sources x with f[x] + 1 <= c of max(minmaxlength[x], c - x),   out[t] = min over c that reach t of G[c]
+// is a lower envelope that needs no matrix at all.  A source that is valid from the block's first column on contributes its
+// value while that dominates (a prefix of the block: a table of 128 minima and one suffix-minimum scan) and its age from then
+// on (a second table, one prefix-minimum scan); the sources whose minimal extension ends inside the block (each source once in
+// its life) are listed and evaluated against the targets one by one.  What the walk reads per block: 32 KB of matrix instead
+// of 2 * 128 * (block length + 256) bytes, whatever the window; the matrices take 256 + 16 bytes per column instead of 2 * WS.
+// (tests/test_wide_chain_model.py restates this in numpy against the oracle.)
+__global__ __launch_bounds__(256) void k_dpw_blockY(const uint16_t *__restrict__ ext16, uint32_t n, uint16_t *__restrict__ My,
+                                                    unsigned long long *__restrict__ Rb)
+{
+    // threads 0..127: the sources of the block before (prefix length x = jb - 127 + k); 128..255: the block's own columns as
+    // sources (the same formula), of whose rows only "finite or not" is kept: bit c of Rb[b][t]
+    constexpr uint32_t RP = DPW_B + 2;
+    __shared__ uint32_t rows_w[256 * RP / 2];
+    __shared__ uint16_t s_ext[DPW_B];
+    __shared__ uint32_t mk_w[4][DPW_B / 2];
+    const uint32_t b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, k = threadIdx.x;
+    const uint32_t jb = DPW_B * b;
+    const int64_t xs = (int64_t)jb - (int64_t)(DPW_B - 1) + k;
+    const uint32_t ext_src = (xs >= 0 && xs <= (int64_t)n) ? ext16[xs] : DPW_INF;
+    if (threadIdx.x < DPW_B) s_ext[threadIdx.x] = jb + 1 + threadIdx.x < n ? ext16[jb + 1 + threadIdx.x] : (uint16_t)DPW_INF;
+    __syncthreads();
+    uint32_t minext = DPW_INF;
+    for (uint32_t q = 0; q < DPW_B; q++) minext = min(minext, (uint32_t)s_ext[q]);
+    dpw_u32 *mk = reinterpret_cast<dpw_u32 *>(mk_w[wv]);
+    dpw_u16 *mk16 = reinterpret_cast<dpw_u16 *>(mk_w[wv]);
+    mk[lane] = 0xffffffffu;
+    uint32_t ready[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) { const uint32_t tp = lane + 64 * r; ready[r] = tp + max(1u, (uint32_t)s_ext[tp]); }
+    dpw_u16 *row = reinterpret_cast<dpw_u16 *>(rows_w) + threadIdx.x * RP;
+    const dpw_u32 *row32 = reinterpret_cast<const dpw_u32 *>(rows_w) + threadIdx.x * (RP / 2);
+    uint16_t *out = My + (size_t)b * DPW_B * DPW_B + k;
+    for (uint32_t t = 0; t < DPW_B; t++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (ready[r] == t) mk16[lane + 64 * r] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t age_src = t + DPW_B - k;                          // wraps for the block's own columns at and behind the target
+        uint32_t w = (age_src - 1 < 2 * DPW_B && ext_src <= age_src) ? age_src : DPW_INF;
+        const uint32_t tp_end = t >= minext ? t - minext + 1 : 0;
+        dp_u16x2 acc = dp_pair(DPW_INF);
+        uint32_t g2 = 0;
+#pragma unroll 4
+        for (; 2 * g2 + 2 <= tp_end; g2++) {
+            const uint32_t base = t - 2 * g2;
+            acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(row32[g2] | mk[g2]), dp_bits(base | ((base - 1) << 16))));
+        }
+        if (2 * g2 < tp_end) {
+            const uint32_t base = t - 2 * g2;
+            acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(dp_bits(row32[g2] | mk[g2] | 0xffff0000u), dp_bits(base | 0xffff0000u)));
+        }
+        w = min(w, min((uint32_t)acc.x, (uint32_t)acc.y));
+        row[t] = (uint16_t)w;
+        if (wv < 2) out[(size_t)t * DPW_B] = (uint16_t)w;                // My[b][t][k]
+        else {
+            const unsigned long long bits = __ballot(w != DPW_INF);
+            if (lane == 0) Rb[((size_t)b * DPW_B + t) * 2 + (wv - 2)] = bits;
+        }
+    }
+}
+
+#define DPW_LIST 2048u                                 // listed sources per block; more are worked off by their own threads
+#define DPW_NT 512u                                    // threads of k_dpw_chain2
+// minimum over the 16 lanes of a DPP row, in every lane; the packed form takes the two 16-bit halves apart
+__device__ __forceinline__ uint32_t dpw_row_min(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ uint32_t dpw_row_min_pk(uint32_t v)
+{
+    v = dp_word(__builtin_elementwise_min(dp_bits(v), dp_bits((uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false))));
+    v = dp_word(__builtin_elementwise_min(dp_bits(v), dp_bits((uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false))));
+    v = dp_word(__builtin_elementwise_min(dp_bits(v), dp_bits((uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false))));
+    v = dp_word(__builtin_elementwise_min(dp_bits(v), dp_bits((uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false))));
+    return v;
+}
+__device__ __forceinline__ uint32_t dpw_wave_min(uint32_t x)                                     // uniform result
+{
+    x = dpw_row_min(x);
+    return min(min((uint32_t)__builtin_amdgcn_readlane((int)x, 0), (uint32_t)__builtin_amdgcn_readlane((int)x, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane((int)x, 32), (uint32_t)__builtin_amdgcn_readlane((int)x, 48)));
+}
+// inclusive prefix minimum over the 64 lanes (row_shr inside the rows of 16, then the rows' last lanes passed on)
+__device__ __forceinline__ uint32_t dpw_wave_prefix_min(uint32_t x)
+{
+    const int inf = (int)DPW_INF;
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x111, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x112, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x114, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x118, 0xF, 0xF, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x142, 0xA, 0xF, false));    // row_bcast:15 into rows 1, 3
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(inf, (int)x, 0x143, 0xC, 0xF, false));    // row_bcast:31 into rows 2, 3
+    return x;
+}
+// tab[idx] = min(tab[idx], val) for the active lanes; when they all name one entry (a plateau of f: one step of the block
+// for a run of sources) the wave sends a single atomic
+__device__ __forceinline__ void dpw_table_min(uint32_t *tab, uint32_t idx, uint32_t val, bool active)
+{
+    const unsigned long long m = __ballot(active);
+    if (!m) return;
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)__builtin_ctzll(m));
+    if (__ballot(active && idx == first) == m) {
+        const uint32_t mv = dpw_wave_min(active ? val : DPW_INF);
+        if ((threadIdx.x & 63) == 0) atomicMin(&tab[first], mv);
+    } else if (active) atomicMin(&tab[idx], val);
+}
+// dynamic LDS of k_dpw_chain2<WS>: the two rings (2 * WS bytes each), then the tables and the list below
+#define DPW_CHAIN2_LDS(WS) (4u * (WS) + 4u * (128u * 9u + 4u) + 6u * DPW_LIST + 16u)
+
+template <uint32_t WS>
+__global__ __launch_bounds__(DPW_NT + 128) void k_dpw_chain2(const uint16_t *__restrict__ My, const unsigned long long *__restrict__ Rb,
+                                                       const uint16_t *__restrict__ ext16, uint32_t n, uint32_t nblocks,
+                                                       uint32_t *__restrict__ mml, unsigned long long *__restrict__ flag, uint32_t first_valid, uint32_t probe)
+{
+    // ringv[(x - 1) & (WS - 1)] = minmaxlength of prefix length x, ringe[...] = minimal extension of column x (a block [x, j)
+    // needs j - x >= it), for the WS prefix lengths before the current block; 0xffff = none.
+    // 8 waves: wave w owns targets 16 w .. 16 w + 15 of the matrix part (four loads of four rows, 16 lanes a row, fetched
+    // PF blocks ahead: the matrices do not depend on the state); every thread owns old sources (age at the block's first
+    // column a0 = 129 + q, q = thread + 512 r, up to L + 128: older ones cannot win, see k_dpw_chain); thread (t, s) = (tid / 4,
+    // tid % 4) evaluates target t against the s-th part of the listed sources, then against 32 of the inner cut points.
+    // An old source x that may end a block at the block's first column already (lo = 0) gives max(v, a0 + t) at step t:
+    // v up to step rr = v - a0 -- pfx, a table by rr read as a suffix minimum (kept reversed) -- and a0 + t from rr + 1 on --
+    // slope, a table by the first such step read as a prefix minimum.  One that becomes valid at step lo > 0 uses slope the
+    // same way from max(lo, rr + 1), csfx (by lo, prefix minimum) when its value dominates to the block's end, and is listed
+    // (lo, rr, v) when it dominates for a part [lo, rr] only.
+    constexpr uint32_t PF = 6;                         // blocks the tenth wave runs ahead
+    constexpr uint32_t MASK = WS - 1;
+    extern __shared__ uint4 dpw_dyn[];
+    uint4 *ringv4 = dpw_dyn;
+    dpw_u16 *ringv = reinterpret_cast<dpw_u16 *>(dpw_dyn);
+    dpw_u16 *ringe = ringv + WS;
+    uint32_t *pfx = reinterpret_cast<uint32_t *>(ringe + WS);      // [127 - rr]
+    uint32_t *slope = pfx + 128;
+    uint32_t *csfx = slope + 128;
+    uint32_t *spfx = csfx + 128, *sslope = spfx + 128, *scsfx = sslope + 128;   // the three after their scans
+    uint32_t *gl = scsfx + 128;                                    // [2][128]: the listed sources' part of G, one table per block parity
+    uint32_t *fresh_y = gl + 256;                                  // the matrix part of the block's values
+    uint32_t *lcount = fresh_y + 128;                              // [0] listed sources, [1] minmaxlength of the block's last column
+    dpw_u16 *lst = reinterpret_cast<dpw_u16 *>(lcount + 4);        // per 8 listed sources: 8 x v, 8 x (65536 - lo), 8 x rr
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t tt = tid >> 2, sl = tid & 3;
+    for (uint32_t i = tid; i < WS / 8; i += DPW_NT) {
+        ringv4[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        reinterpret_cast<uint4 *>(ringe)[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    }
+    for (uint32_t i = tid; i < 128 * 9; i += DPW_NT) pfx[i] = DPW_INF;
+    __syncthreads();
+    if (tid == 0) { ringv[WS - 1] = 0; ringe[WS - 1] = ext16[0]; lcount[0] = 0; lcount[1] = 0; }   // prefix length 0
+    __syncthreads();
+    if (wv == DPW_NT / 64) {
+        // the ninth wave takes the blocks' values from the ring to memory, a block behind the others.  The eight that compute issue
+        // no store at all: loads and stores share one counter (vmcnt) that only stays in order for loads alone -- with a store
+        // in flight every use of a row fetched ahead would wait for ALL the wave's loads, the newest included
+        bool bad = false;
+        if (lane == 0) mml[0] = 0;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            dpw_lds_barrier();
+            if (!(probe & 128)) { dpw_lds_barrier(); dpw_lds_barrier(); }
+            const uint32_t j0 = DPW_B * b + 1 + 2 * lane;
+            const uint32_t w = *reinterpret_cast<const dpw_u32 *>(ringv + ((j0 - 1) & MASK));
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint32_t j = j0 + h, v = h ? w >> 16 : w & 0xffffu;
+                if (j <= n) { if (j < first_valid) mml[j] = n + j; else { mml[j] = v; if (v >= WS) bad = true; } }
+            }
+        }
+        if (bad) flag[4] = 1;
+        return;
+    }
+    if (wv == DPW_NT / 64 + 1) {
+        // the tenth wave touches one word of every 128-byte line the block PF steps ahead will read (matrix, bits, extensions),
+        // so that the loads of the eight -- issued one block ahead, as far as the compiler's wait counts follow a value through
+        // registers -- find their lines in the L2.  The loads are written as assembly with one fixed destination register that nothing reads:
+        // the compiler would make the wave wait for a value it loads before it lets go of it, and this wave shares the others'
+        // barriers -- a wave that waits for memory there makes every block as long as a trip to memory
+        const char *mp = reinterpret_cast<const char *>(My) + (size_t)lane * 128;
+        const char *rp = reinterpret_cast<const char *>(Rb) + (size_t)(lane & 15) * 128;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            const uint32_t bn = min(b + PF, nblocks - 1);
+            const char *m0 = mp + (size_t)bn * 32768, *r0 = rp + (size_t)bn * 2048;
+            const uint16_t *e0 = ext16 + min(DPW_B * bn + 1 + 64 * (lane & 1), n);
+            asm volatile("global_load_dword v127, %0, off\n\t"
+                         "global_load_dword v127, %1, off\n\t"
+                         "global_load_dword v127, %2, off\n\t"
+                         "global_load_dword v127, %3, off\n\t"
+                         "global_load_dword v127, %4, off\n\t"
+                         "global_load_ushort v127, %5, off"
+                         :
+                         : "v"(m0), "v"(m0 + 8192), "v"(m0 + 16384), "v"(m0 + 24576), "v"(r0), "v"(e0)
+                         : "v127", "memory");
+            dpw_lds_barrier();
+            if (!(probe & 128)) { dpw_lds_barrier(); dpw_lds_barrier(); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const uint4 *M4 = reinterpret_cast<const uint4 *>(My) + (size_t)(16 * wv) * (DPW_B / 8) + lane;
+    const uint32_t *R32 = reinterpret_cast<const uint32_t *>(Rb) + (size_t)tt * 4 + sl;
+    uint4 nxt[4];                                      // the rows, bits and extension of the next block: loaded a block ahead
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) nxt[i] = M4[64 * i];
+    uint32_t nrb = R32[0], nex = ext16[min(1 + tt, n)];
+    uint32_t L = 0;                                    // minmaxlength at the column before the block; 0xffff (none): no bound
+    {
+        for (uint32_t b = 0; b < nblocks; b++) {
+            const uint32_t jb = DPW_B * b;
+            uint4 cur[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) cur[i] = nxt[i];
+            const uint32_t crb = nrb, cex = nex;
+            {                                          // (a block beyond the last is asked for as the last: no branches; ext16[n] = none)
+                const uint32_t bn = (probe & 64) ? 0u : min(b + 1, nblocks - 1);
+                if (!(probe & 64) || b == 0)
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) nxt[i] = M4[(size_t)bn * DPW_B * (DPW_B / 8) + 64 * i];
+                nrb = R32[(size_t)bn * DPW_B * 4];
+                nex = ext16[min(DPW_B * bn + 1 + tt, n)];
+            }
+            uint32_t *glb = gl + 128 * (b & 1);
+            // ---- phase 0 (a): the 128 sources before the block through their matrix
+            if (!(probe & 2)) {
+                const uint4 s4 = ringv4[(((jb - DPW_B) >> 3) + (lane & 15)) & (WS / 8 - 1)];
+                uint32_t part[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint4 r = cur[i];
+                    dp_u16x2 a = __builtin_elementwise_max(dp_bits(s4.x), dp_bits(r.x));
+                    a = __builtin_elementwise_min(a, __builtin_elementwise_max(dp_bits(s4.y), dp_bits(r.y)));
+                    a = __builtin_elementwise_min(a, __builtin_elementwise_max(dp_bits(s4.z), dp_bits(r.z)));
+                    a = __builtin_elementwise_min(a, __builtin_elementwise_max(dp_bits(s4.w), dp_bits(r.w)));
+                    part[i] = min((uint32_t)a.x, (uint32_t)a.y);
+                }
+                const uint32_t w0 = dpw_row_min_pk(part[0] | (part[1] << 16)), w1 = dpw_row_min_pk(part[2] | (part[3] << 16));
+                if ((lane & 15) == 0) {                // load i holds rows 16 w + 4 i + (lane >> 4)
+                    const uint32_t t0 = 16 * wv + (lane >> 4);
+                    fresh_y[t0] = w0 & 0xffffu;
+                    fresh_y[t0 + 4] = w0 >> 16;
+                    fresh_y[t0 + 8] = w1 & 0xffffu;
+                    fresh_y[t0 + 12] = w1 >> 16;
+                }
+            }
+            // ---- phase 0 (b): the older sources
+            {
+                const uint32_t Q = (probe & 1) ? 0u : min(WS - DPW_B, L);
+                for (uint32_t q0 = 0; q0 < Q; q0 += DPW_NT) {          // uniform
+                    const uint32_t q = q0 + tid;
+                    const uint32_t a0 = DPW_B + 1 + q;
+                    const uint32_t idx = (jb - DPW_B - 1 - q) & MASK;
+                    const uint32_t v = ringv[idx], e = ringe[idx];
+                    bool ok = q < Q && jb >= DPW_B + q && v < 0x8000u;   // prefix length x = jb - 128 - q >= 0
+                    const uint32_t lo = e > a0 ? e - a0 : 0;
+                    ok = ok && lo < DPW_B;
+                    const int rr = (int)v - (int)a0;                       // the value dominates up to step rr
+                    const bool always = ok && lo == 0, late = ok && lo != 0;
+                    // the value's part
+                    dpw_table_min(pfx, (uint32_t)(DPW_B - 1 - min(max(rr, 0), (int)DPW_B - 1)), v, always && rr >= 0);
+                    dpw_table_min(csfx, lo, v, late && rr >= (int)DPW_B - 1);
+                    // the age's part, from step max(lo, rr + 1) on
+                    const uint32_t s = (uint32_t)max((int)lo, rr + 1);
+                    dpw_table_min(slope, s, a0, ok && (int)s < (int)DPW_B && rr + 1 < (int)DPW_B);
+                    // the value dominates on [lo, rr] only, lo > 0: listed
+                    const bool part = late && rr >= (int)lo && rr < (int)DPW_B - 1;
+                    const unsigned long long lm = __ballot(part);
+                    if (lm) {
+                        const uint32_t cnt = (uint32_t)__popcll(lm);
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&lcount[0], cnt);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        const uint32_t pos = base + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull));
+                        if (part) {
+                            if (pos < DPW_LIST) {
+                                dpw_u16 *g = lst + 24 * (pos >> 3) + (pos & 7);
+                                g[0] = (uint16_t)v; g[8] = (uint16_t)(0x10000u - lo); g[16] = (uint16_t)rr;
+                            } else
+                                for (uint32_t t = lo; t <= (uint32_t)rr; t++) atomicMin(&glb[t], v);
+                        }
+                    }
+                }
+            }
+            dpw_lds_barrier();
+            // ---- phase 1: the listed sources against the targets (pairs of sources in the 16-bit halves of a word: a step
+            // outside [lo, rr] wraps to a value above every window); waves 0..2 scan a table each
+            {
+                const uint32_t cnt = min(lcount[0], DPW_LIST), ng = (probe & 4) ? 0u : (cnt + 7) >> 3;
+                if (ng) {
+                    dp_u16x2 acc = dp_pair(DPW_INF);
+                    const dp_u16x2 t2 = dp_pair(tt);
+                    for (uint32_t g = sl; g < ng; g += 4) {
+                        const uint4 *gp = reinterpret_cast<const uint4 *>(lst + 24 * g);
+                        uint4 v4 = gp[0];
+                        const uint4 n4 = gp[1], r4 = gp[2];
+                        const uint32_t left = cnt - 8 * g;                  // sources of this group that exist (1 .. 8, or more)
+                        if (left < 8) {
+                            if (left < 2) v4.x |= 0xffff0000u;
+                            if (left < 3) v4.y = 0xffffffffu; else if (left < 4) v4.y |= 0xffff0000u;
+                            if (left < 5) v4.z = 0xffffffffu; else if (left < 6) v4.z |= 0xffff0000u;
+                            if (left < 7) v4.w = 0xffffffffu; else v4.w |= 0xffff0000u;
+                        }
+#define DPW_LST(V, N, R) acc = __builtin_elementwise_min(acc, __builtin_elementwise_max(__builtin_elementwise_max(dp_bits(V), dp_bits(N) + t2), dp_bits(R) - t2))
+                        DPW_LST(v4.x, n4.x, r4.x);
+                        DPW_LST(v4.y, n4.y, r4.y);
+                        DPW_LST(v4.z, n4.z, r4.z);
+                        DPW_LST(v4.w, n4.w, r4.w);
+#undef DPW_LST
+                    }
+                    uint32_t m = min((uint32_t)acc.x, (uint32_t)acc.y);
+                    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0xB1, 0xF, 0xF, false));
+                    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x4E, 0xF, 0xF, false));
+                    if (sl == 0) glb[tt] = min(glb[tt], m);
+                }
+                if (wv < 3 && !(probe & 8)) {
+                    // elements 2 lane, 2 lane + 1 of table wv: prefix minima
+                    const uint2 ev = reinterpret_cast<const uint2 *>(pfx + 128 * wv)[lane];
+                    const uint32_t inc = dpw_wave_prefix_min(min(ev.x, ev.y));
+                    const uint32_t exc = (uint32_t)__builtin_amdgcn_update_dpp((int)DPW_INF, (int)inc, 0x138, 0xF, 0xF, false);   // wave_shr:1
+                    const uint32_t p0 = min(ev.x, exc), p1 = min(ev.y, p0);
+                    reinterpret_cast<uint2 *>(spfx + 128 * wv)[lane] = make_uint2(p0, p1);
+                }
+            }
+            if (!(probe & 128)) dpw_lds_barrier();
+            // ---- phase 2: out[t] = min over the inner cut points c that reach t (and c = t) of G[c], with the matrix part; the
+            // rings move on; the tables are made ready for the next block
+            {
+                uint32_t bits = (probe & 16) ? 0u : crb;
+                if ((tt >> 5) == sl && !(probe & 32)) bits |= 1u << (tt & 31);
+                uint32_t best = DPW_INF;
+                while (bits) {
+                    const uint32_t c = 32 * sl + (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1;
+                    const uint32_t sp = sslope[c];
+                    best = min(best, min(min(spfx[DPW_B - 1 - c], scsfx[c]), min(glb[c], sp >= DPW_INF ? DPW_INF : sp + c)));
+                }
+                best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0xB1, 0xF, 0xF, false));
+                best = min(best, (uint32_t)__builtin_amdgcn_update_dpp((int)best, (int)best, 0x4E, 0xF, 0xF, false));
+                if (sl == 0 && !(probe & 32)) {
+                    const uint32_t v = min(min(best, fresh_y[tt]), DPW_INF);
+                    const uint32_t j = jb + 1 + tt;
+                    ringv[(j - 1) & MASK] = (uint16_t)v;
+                    ringe[(j - 1) & MASK] = (uint16_t)cex;
+                    if (tt == DPW_B - 1) lcount[1] = v;
+                }
+                if (sl == 1) { pfx[tt] = DPW_INF; slope[tt] = DPW_INF; csfx[tt] = DPW_INF; gl[128 * ((b + 1) & 1) + tt] = DPW_INF; }
+                if (tid == 2) lcount[0] = 0;
+            }
+            if (!(probe & 128)) dpw_lds_barrier();
+            L = lcount[1];
+        }
+    }
 }
 
 __global__ void k_dpw_bt(const uint32_t *__restrict__ mml, const uint16_t *__restrict__ ext16, uint32_t n, uint32_t window, uint32_t *__restrict__ bt,
@@ -941,13 +1327,14 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
              *mml = ctx->dp_g.as<uint32_t>(), *bt = ctx->dp_h.as<uint32_t>(), *tnext = ctx->list.as<uint32_t>();
     unsigned long long *sc = ctx->scalars.as<unsigned long long>() + 16;
     FBG_HIP_TRY(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned long long), st));
-    FBG_HIP_TRY(ctx, hipMemsetAsync(bstart, 0, w, st));
-    hipLaunchKernelGGL(k_dp_keys, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, d_f, n, e, bstart, sc + 2);
+    hipLaunchKernelGGL(k_dp_keys, dim3(fbg_blocks(n, 256, 2048)), dim3(256), 0, st, d_f, n, e, sc + 2);
     // the bucket order of fbg.cpp:1941-1953 (counting sort of x by f[x]+1): only the wave-parallel and the literal sweep
     // read it -- built when one of them is about to run
     bool buckets_ready = false;
     auto build_buckets = [&]() -> int {
         if (buckets_ready) return FBG_OK;
+        FBG_HIP_TRY(ctx, hipMemsetAsync(bstart, 0, w, st));
+        hipLaunchKernelGGL(k_dp_hist, dim3(fbg_blocks(n, 256)), dim3(256), 0, st, e, n, bstart);
         size_t bytes = 0;
         hipError_t er = rocprim::exclusive_scan(nullptr, bytes, bstart, bstart, 0u, (size_t)(n + 2), rocprim::plus<uint32_t>(), st);
         if (er != hipSuccess) return fbg_fail(ctx, FBG_ERR_HIP, "rocprim scan size query failed");
@@ -994,6 +1381,41 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         hipLaunchKernelGGL(k_dpw_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext16);
         uint32_t WS = 1024;
         while (WS < max_ext + 2) WS *= 2;
+        if (ctx->opt.dpw_matrix != 1) {
+            const uint32_t probe = ctx->opt.dpw_matrix > 1 ? (uint32_t)ctx->opt.dpw_matrix >> 1 : 0u;   // timing probes: wrong results
+            // round 4: a 128 x 128 matrix and 128 x 128 bits per block, whatever the window (k_dpw_blockY), the older sources in
+            // closed form (k_dpw_chain2); 272 bytes per column
+            const size_t ybytes = (size_t)nblocks * DPW_B * DPW_B * 2, rbytes = (size_t)nblocks * DPW_B * 16;
+            FBG_TRY(fbg_reserve(ctx, ctx->tmp, ybytes + rbytes));
+            uint16_t *My = ctx->tmp.as<uint16_t>();
+            unsigned long long *Rb = reinterpret_cast<unsigned long long *>(ctx->tmp.as<uint8_t>() + ybytes);
+            hipLaunchKernelGGL(k_dpw_blockY, dim3(nblocks), dim3(256), 0, st, ext16, (uint32_t)n, My, Rb);
+            for (; WS <= 16384 && !done; WS *= 2) {
+                FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+#define FBG_DPW2(W)                                                                                                                   \
+    do {                                                                                                                              \
+        const size_t lds = DPW_CHAIN2_LDS(W);                                                                                         \
+        if (lds > 48 * 1024)                                                                                                          \
+            FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dpw_chain2<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_dpw_chain2<W>), dim3(1), dim3(DPW_NT + 128), lds, st, My, Rb, ext16, (uint32_t)n, nblocks, mml, sc, first_valid, probe); \
+    } while (0)
+                switch (WS) {
+                case 1024: FBG_DPW2(1024); break;
+                case 2048: FBG_DPW2(2048); break;
+                case 4096: FBG_DPW2(4096); break;
+                case 8192: FBG_DPW2(8192); break;
+                default: FBG_DPW2(16384); break;
+                }
+#undef FBG_DPW2
+                hipLaunchKernelGGL(k_dpw_bt, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, mml, ext16, (uint32_t)n, WS, bt, sc, first_valid);
+                FBG_HIP_TRY(ctx, hipMemcpyAsync(hk, sc, sizeof(hk), hipMemcpyDeviceToHost, st));
+                FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
+                done = hk[4] == 0;
+                if (done) { int k = 3; for (uint32_t w2 = 1024; w2 < WS; w2 *= 2) k++; ctx->dp_kind = k; }
+            }
+            if (!done) FBG_HIP_TRY(ctx, hipMemsetAsync(sc + 4, 0, sizeof(unsigned long long), st));
+            return FBG_OK;
+        }
         for (; WS <= 16384 && !done; WS *= 2) {
             const size_t mbytes = (size_t)nblocks * DPW_B * WS * 2;
             if (mbytes > (64ull << 30)) break;
