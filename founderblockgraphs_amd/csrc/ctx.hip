@@ -182,7 +182,7 @@ static const OptKey g_opt_keys[] = {
     {"no_aux_stream", &FbgOptions::no_aux_stream}, {"rank_no_threshold", &FbgOptions::rank_no_threshold},
     {"dp_literal", &FbgOptions::dp_literal}, {"dp_wave", &FbgOptions::dp_wave}, {"dp_safe_window", &FbgOptions::dp_safe_window},
     {"dp_tile", &FbgOptions::dp_tile}, {"pure_scan", &FbgOptions::pure_scan}, {"gapped_rank", &FbgOptions::gapped_rank}, {"part_tricks_off", &FbgOptions::part_tricks_off}, {"msd_sample_bins", &FbgOptions::msd_sample_bins}, {"msd_min_force", &FbgOptions::msd_min_force}, {"msd_probe", &FbgOptions::msd_probe}, {"msd_xcd", &FbgOptions::msd_xcd}, {"rank_no_lean", &FbgOptions::rank_no_lean}, {"no_stream_upload", &FbgOptions::no_stream_upload},
-    {"span_scan", &FbgOptions::span_scan}, {"span_key_flags", &FbgOptions::span_key_flags}, {"span_slow_split", &FbgOptions::span_slow_split}, {"poison", &FbgOptions::poison}, {"dpw_matrix", &FbgOptions::dpw_matrix},
+    {"span_scan", &FbgOptions::span_scan}, {"span_key_flags", &FbgOptions::span_key_flags}, {"span_slow_split", &FbgOptions::span_slow_split}, {"poison", &FbgOptions::poison}, {"dpw_matrix", &FbgOptions::dpw_matrix}, {"dp_chain1", &FbgOptions::dp_chain1},
 };
 
 // The one place the library reads the environment: FBG_DEBUG_ENV=1 lets FBG_<KEY>=<integer> preset the options of

@@ -467,6 +467,98 @@ __global__ __launch_bounds__(64) void k_dp_chain(const uint8_t *__restrict__ Wt,
     if (__ballot(bad != 0) && lane == 0) flag[4] = 1;
 }
 
+// A barrier between phases that exchange through LDS only: __syncthreads() also waits for every global load and store in flight
+// (its fence covers global memory), which would put the latency of the rows fetched ahead back on every step of a chain
+__device__ __forceinline__ void dpw_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// The same walk on six waves (round 4).  One wave alone spends 4 instructions per (source, target) pair -- 1.2 us per group of
+// 128 x 128, all of it instruction issue.  Waves 0..3 take a quarter of the sources each (their part of every target's row,
+// fetched a group ahead), leave their partial minima in LDS and, behind ONE barrier per group (the table alternates between
+// two copies), every wave folds the four parts into the next state.  Wave 4 keeps the state too and is the only one that stores
+// (Sg): a store in flight would make every use of a fetched row wait for all of the wave's loads (one counter for both).
+// Wave 5 touches the lines of the matrix PF groups ahead (see k_dpw_chain2).
+template <int R>
+__global__ __launch_bounds__(384) void k_dp_chain6(const uint8_t *__restrict__ Wt, uint32_t n, uint32_t nblocks, uint32_t F, uint8_t *__restrict__ Sg,
+                                                   uint32_t *__restrict__ mml)
+{
+    constexpr uint32_t WN = 64 * R, PF = 6;
+    __shared__ uint32_t part[2][4][WN];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ngroups = (nblocks + F - 1) / F;
+    auto last_block = [&](uint32_t g) { return min(g * F + F - 1, nblocks - 1); };
+    if (wv == 5) {
+        constexpr uint32_t NL = R == 1 ? 1 : R * R / 2;          // loads of 64 lines each that cover WN * WN bytes
+        for (uint32_t g = 0; g < ngroups; g++) {
+            const char *p = reinterpret_cast<const char *>(Wt) + (size_t)last_block(min(g + PF, ngroups - 1)) * WN * WN + (size_t)(R == 1 ? lane & 31 : lane) * 128;
+            for (uint32_t i = 0; i < NL; i++) asm volatile("global_load_dword v127, %0, off" : : "v"(p + (size_t)i * 8192) : "v127", "memory");
+            dpw_lds_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    uint32_t S[R];                                                        // S[r]: state of source k = 64r + lane
+#pragma unroll
+    for (int r = 0; r < R; r++) S[r] = (r == R - 1 && lane == 63) ? 0u : DPB_INF;   // before block 0: only column 0
+    if (wv == 4) {
+        if (lane == 0) mml[0] = 0;
+        for (uint32_t g = 0; g < ngroups; g++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) Sg[(size_t)g * WN + 64 * r + lane] = (uint8_t)min(S[r], DPB_INF);
+            dpw_lds_barrier();
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                S[r] = min(min(part[g & 1][0][64 * r + lane], part[g & 1][1][64 * r + lane]), min(part[g & 1][2][64 * r + lane], part[g & 1][3][64 * r + lane]));
+        }
+        return;
+    }
+    // waves 0..3: sources 16 R wv .. 16 R wv + 16 R - 1, i.e. the uint4 words R wv .. R wv + R - 1 of every target's row
+    auto row_ptr = [&](uint32_t g, int rt) {
+        return reinterpret_cast<const uint4 *>(Wt + (size_t)last_block(g) * WN * WN + (size_t)(64 * rt + lane) * WN) + R * wv;
+    };
+    uint4 nx[R * R];
+#pragma unroll
+    for (int rt = 0; rt < R; rt++)
+#pragma unroll
+        for (int i = 0; i < R; i++) nx[rt * R + i] = row_ptr(0, rt)[i];
+    const uint32_t k0 = 16 * R * wv;                                      // first source of the wave: lane (k0 & 63) of S[k0 >> 6]
+    for (uint32_t g = 0; g < ngroups; g++) {
+        uint4 cur[R * R];
+#pragma unroll
+        for (int i = 0; i < R * R; i++) cur[i] = nx[i];
+        {
+            const uint32_t gn = min(g + 1, ngroups - 1);
+#pragma unroll
+            for (int rt = 0; rt < R; rt++)
+#pragma unroll
+                for (int i = 0; i < R; i++) nx[rt * R + i] = row_ptr(gn, rt)[i];
+        }
+        uint32_t Ssel = S[0];                                             // the state register that holds the wave's sources
+#pragma unroll
+        for (int r = 1; r < R; r++) Ssel = (k0 >> 6) == (uint32_t)r ? S[r] : Ssel;
+        const uint32_t l0 = k0 & 63;
+#pragma unroll
+        for (int rt = 0; rt < R; rt++) {
+            uint32_t acc = DPB_INF;
+#pragma unroll
+            for (int j = 0; j < 16 * R; j++) {
+                const uint4 q = cur[rt * R + (j >> 4)];
+                const uint32_t word = ((j >> 2) & 3) == 0 ? q.x : ((j >> 2) & 3) == 1 ? q.y : ((j >> 2) & 3) == 2 ? q.z : q.w;
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)Ssel, (int)(l0 + j));
+                acc = min(acc, max(sk, (word >> (8 * (j & 3))) & 255u));
+            }
+            part[g & 1][wv][64 * rt + lane] = acc;
+        }
+        dpw_lds_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            S[r] = min(min(part[g & 1][0][64 * r + lane], part[g & 1][1][64 * r + lane]), min(part[g & 1][2][64 * r + lane], part[g & 1][3][64 * r + lane]));
+    }
+}
+
 // Shorten the sequential chain: inside every group of F consecutive blocks the matrices are replaced by
 // their running (min,max) products P_i = W_first (x) ... (x) W_i (in place, all groups in parallel), so the
 // chain only has to step from group to group (through the last product) and every block's values follow
@@ -645,14 +737,6 @@ __global__ __launch_bounds__(64) void k_dp_backtrack_wave(const uint32_t *__rest
 #define DPW_INF 0xffffu
 typedef uint16_t __attribute__((may_alias)) dpw_u16;     // the LDS rows are written as 16-bit entries and read as pairs / quads
 typedef uint32_t __attribute__((may_alias)) dpw_u32;
-// A barrier between phases that exchange through LDS only: __syncthreads() also waits for every global load and store in flight
-// (its fence covers global memory), which would put the latency of the rows fetched ahead back on every step of a chain
-__device__ __forceinline__ void dpw_lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 __global__ void k_dpw_prep(const uint32_t *__restrict__ e, uint32_t n, uint16_t *__restrict__ ext16)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1381,8 +1465,8 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
         hipLaunchKernelGGL(k_dpw_prep, dim3(fbg_blocks(n + 1, 256)), dim3(256), 0, st, e, (uint32_t)n, ext16);
         uint32_t WS = 1024;
         while (WS < max_ext + 2) WS *= 2;
-        if (ctx->opt.dpw_matrix != 1) {
-            const uint32_t probe = ctx->opt.dpw_matrix > 1 ? (uint32_t)ctx->opt.dpw_matrix >> 1 : 0u;   // timing probes: wrong results
+        if (!ctx->opt.dpw_matrix) {
+            const uint32_t probe = 0;                   // bits that leave parts of k_dpw_chain2 out: timing only, wrong results (scripts/gpu_dpw_probe.py)
             // round 4: a 128 x 128 matrix and 128 x 128 bits per block, whatever the window (k_dpw_blockY), the older sources in
             // closed form (k_dpw_chain2); 272 bytes per column
             const size_t ybytes = (size_t)nblocks * DPW_B * DPW_B * 2, rbytes = (size_t)nblocks * DPW_B * 16;
@@ -1494,7 +1578,8 @@ int fbg_dp_minmax(fbg_ctx *ctx, const uint64_t *d_f, uint64_t n, uint64_t *d_bou
             FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_compose<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
         hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext7, (const uint8_t *)nullptr, (uint32_t)n, nblocks, Wt);             \
         hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
-        hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);        \
+        if (ctx->opt.dp_chain1) hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml, sc);   \
+        else hipLaunchKernelGGL((k_dp_chain6<RR>), dim3(1), dim3(384), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, mml);        \
         hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, mml, sc, first_valid);    \
     } while (0)
                     if (Rt == 1) FBG_DP_PIPE(1);
@@ -1691,7 +1776,8 @@ int fbg_dp_repeatfree(fbg_ctx *ctx, const uint64_t *d_v, uint64_t n, uint64_t *d
             FBG_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dp_compose<RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
         hipLaunchKernelGGL((k_dp_blockW<RR>), dim3(grid), dim3(64 * RR), lds, st, ext1, amin, (uint32_t)n, nblocks, Wt);  \
         hipLaunchKernelGGL((k_dp_compose<RR>), dim3(ngroups), dim3(256), lds2, st, Wt, nblocks, Fg);                     \
-        hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, sp, sc);         \
+        if (ctx->opt.dp_chain1) hipLaunchKernelGGL((k_dp_chain<RR>), dim3(1), dim3(64), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, sp, sc);   \
+        else hipLaunchKernelGGL((k_dp_chain6<RR>), dim3(1), dim3(384), 0, st, Wt, (uint32_t)n, nblocks, Fg, Sg, sp);        \
         hipLaunchKernelGGL((k_dp_expand<RR>), dim3(grid), dim3(64), 0, st, Wt, Sg, (uint32_t)n, nblocks, Fg, sp, sc + 8, 0u); \
     } while (0)
             if (R == 1) FBG_NE_PIPE(1);

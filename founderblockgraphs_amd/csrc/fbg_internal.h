@@ -38,7 +38,7 @@ struct FbgOptions {
     int64_t no_ranked = 0, no_packed = 0, force_wide = 0, full_keys = 0, no_msd_sort = 0, msd_min = -1, bp_min = -1,
             record_scatter = 0, lcp_text = 0, no_aux_stream = 0, rank_no_threshold = 0, dp_literal = 0, dp_wave = 0,
             dp_safe_window = 0, dp_tile = 0, pure_scan = 0, gapped_rank = 0, part_tricks_off = 0, msd_sample_bins = 0, msd_min_force = 0, msd_probe = 0, msd_xcd = -1, rank_no_lean = 0, no_stream_upload = 0,
-            span_scan = 0, span_key_flags = 0, span_slow_split = 0, poison = 0, dpw_matrix = 0;
+            span_scan = 0, span_key_flags = 0, span_slow_split = 0, poison = 0, dpw_matrix = 0, dp_chain1 = 0;
 };
 
 struct fbg_ctx {

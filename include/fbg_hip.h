@@ -112,6 +112,8 @@ const char *fbg_last_error(const fbg_ctx *ctx);
  *   dpw_matrix         1: the sweep over windows of 1024 .. 16384 columns with one 128 x window matrix per block (the method of
  *                      rounds 2-3: k_dpw_blockM / k_dpw_chain) instead of the matrix of the 128 columns before a block and the
  *                      closed form for the older ones (k_dpw_blockY / k_dpw_chain2); results unchanged
+ *   dp_chain1          1: the walk over the groups of byte matrices on one wave (k_dp_chain, rounds 1-3) instead of six
+ *                      (k_dp_chain6); results unchanged
  *   span_slow_split    workgroups that share the odd members of one large group whose pairs are all compared (0 = 32);
  *                      results unchanged
  * fbg_get_option also answers "index_kind" (read-only): -1 no index, 0 per-position records, 1 rank-order scan of a
