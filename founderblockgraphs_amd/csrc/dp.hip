@@ -582,27 +582,44 @@ __global__ __launch_bounds__(256) void k_dp_compose(uint8_t *__restrict__ Wt, ui
         for (uint32_t q = tid * 16; q < WN * WN; q += 256 * 16)
             *reinterpret_cast<uint4 *>(W + q) = *reinterpret_cast<const uint4 *>(G + q);
         __syncthreads();
-        // thread -> (row t, 8 consecutive sources k): WN*WN/8 work items.  Bytes as two pairs of 16-bit lanes per word
-        // (even / odd bytes): packed 16-bit max / min do two sources per instruction
-        for (uint32_t item = tid; item < WN * WN / 8; item += 256) {
-            const uint32_t t = item / (WN / 8), k8 = (item % (WN / 8)) * 8;
-            dp_u16x2 a0 = dp_pair(DPB_INF), a1 = a0, a2 = a0, a3 = a0;       // sources (k8, k8+2), (k8+1, k8+3), (k8+4, k8+6), (k8+5, k8+7)
-            // (no shortcut for w = 255: max(255, p) = 255 changes nothing, and without the branch eight iterations' loads are in
-            // flight at once -- the loop was bound by the latency of its two LDS reads)
-#pragma unroll 8
-            for (uint32_t u = 0; u < WN; u++) {
-                const uint32_t w = W[t * WN + u];
-                const uint2 p8 = *reinterpret_cast<const uint2 *>(P + u * WN + k8);
-                const dp_u16x2 ww = dp_pair(w);
-                a0 = __builtin_elementwise_min(a0, __builtin_elementwise_max(ww, dp_bits(p8.x & 0x00ff00ffu)));
-                a1 = __builtin_elementwise_min(a1, __builtin_elementwise_max(ww, dp_bits((p8.x >> 8) & 0x00ff00ffu)));
-                a2 = __builtin_elementwise_min(a2, __builtin_elementwise_max(ww, dp_bits(p8.y & 0x00ff00ffu)));
-                a3 = __builtin_elementwise_min(a3, __builtin_elementwise_max(ww, dp_bits((p8.y >> 8) & 0x00ff00ffu)));
+        // thread -> a tile of 4 rows t x 8 consecutive sources k, four u per step: the four W words (4 u each) and the four P
+        // rows' 8 bytes are read once for 128 (t, k, u) triples; bytes as two pairs of 16-bit lanes per word (even / odd bytes:
+        // packed 16-bit max / min do two sources per instruction), a W byte in both lanes by one v_perm.  1.4 instructions per
+        // triple (round 4; a row t x 8 sources per thread, one u per step: 2.1)
+        for (uint32_t tile = tid; tile < WN * WN / 32; tile += 256) {
+            const uint32_t t0 = 4 * (tile / (WN / 8)), k8 = (tile % (WN / 8)) * 8;
+            dp_u16x2 acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[a][c] = dp_pair(DPB_INF);
+#pragma unroll 2
+            for (uint32_t u = 0; u < WN; u += 4) {
+                uint32_t w[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) w[a] = *reinterpret_cast<const uint32_t *>(W + (t0 + a) * WN + u);
+#pragma unroll
+                for (int uu = 0; uu < 4; uu++) {
+                    const uint2 p8 = *reinterpret_cast<const uint2 *>(P + (u + uu) * WN + k8);
+                    const dp_u16x2 pe0 = dp_bits(p8.x & 0x00ff00ffu), po0 = dp_bits((p8.x >> 8) & 0x00ff00ffu),
+                                   pe1 = dp_bits(p8.y & 0x00ff00ffu), po1 = dp_bits((p8.y >> 8) & 0x00ff00ffu);
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        const dp_u16x2 ww = dp_bits(__builtin_amdgcn_perm(w[a], w[a], 0x0c000c00u | (uint32_t)uu | ((uint32_t)uu << 16)));
+                        acc[a][0] = __builtin_elementwise_min(acc[a][0], __builtin_elementwise_max(ww, pe0));
+                        acc[a][1] = __builtin_elementwise_min(acc[a][1], __builtin_elementwise_max(ww, po0));
+                        acc[a][2] = __builtin_elementwise_min(acc[a][2], __builtin_elementwise_max(ww, pe1));
+                        acc[a][3] = __builtin_elementwise_min(acc[a][3], __builtin_elementwise_max(ww, po1));
+                    }
+                }
             }
-            uint2 o;
-            o.x = dp_word(a0) | (dp_word(a1) << 8);
-            o.y = dp_word(a2) | (dp_word(a3) << 8);
-            *reinterpret_cast<uint2 *>(G + t * WN + k8) = o;
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                uint2 o;
+                o.x = dp_word(acc[a][0]) | (dp_word(acc[a][1]) << 8);
+                o.y = dp_word(acc[a][2]) | (dp_word(acc[a][3]) << 8);
+                *reinterpret_cast<uint2 *>(G + (t0 + a) * WN + k8) = o;
+            }
         }
         __syncthreads();
         // the product becomes P for the next block of the group
@@ -1160,6 +1177,7 @@ __global__ __launch_bounds__(DPW_NT + 128) void k_dpw_chain2(const uint16_t *__r
             {
                 const uint32_t Q = (probe & 1) ? 0u : min(WS - DPW_B, L);
                 for (uint32_t q0 = 0; q0 < Q; q0 += DPW_NT) {          // uniform
+                    if (q0 + 64 * wv >= Q) break;                      // none of this wave's sources left (uniform in the wave)
                     const uint32_t q = q0 + tid;
                     const uint32_t a0 = DPW_B + 1 + q;
                     const uint32_t idx = (jb - DPW_B - 1 - q) & MASK;

@@ -186,6 +186,22 @@ def test_dp_sweep_wide_windows(engine, max_ext, style):
     assert kinds <= {0, 1, 2, 3, 4, 5, 6, 7}
 
 
+@pytest.mark.parametrize("switches", [{"dpw_matrix": 1}, {"dp_chain1": 1}])
+def test_dp_sweep_earlier_methods_stay_exact(engine, switches):
+    """The sweep's kernels of rounds 1-3 that round 4 replaced stay reachable through options (A/B timing in one process):
+    k_dpw_blockM / k_dpw_chain (one 128 x window matrix per block) behind dpw_matrix, the one-wave walk over the byte
+    matrices k_dp_chain behind dp_chain1 -- both against the oracle on every window size."""
+    rng = np.random.default_rng(404)
+    with fbg_options(engine, switches):
+        for max_ext, style in ((40, "uniform"), (100, "plateau"), (200, "spiky"), (700, "plateau"), (1500, "uniform"), (3000, "plateau"),
+                               (6000, "plateau"), (12000, "uniform")):
+            for n in (300, 40_000):
+                f = _random_f(rng, n, max_ext, style)
+                mml, bt, b = O.minmax_dp(f)
+                gb, gmml, gbt = engine.minmax_dp(f, full=True)
+                assert np.array_equal(gmml, mml) and np.array_equal(gbt, bt) and np.array_equal(gb, b), (switches, n, max_ext, style)
+
+
 def test_dp_sweep_wide_windows_full_size(engine):
     """10^6 columns whose extensions reach 900 columns (rows that resemble each other, with gaps): the 16-bit matrix chain
     against the statement-by-statement sweep, and the properties of a valid segmentation."""
