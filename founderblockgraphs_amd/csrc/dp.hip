@@ -368,7 +368,19 @@ __global__ __launch_bounds__(64 * R) void k_dp_blockW(const uint8_t *__restrict_
             const uint32_t tp_end = t >= need ? t - need + 1 : 0;
             dp_u16x2 acc_e = dp_pair(0xffffu), acc_o = acc_e;
             uint32_t g4 = 0;
-#pragma unroll 4
+            // sixteen candidates a turn without a bound check in between (round 4: the compiler's own unrolling kept a compare
+            // and a branch after every four), then the rest four at a time
+            for (; g4 + 16 <= tp_end; g4 += 16) {
+#pragma unroll
+                for (uint32_t h = 0; h < 16; h += 4) {
+                    const uint32_t word = *reinterpret_cast<const uint32_t *>(row + g4 + h);
+                    const uint2 m = *reinterpret_cast<const uint2 *>(mk + 2 * (g4 + h));
+                    const uint32_t base = t - g4 - h;
+                    const dp_u16x2 age_e = dp_bits(base | ((base - 2) << 16)), age_o = dp_bits((base - 1) | ((base - 3) << 16));
+                    acc_e = __builtin_elementwise_min(acc_e, __builtin_elementwise_max(dp_bits((word & 0x00ff00ffu) | m.x), age_e));
+                    acc_o = __builtin_elementwise_min(acc_o, __builtin_elementwise_max(dp_bits(((word >> 8) & 0x00ff00ffu) | m.y), age_o));
+                }
+            }
             for (; g4 + 4 <= tp_end; g4 += 4) {
                 const uint32_t word = *reinterpret_cast<const uint32_t *>(row + g4);
                 const uint2 m = *reinterpret_cast<const uint2 *>(mk + 2 * g4);
