@@ -1060,15 +1060,17 @@ __global__ __launch_bounds__(DPW_NT + 128) void k_dpw_chain2(const uint16_t *__r
 {
     // ringv[(x - 1) & (WS - 1)] = minmaxlength of prefix length x, ringe[...] = minimal extension of column x (a block [x, j)
     // needs j - x >= it), for the WS prefix lengths before the current block; 0xffff = none.
-    // 8 waves: wave w owns targets 16 w .. 16 w + 15 of the matrix part (four loads of four rows, 16 lanes a row, fetched
-    // PF blocks ahead: the matrices do not depend on the state); every thread owns old sources (age at the block's first
+    // Ten waves.  Waves 0..7 compute: wave w owns targets 16 w .. 16 w + 15 of the matrix part (four loads of four rows, 16 lanes
+    // a row, fetched one block ahead: the matrices do not depend on the state); every thread owns old sources (age at the block's first
     // column a0 = 129 + q, q = thread + 512 r, up to L + 128: older ones cannot win, see k_dpw_chain); thread (t, s) = (tid / 4,
     // tid % 4) evaluates target t against the s-th part of the listed sources, then against 32 of the inner cut points.
     // An old source x that may end a block at the block's first column already (lo = 0) gives max(v, a0 + t) at step t:
     // v up to step rr = v - a0 -- pfx, a table by rr read as a suffix minimum (kept reversed) -- and a0 + t from rr + 1 on --
     // slope, a table by the first such step read as a prefix minimum.  One that becomes valid at step lo > 0 uses slope the
     // same way from max(lo, rr + 1), csfx (by lo, prefix minimum) when its value dominates to the block's end, and is listed
-    // (lo, rr, v) when it dominates for a part [lo, rr] only.
+    // (lo, rr, v) when it dominates for a part [lo, rr] only.  Wave 8 takes the block before from the ring to memory, wave 9
+    // touches the lines PF blocks ahead (both below).  `probe` (0 in the library): bits that leave parts out, for timing only
+    // (wrong results; DESIGN_HISTORY.md has what they measured).
     constexpr uint32_t PF = 6;                         // blocks the tenth wave runs ahead
     constexpr uint32_t MASK = WS - 1;
     extern __shared__ uint4 dpw_dyn[];
