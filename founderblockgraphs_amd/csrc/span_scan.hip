@@ -1418,9 +1418,12 @@ static int sp_scan(fbg_ctx *ctx, int disable_tricks, int *ok, int *launches)
     FBG_HIP_TRY(ctx, hipStreamSynchronize(st));
     *launches += 2;
     ctx->sp_work = h[0];
-    // text comparisons ahead (odd members x group size): beyond a few dozen per suffix of the text the record path is cheaper
+    // text comparisons ahead (odd members x group size): beyond ten per suffix of the text the record path is cheaper.  Measured on
+    // the star phylogeny 1000 x 200 000 with deletions that 30 % / 90 % of the rows share at 1000 and at 4000 columns
+    // (scripts/gpu_stargaps.py, FBG_STAR_SHARED; profiles/r04_shared_deletions.txt): 4.2 / 5.9 / 7.1 comparisons per suffix took
+    // 87 / 131 / 118 ms here against 150 / 149 / 140 on the record path, 12.7 took 326 against 128 (the bound was 32 until round 4)
     if (h[1] != 0) { ctx->sp_decline = 1; return FBG_OK; }
-    if (h[0] > std::max<unsigned long long>(32 * ctx->N, 1ull << 26)) { ctx->sp_decline = 2; return FBG_OK; }
+    if (h[0] > std::max<unsigned long long>(10 * ctx->N, 1ull << 26)) { ctx->sp_decline = 2; return FBG_OK; }
     // the larger groups' odd members: a list for those that are coloured alone, a list of the groups that need every pair compared
     const uint64_t members = h[3];
     FBG_TRY(fbg_reserve(ctx, ctx->sp_chain, (members + 1) * sizeof(SpChain)));

@@ -28,6 +28,16 @@ for i0 in range(0, m, 50):
     start = (torch.rand((i1 - i0, n), device="cuda", generator=g) < 0.02 / 8).float().unsqueeze(1)
     gap = torch.nn.functional.max_pool1d(torch.nn.functional.pad(start, (7, 0)), 8, 1).squeeze(1) > 0
     d[i0:i1][gap] = ord("-")
+# FBG_STAR_SHARED=d: a part of the gap runs is shared -- at one column in 2000 (FBG_STAR_SHARED_RATE) a run of 8 starts in a fraction d of the rows at once
+# (deletions that hundreds of rows have in common: the groups whose odd members are compared pair by pair, k_sp_odd_slow)
+shared = float(os.environ.get("FBG_STAR_SHARED", 0))
+if shared > 0:
+    ev = (torch.rand((n,), device="cuda", generator=g) < float(os.environ.get("FBG_STAR_SHARED_RATE", 1 / 2000))).unsqueeze(0)
+    for i0 in range(0, m, 50):
+        i1 = min(m, i0 + 50)
+        start = ((torch.rand((i1 - i0, n), device="cuda", generator=g) < shared) & ev).float().unsqueeze(1)
+        gap = torch.nn.functional.max_pool1d(torch.nn.functional.pad(start, (7, 0)), 8, 1).squeeze(1) > 0
+        d[i0:i1][gap] = ord("-")
 d = d.reshape(-1)
 with F.Engine(0) as eng:
     eng.set_option("span_scan", opt)
@@ -47,7 +57,7 @@ with F.Engine(0) as eng:
         eng.sync()
         dt = time.perf_counter() - t0
         print(json.dumps({"ms": round(1e3 * dt, 2), "blocks": blocks, "index_kind": eng.get_option("index_kind"),
-                          "span": eng.get_option("span_scan_used"), "work": eng.get_option("span_scan_work"), "G": eng.get_option("span_groups"), "odd": eng.get_option("span_odd_groups"), "irr": eng.get_option("span_irregular"), "chain": eng.get_option("span_chain"), "slow": eng.get_option("span_slow_groups"), "dp_kind": eng.get_option("dp_kind"),
+                          "span": eng.get_option("span_scan_used"), "work": eng.get_option("span_scan_work"), "G": eng.get_option("span_groups"), "odd": eng.get_option("span_odd_groups"), "irr": eng.get_option("span_irregular"), "chain": eng.get_option("span_chain"), "slow": eng.get_option("span_slow_groups"), "decline": eng.get_option("span_decline"), "dp_kind": eng.get_option("dp_kind"),
                           "stages": {k: round(v[0], 2) for k, v in eng.stage_ms().items()},
                           "f_sum": int(d_f.sum())}), flush=True)
         if os.environ.get("FBG_PHASES"):                      # a library built with -DSP_PHASE_TIMERS: cycles of k_sp_odd_pairs<28,64> per phase
